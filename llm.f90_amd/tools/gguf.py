@@ -1,0 +1,450 @@
+"""GGUF writer / reader and deterministic synthetic Llama weights.
+
+Why this exists: there is no network, so no real model file.  Every parity and bench
+run uses a synthetic Llama-shaped GGUF whose bytes are a pure function of
+(shape, seed) -- a counter-based integer hash, no library RNG -- so the file written
+in the build container, the file re-generated on the GPU box and the arrays handed
+straight to the C-ABI are bit-identical.
+
+The byte layout written here is the one the reference loader accepts
+(/root/reference/read_ggml.f90:112 header, :129-158 KV pairs, :663-685 value types,
+:706-718 tensor infos, :176-192 zero padding to `alignment`, :600-620 tensor reads,
+:238-410 tensor names).  The reader additionally understands every GGUF scalar KV
+type and ggml tensor types 0 (f32), 1 (f16) and 2 (q4_0); q4_0 is the public ggml
+block format (32 weights = one f16 scale d + 16 bytes; low nibbles are elements
+0..15, high nibbles elements 16..31; value = (nibble - 8) * d) -- third-party (ggml)
+knowledge, not citable inside /root/reference.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+GGUF_MAGIC = 0x46554747  # "GGUF" little endian == 1179993927 (read_ggml.f90:122)
+GGML_F32, GGML_F16, GGML_Q4_0 = 0, 1, 2
+QK4_0 = 32
+Q4_0_BLOCK_BYTES = 18
+
+# GGUF metadata value types
+T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I64, T_F64 = range(13)
+_SCALAR_FMT = {T_U8: "<B", T_I8: "<b", T_U16: "<H", T_I16: "<h", T_U32: "<I", T_I32: "<i",
+               T_F32: "<f", T_BOOL: "<B", T_U64: "<Q", T_I64: "<q", T_F64: "<d"}
+
+
+@dataclass
+class LlamaShape:
+    emb_dim: int
+    hidden_dim: int
+    n_layers: int
+    n_heads: int
+    n_kv_heads: int
+    vocab_size: int
+    seq_len: int
+
+    @property
+    def head_size(self) -> int:
+        return self.emb_dim // self.n_heads
+
+    @property
+    def kv_dim(self) -> int:
+        return self.n_kv_heads * self.head_size
+
+    def matmul_params(self) -> int:
+        E, H, L, KV, V = self.emb_dim, self.hidden_dim, self.n_layers, self.kv_dim, self.vocab_size
+        return L * (E * (E + 2 * KV) + E * E + 3 * E * H) + V * E
+
+
+# Shapes named by BASELINE.json `configs` plus the small parity shapes.
+SHAPES: Dict[str, LlamaShape] = {
+    # reference compile-time parameters, /root/reference/llama2.f90:102-108
+    "tinyllama": LlamaShape(2048, 5632, 22, 32, 4, 32000, 2048),
+    "llama2-7b": LlamaShape(4096, 11008, 32, 32, 32, 32000, 2048),
+    "llama2-70b": LlamaShape(8192, 28672, 80, 64, 8, 32000, 2048),
+    # parity shapes (oracle / reference finish in milliseconds)
+    "tiny-gqa": LlamaShape(128, 256, 2, 8, 2, 300, 64),      # hs 16, kv_mul 4
+    "tiny-mha": LlamaShape(128, 352, 3, 4, 4, 512, 48),      # hs 32, kv_mul 1
+    "tiny-hs64": LlamaShape(256, 704, 2, 4, 2, 1000, 96),    # hs 64 like TinyLlama, kv_mul 2
+    "tiny-hs128": LlamaShape(512, 1376, 2, 4, 4, 640, 40),   # hs 128 like Llama-2-7B
+    "tiny-70bish": LlamaShape(1024, 3584, 3, 8, 1, 800, 64),  # E:nh:nkv = 70B ratios / 8, hs 128
+}
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic values
+# ----------------------------------------------------------------------------------------------
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def det_uniform(seed: int, stream: int, n: int, lo: float, hi: float, chunk: int = 1 << 24) -> np.ndarray:
+    """n float32 values uniform in [lo, hi): element i = hash(seed, stream, i). Pure integer
+    arithmetic up to the final affine map, so identical on every numpy build."""
+    out = np.empty(n, dtype=np.float32)
+    base = np.uint64((seed * 0x9E3779B1 + stream * 0x85EBCA77) & 0xFFFFFFFF) << np.uint64(32)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        idx = np.arange(s, e, dtype=np.uint64) + base
+        u24 = (_splitmix64(idx) >> np.uint64(40)).astype(np.float32)  # exact: < 2**24
+        out[s:e] = u24 * np.float32(1.0 / (1 << 24))
+    out *= np.float32(hi - lo)
+    out += np.float32(lo)
+    return out
+
+
+def tensor_names(shape: LlamaShape) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(name, numpy shape [out, in] or [n], kind) in file order. Names: read_ggml.f90:238-406."""
+    E, H, KV, V = shape.emb_dim, shape.hidden_dim, shape.kv_dim, shape.vocab_size
+    out = [("token_embd.weight", (V, E), "emb")]
+    for i in range(shape.n_layers):
+        p = f"blk.{i}."
+        out += [
+            (p + "attn_norm.weight", (E,), "norm"),
+            (p + "attn_q.weight", (E, E), "mat"),
+            (p + "attn_k.weight", (KV, E), "mat"),
+            (p + "attn_v.weight", (KV, E), "mat"),
+            (p + "attn_output.weight", (E, E), "mat"),
+            (p + "ffn_norm.weight", (E,), "norm"),
+            (p + "ffn_gate.weight", (H, E), "mat"),
+            (p + "ffn_down.weight", (E, H), "mat"),
+            (p + "ffn_up.weight", (H, E), "mat"),
+        ]
+    out += [("output_norm.weight", (E,), "norm"), ("output.weight", (V, E), "mat")]
+    return out
+
+
+def synth_tensor(shape: LlamaShape, seed: int, index: int, dims: Tuple[int, ...], kind: str) -> np.ndarray:
+    """Deterministic f32 tensor. Matrices: uniform with variance 1/in_features (so activations
+    stay O(1) through the stack); embeddings: uniform(-1,1); norm gains: 1 +- 0.1."""
+    n = int(np.prod(dims))
+    if kind == "norm":
+        v = det_uniform(seed, index, n, 0.9, 1.1)
+    elif kind == "emb":
+        v = det_uniform(seed, index, n, -1.0, 1.0)
+    else:
+        a = float(np.sqrt(3.0 / dims[-1]))
+        v = det_uniform(seed, index, n, -a, a)
+    return v.reshape(dims)
+
+
+# ----------------------------------------------------------------------------------------------
+# f16 / q4_0 encodings of an f32 matrix
+# ----------------------------------------------------------------------------------------------
+def quantize_q4_0(w: np.ndarray) -> np.ndarray:
+    """ggml q4_0 reference quantiser: per 32-block, d = max_signed/-8, q = clamp(round(x/d)+8, 0, 15).
+    Returns uint8 array [..., nblocks*18]."""
+    assert w.shape[-1] % QK4_0 == 0
+    blocks = w.reshape(-1, QK4_0).astype(np.float32)
+    idx = np.argmax(np.abs(blocks), axis=1)
+    mx = blocks[np.arange(blocks.shape[0]), idx]
+    d = (mx / np.float32(-8.0)).astype(np.float32)
+    inv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0.0)).astype(np.float32)
+    q = np.minimum(15, (blocks * inv[:, None] + np.float32(8.5)).astype(np.int32)).astype(np.uint8)
+    out = np.empty((blocks.shape[0], Q4_0_BLOCK_BYTES), dtype=np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:] = q[:, :16] | (q[:, 16:] << 4)
+    return out.reshape(*w.shape[:-1], w.shape[-1] // QK4_0 * Q4_0_BLOCK_BYTES)
+
+
+def dequantize_q4_0(raw: np.ndarray, cols: int) -> np.ndarray:
+    """uint8 [..., cols/32*18] -> f32 [..., cols]."""
+    b = raw.reshape(-1, Q4_0_BLOCK_BYTES)
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)  # [nb,1]
+    qs = b[:, 2:]
+    lo = (qs & 0x0F).astype(np.int32) - 8
+    hi = (qs >> 4).astype(np.int32) - 8
+    vals = np.concatenate([lo, hi], axis=1).astype(np.float32) * d
+    return vals.reshape(*raw.shape[:-1], cols)
+
+
+def encode(w: np.ndarray, ggml_type: int) -> np.ndarray:
+    if ggml_type == GGML_F32:
+        return np.ascontiguousarray(w, dtype="<f4")
+    if ggml_type == GGML_F16:
+        return np.ascontiguousarray(w.astype("<f2"))
+    if ggml_type == GGML_Q4_0:
+        return quantize_q4_0(w)
+    raise ValueError(ggml_type)
+
+
+def decode(raw: np.ndarray, ggml_type: int, cols: int) -> np.ndarray:
+    """Exact f32 value of stored weights (f16 -> f32 is exact; q4_0 = (nibble-8)*d in f32)."""
+    if ggml_type == GGML_F32:
+        return raw.astype(np.float32, copy=False)
+    if ggml_type == GGML_F16:
+        return raw.view("<f2").astype(np.float32) if raw.dtype != np.float16 else raw.astype(np.float32)
+    if ggml_type == GGML_Q4_0:
+        return dequantize_q4_0(raw, cols)
+    raise ValueError(ggml_type)
+
+
+# ----------------------------------------------------------------------------------------------
+# fused in-memory layout == weight_module.f90:13-26 (Fortran (in,rows,L) == C [L][rows][in])
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class FusedWeights:
+    shape: LlamaShape
+    ggml_type: int
+    token_embedding_table: np.ndarray = None  # [V][E] f32 (always f32: it is gathered, not streamed)
+    rms_att_weight: np.ndarray = None         # [L][E] f32
+    rms_ffn_weight: np.ndarray = None         # [L][E] f32
+    rms_final_weight: np.ndarray = None       # [E]   f32
+    wqkv: np.ndarray = None                   # [L][E+2KV][E*]   (* = encoded row bytes for f16/q4_0)
+    wo: np.ndarray = None                     # [L][E][E*]
+    w13: np.ndarray = None                    # [L][2H][E*]  rows 0..H-1 gate, H.. up (read_ggml.f90:347,376)
+    w2: np.ndarray = None                     # [L][E][H*]
+    wcls: np.ndarray = None                   # [V][E*]
+
+    def as_f32(self) -> "FusedWeights":
+        """Same weights with every matrix decoded to f32 (what an f32 reference run consumes)."""
+        s, t = self.shape, self.ggml_type
+        return FusedWeights(s, GGML_F32, self.token_embedding_table, self.rms_att_weight, self.rms_ffn_weight,
+                            self.rms_final_weight, decode(self.wqkv, t, s.emb_dim), decode(self.wo, t, s.emb_dim),
+                            decode(self.w13, t, s.emb_dim), decode(self.w2, t, s.hidden_dim),
+                            decode(self.wcls, t, s.emb_dim))
+
+
+def synth_fused(shape: LlamaShape, seed: int, ggml_type: int = GGML_F32) -> FusedWeights:
+    """Build the fused arrays directly (no file). Tensor values are identical to write_synth_gguf's."""
+    E, H, L, KV, V = shape.emb_dim, shape.hidden_dim, shape.n_layers, shape.kv_dim, shape.vocab_size
+    fw = FusedWeights(shape, ggml_type)
+    enc_cols = lambda k: encode(np.zeros((1, k), np.float32), ggml_type).shape[-1]
+    dt = {GGML_F32: np.float32, GGML_F16: np.float16, GGML_Q4_0: np.uint8}[ggml_type]
+    fw.rms_att_weight = np.empty((L, E), np.float32)
+    fw.rms_ffn_weight = np.empty((L, E), np.float32)
+    fw.wqkv = np.empty((L, E + 2 * KV, enc_cols(E)), dt)
+    fw.wo = np.empty((L, E, enc_cols(E)), dt)
+    fw.w13 = np.empty((L, 2 * H, enc_cols(E)), dt)
+    fw.w2 = np.empty((L, E, enc_cols(H)), dt)
+    for index, (name, dims, kind) in enumerate(tensor_names(shape)):
+        t = synth_tensor(shape, seed, index, dims, kind)
+        if name == "token_embd.weight":
+            fw.token_embedding_table = t
+        elif name == "output_norm.weight":
+            fw.rms_final_weight = t
+        elif name == "output.weight":
+            fw.wcls = encode(t, ggml_type)
+        else:
+            _, li, rest = name.split(".", 2)
+            li = int(li)
+            if rest == "attn_norm.weight":
+                fw.rms_att_weight[li] = t
+            elif rest == "ffn_norm.weight":
+                fw.rms_ffn_weight[li] = t
+            elif rest == "attn_q.weight":
+                fw.wqkv[li, 0:E] = encode(t, ggml_type)
+            elif rest == "attn_k.weight":
+                fw.wqkv[li, E:E + KV] = encode(t, ggml_type)
+            elif rest == "attn_v.weight":
+                fw.wqkv[li, E + KV:E + 2 * KV] = encode(t, ggml_type)
+            elif rest == "attn_output.weight":
+                fw.wo[li] = encode(t, ggml_type)
+            elif rest == "ffn_gate.weight":
+                fw.w13[li, 0:H] = encode(t, ggml_type)
+            elif rest == "ffn_up.weight":
+                fw.w13[li, H:2 * H] = encode(t, ggml_type)
+            elif rest == "ffn_down.weight":
+                fw.w2[li] = encode(t, ggml_type)
+    return fw
+
+
+# ----------------------------------------------------------------------------------------------
+# writer
+# ----------------------------------------------------------------------------------------------
+def _w_str(f, s: bytes):
+    f.write(struct.pack("<Q", len(s)))
+    f.write(s)
+
+
+def vocab_strings(V: int) -> List[bytes]:
+    """Unique printable token strings so greedy ids can be parsed back from CLI output.
+    ids 0..2 mimic <unk>/<s>/</s>; single printable ASCII characters get their own tokens so
+    bpe_encode's per-character lookup (llama2.f90:666-668) finds prompt characters."""
+    out = []
+    for i in range(V):
+        if i == 0:
+            out.append(b"<unk>")
+        elif i == 1:
+            out.append(b"<s>")
+        elif i == 2:
+            out.append(b"</s>")
+        elif 3 <= i < 3 + 95 and V >= 200:
+            out.append(bytes([32 + i - 3]))
+        else:
+            out.append(b"<%05d>" % i)
+    return out
+
+
+def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = GGML_F32,
+                     alignment: int = 32, version: int = 3) -> None:
+    """Synthetic Llama GGUF. With ggml_type == GGML_F32 the reference loader reads it as is."""
+    names = tensor_names(shape)
+    vocab = vocab_strings(shape.vocab_size)
+    kvs = [
+        ("general.architecture", T_STR, b"llama"),
+        ("general.name", T_STR, b"synthetic"),
+        ("llama.context_length", T_U32, shape.seq_len),
+        ("llama.embedding_length", T_U32, shape.emb_dim),
+        ("llama.block_count", T_U32, shape.n_layers),
+        ("llama.feed_forward_length", T_U32, shape.hidden_dim),
+        ("llama.attention.head_count", T_U32, shape.n_heads),
+        ("llama.attention.head_count_kv", T_U32, shape.n_kv_heads),
+        ("llama.attention.layer_norm_rms_epsilon", T_F32, 1e-5),
+        ("general.alignment", T_U32, alignment),
+        ("tokenizer.ggml.model", T_STR, b"llama"),
+    ]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIqq", GGUF_MAGIC, version, len(names), len(kvs) + 2))
+        for k, t, v in kvs:
+            _w_str(f, k.encode())
+            f.write(struct.pack("<I", t))
+            if t == T_STR:
+                _w_str(f, v)
+            else:
+                f.write(struct.pack(_SCALAR_FMT[t], v))
+        _w_str(f, b"tokenizer.ggml.tokens")
+        f.write(struct.pack("<IIQ", T_ARR, T_STR, len(vocab)))
+        for s in vocab:
+            _w_str(f, s)
+        _w_str(f, b"tokenizer.ggml.scores")
+        f.write(struct.pack("<IIQ", T_ARR, T_F32, len(vocab)))
+        f.write((-np.arange(len(vocab), dtype="<f4")).tobytes())
+        # tensor infos
+        offset = 0
+        infos = []
+        for name, dims, kind in names:
+            tt = ggml_type if kind == "mat" else GGML_F32
+            nbytes = encode(np.zeros((1, dims[-1]), np.float32), tt).nbytes * (int(np.prod(dims[:-1])) if len(dims) > 1 else 1)
+            infos.append((tt, offset, nbytes))
+            _w_str(f, name.encode())
+            f.write(struct.pack("<I", len(dims)))
+            for d in reversed(dims):  # GGUF ne[0] = innermost = in_features
+                f.write(struct.pack("<Q", d))
+            f.write(struct.pack("<IQ", tt, offset))
+            offset += (nbytes + alignment - 1) // alignment * alignment
+        pad = (-f.tell()) % alignment
+        f.write(b"\0" * pad)
+        data_start = f.tell()
+        for index, ((name, dims, kind), (tt, off, nbytes)) in enumerate(zip(names, infos)):
+            assert f.tell() == data_start + off
+            t = synth_tensor(shape, seed, index, dims, kind)
+            raw = encode(t, tt)
+            assert raw.nbytes == nbytes
+            f.write(raw.tobytes())
+            f.write(b"\0" * ((-nbytes) % alignment))
+
+
+# ----------------------------------------------------------------------------------------------
+# reader (python mirror of the host loader; used by tests to cross-check the Fortran loader)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class GGUFFile:
+    version: int
+    kv: Dict[str, object]
+    tensors: Dict[str, Tuple[Tuple[int, ...], int, int]]  # name -> (dims innermost-first, type, offset)
+    data_start: int
+    path: str = ""
+    alignment: int = 32
+
+    def shape(self) -> LlamaShape:
+        k = self.kv
+        return LlamaShape(k["llama.embedding_length"], k["llama.feed_forward_length"], k["llama.block_count"],
+                          k["llama.attention.head_count"], k.get("llama.attention.head_count_kv",
+                                                                 k["llama.attention.head_count"]),
+                          len(k["tokenizer.ggml.tokens"]), k["llama.context_length"])
+
+    def read_tensor(self, name: str) -> Tuple[np.ndarray, int]:
+        dims, tt, off = self.tensors[name]
+        cols = dims[0]
+        rows = int(np.prod(dims[1:])) if len(dims) > 1 else 1
+        row_bytes = {GGML_F32: 4 * cols, GGML_F16: 2 * cols, GGML_Q4_0: cols // 32 * 18}[tt]
+        with open(self.path, "rb") as f:
+            f.seek(self.data_start + off)
+            raw = np.frombuffer(f.read(rows * row_bytes), dtype=np.uint8)
+        dt = {GGML_F32: "<f4", GGML_F16: "<f2", GGML_Q4_0: np.uint8}[tt]
+        arr = raw.view(dt)
+        return (arr.reshape(rows, -1) if len(dims) > 1 else arr), tt
+
+
+def _r(f, fmt):
+    sz = struct.calcsize(fmt)
+    return struct.unpack(fmt, f.read(sz))
+
+
+def _r_str(f) -> bytes:
+    (n,) = _r(f, "<Q")
+    return f.read(n)
+
+
+def _r_val(f, t):
+    if t == T_STR:
+        return _r_str(f)
+    if t == T_ARR:
+        et, n = _r(f, "<IQ")
+        if et in _SCALAR_FMT:
+            dt = np.dtype(_SCALAR_FMT[et])
+            return np.frombuffer(f.read(dt.itemsize * n), dtype=dt)
+        return [_r_val(f, et) for _ in range(n)]
+    return _r(f, _SCALAR_FMT[t])[0]
+
+
+def read_gguf(path: str) -> GGUFFile:
+    with open(path, "rb") as f:
+        magic, version, n_tensors, n_kv = _r(f, "<IIqq")
+        if magic != GGUF_MAGIC:
+            raise ValueError("Magic numbers do not match")
+        kv = {}
+        for _ in range(n_kv):
+            key = _r_str(f).decode()
+            (t,) = _r(f, "<I")
+            kv[key] = _r_val(f, t)
+        tensors = {}
+        for _ in range(n_tensors):
+            name = _r_str(f).decode()
+            (nd,) = _r(f, "<I")
+            dims = tuple(_r(f, "<Q")[0] for _ in range(nd))
+            tt, off = _r(f, "<IQ")
+            tensors[name] = (dims, tt, off)
+        alignment = int(kv.get("general.alignment", 32))
+        data_start = (f.tell() + alignment - 1) // alignment * alignment
+    return GGUFFile(version, kv, tensors, data_start, path, alignment)
+
+
+def load_fused(path: str) -> FusedWeights:
+    """Read a Llama GGUF into the fused weight_module layout (python mirror of load_ggml)."""
+    g = read_gguf(path)
+    s = g.shape()
+    E, H, L, KV = s.emb_dim, s.hidden_dim, s.n_layers, s.kv_dim
+    _, mt = g.read_tensor("blk.0.attn_q.weight")
+    fw = FusedWeights(s, mt)
+    emb, et = g.read_tensor("token_embd.weight")
+    fw.token_embedding_table = decode(emb, et, E)
+    fw.rms_final_weight = g.read_tensor("output_norm.weight")[0].astype(np.float32)
+    fw.wcls = g.read_tensor("output.weight")[0]
+    cat = lambda parts: np.ascontiguousarray(np.concatenate(parts, axis=0))
+    fw.rms_att_weight = np.stack([g.read_tensor(f"blk.{i}.attn_norm.weight")[0] for i in range(L)]).astype(np.float32)
+    fw.rms_ffn_weight = np.stack([g.read_tensor(f"blk.{i}.ffn_norm.weight")[0] for i in range(L)]).astype(np.float32)
+    fw.wqkv = np.stack([cat([g.read_tensor(f"blk.{i}.attn_{n}.weight")[0] for n in "qkv"]) for i in range(L)])
+    fw.wo = np.stack([g.read_tensor(f"blk.{i}.attn_output.weight")[0] for i in range(L)])
+    fw.w13 = np.stack([cat([g.read_tensor(f"blk.{i}.ffn_{n}.weight")[0] for n in ("gate", "up")]) for i in range(L)])
+    fw.w2 = np.stack([g.read_tensor(f"blk.{i}.ffn_down.weight")[0] for i in range(L)])
+    return fw
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser(description="write a synthetic Llama GGUF")
+    ap.add_argument("out")
+    ap.add_argument("--shape", default="tiny-gqa", choices=sorted(SHAPES))
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--type", default="f32", choices=["f32", "f16", "q4_0"])
+    a = ap.parse_args()
+    write_synth_gguf(a.out, SHAPES[a.shape], a.seed, {"f32": 0, "f16": 1, "q4_0": 2}[a.type])
+    print("wrote", a.out)

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REAL REFERENCE (build container only).
+
+The reference has no tests and no golden vectors, so the parity pin is
+the reference itself: oracle/build_ref.sh compiles /root/reference's llama2.f90 (dims rewritten,
+a 2-line logits dump inserted) with amdflang into oracle/_ref/, this script runs it on synthetic
+GGUFs that are a pure function of (shape, seed) (llm.f90_amd/tools/gguf.py) and commits only
+DATA: the reference's logits per position, its greedy token ids and its stdout.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Nothing here runs on the GPU box (no /root/reference there); tests read the .npz files.
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import llm_f90_amd  # noqa: E402,F401
+from llm_f90_amd.tools import gguf  # noqa: E402
+
+SEED = 20260928
+# (shape name, n positions, prompt)
+CASES = [
+    ("tiny-gqa", 24, ""),
+    ("tiny-gqa", 20, "hi there"),
+    ("tiny-mha", 16, ""),
+    ("tiny-hs64", 24, ""),
+    ("tiny-hs128", 12, ""),
+    ("tiny-70bish", 12, ""),
+]
+
+
+def prompt_ids(prompt: str):
+    """1-based ids bpe_encode (llama2.f90:658-724) yields on the synthetic vocab: one token per
+    character (printable ASCII c -> 0-based id 3 + ord(c) - 32); no merged token exists."""
+    return [3 + ord(c) - 32 + 1 for c in prompt]
+
+
+def main():
+    outdir = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
+    with tempfile.TemporaryDirectory() as td:
+        for name, n, prompt in CASES:
+            s = gguf.SHAPES[name]
+            path = os.path.join(td, name + ".gguf")
+            gguf.write_synth_gguf(path, s, SEED)
+            exe = os.path.join(ROOT, "oracle", "_ref", "llm_ref_" + name)
+            cmd = [exe, "-m", path, "-n", str(n), "-t", "0"] + (["-p", prompt] if prompt else [])
+            r = subprocess.run(cmd, cwd=td, capture_output=True, check=True)
+            logits = np.fromfile(os.path.join(td, "logits.bin"), dtype="<f4").reshape(n, s.vocab_size)
+            pids = prompt_ids(prompt)
+            toks = [pids[i] if i < len(pids) else int(np.argmax(logits[i])) + 1 for i in range(n)]
+            vocab = gguf.vocab_strings(s.vocab_size)
+            text = b"".join(vocab[t - 1] for t in toks)
+            lines = r.stdout.split(b"\n")
+            assert lines[0].strip().startswith(b"data offset"), lines[0]
+            assert lines[1].rstrip(b" ") == text, (lines[1], text)   # reference printed the same tokens
+            srt = np.sort(logits, axis=1)
+            tag = name + ("-prompt" if prompt else "")
+            np.savez_compressed(os.path.join(outdir, tag + ".npz"), shape=name, seed=SEED, n=n, prompt=prompt,
+                                prompt_ids=np.asarray(pids, np.int32), logits=logits,
+                                tokens=np.asarray(toks, np.int32), stdout=np.frombuffer(r.stdout, np.uint8),
+                                top1_margin=(srt[:, -1] - srt[:, -2]))
+            print(f"{tag}: n={n} V={s.vocab_size} max|logit|={np.abs(logits).max():.3f} "
+                  f"min top-1 margin={np.min(srt[:, -1] - srt[:, -2]):.4f}")
+
+
+if __name__ == "__main__":
+    main()
