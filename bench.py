@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- tokens/sec of the llm.f90 decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" = one token through the whole forward pass (`transformer`, /root/reference/llama2.f90:480-640)
+via the C-ABI entry llmk_forward, weights already resident in HBM; logits (V floats) are handed back
+to the host every step exactly as the reference loop consumes them (llama2.f90:380-393), and the next
+token is the greedy argmax.  Workload at N=1: BASELINE.json configs[1], TinyLlama-1.1B f32 decode,
+synthetic weights (no model file offline), positions 1..W+K like `./llm -n 256 -t 0`.
+
+N>1: the path does not shard for a 1.1B model ("replicas only"): N independent
+replicas, one process per GPU (launched by torch.distributed.run), barrier on both sides of the
+timed region, max over ranks, value = total tokens of all replicas / that time ("weak").
+
+Prints ONE JSON line on rank 0, with `roofline` for the dominant kernel (the fused w1|w3 GEMV) and
+`cpu_baseline` (the real reference binary from oracle/_ref when present, else the C port).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import llm_f90_amd  # noqa: E402,F401
+from llm_f90_amd import llmk  # noqa: E402
+from llm_f90_amd.tools import gguf  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+SEED = 20260928
+KERNEL_NAMES = {0: "qkv", 1: "attn", 2: "wo", 3: "w13", 4: "w2", 5: "cls"}
+
+
+def bytes_per_token(s: gguf.LlamaShape, wtype: int, mean_pos: float) -> float:
+    """Algorithmic HBM bytes of one token (SURVEY.md 8d / BASELINE.md section 3)."""
+    per_w = {0: 4.0, 1: 2.0, 2: 18.0 / 32.0}[wtype]
+    E, L, KV, V = s.emb_dim, s.n_layers, s.kv_dim, s.vocab_size
+    return (s.matmul_params() * per_w            # every matmul weight once
+            + (2 * L + 1) * E * 4                # rmsnorm gains
+            + E * 4                              # embedding row
+            + 2 * L * KV * 4 * mean_pos          # KV-cache read
+            + 2 * L * KV * 4                     # KV-cache write
+            + V * 4)                             # logits write
+
+
+def cpu_baseline(fw, shape_name: str, wtype: int, n_ref: int = 24):
+    """Reference timed on this box's host cores, 1 thread, bounded sample (10-30 s of CPU work)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "llm_ref")
+    if shape_name == "tinyllama" and wtype == 0 and os.path.exists(ref):
+        # the REAL reference (unmodified llama2.f90, dims hard-coded to TinyLlama) on the same weights
+        try:
+            with tempfile.TemporaryDirectory(dir=os.environ.get("LLMK_TMP", "/tmp")) as td:
+                path = os.path.join(td, "synthetic-tinyllama-f32.gguf")
+                gguf.write_gguf(path, fw)
+                cmd = [ref, "-m", path, "-n", str(n_ref), "-t", "0"]
+                if subprocess.run(["which", "taskset"], capture_output=True).returncode == 0:
+                    cmd = ["taskset", "-c", "0"] + cmd
+                r = subprocess.run(cmd, capture_output=True, timeout=600, cwd=td)
+                m = re.search(rb"([0-9.Ee+-]+)\s*tokens/second", r.stdout)
+                if r.returncode == 0 and m:
+                    return {"value": float(m.group(1)), "unit": "tokens/s", "cores": 1, "kind": "reference",
+                            "sample": f"oracle/_ref/llm_ref (real reference, amdflang -O3 -march=native -ffast-math "
+                                      f"-funroll-loops) -n {n_ref} -t 0 on the same synthetic GGUF, 1 thread pinned; "
+                                      f"host has {os.cpu_count()} logical cores"}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write(f"[bench] reference baseline failed: {e}\n")
+    from oracle.oracle import Oracle
+    o = Oracle(fw.as_f32(), "fast")
+    n = 6 if fw.shape.matmul_params() > 5e8 else 64
+    o.forward(2, 1)
+    t0 = time.perf_counter()
+    tok = 2
+    for pos in range(2, n + 2):
+        tok = int(np.argmax(o.forward(tok, pos))) + 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "tokens/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/llm_oracle.c (gcc -O3 -march=native -ffast-math -funroll-loops), {n} tokens, 1 thread; "
+                      f"host has {os.cpu_count()} logical cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=248)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--shape", default="tinyllama", choices=sorted(gguf.SHAPES))
+    ap.add_argument("--type", default="f32", choices=["f32", "f16", "q4_0"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--greedy-on-device", action="store_true", help="time llmk_forward_greedy instead")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    shape = gguf.SHAPES[a.shape]
+    wtype = {"f32": 0, "f16": 1, "q4_0": 2}[a.type]
+    K, W = a.steps, a.warmup
+    if W + K > shape.seq_len:
+        raise SystemExit(f"warmup+steps must be <= seq_len {shape.seq_len}")
+
+    t0 = time.perf_counter()
+    fw = gguf.synth_fused(shape, SEED, wtype)
+    t_gen = time.perf_counter() - t0
+    m = llmk.Llmk(fw, device=local)
+    t_up = time.perf_counter() - t0 - t_gen
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    step = m.forward_greedy if a.greedy_on_device else None
+    token = 2
+    for pos in range(1, W + 1):  # untimed warm-up (first call also captures the hipGraph)
+        if step:
+            token = step(token, pos)
+        else:
+            token = int(np.argmax(m.forward(token, pos))) + 1
+    barrier()
+    lib, h, lg = llmk.lib(), m._h, m._logits
+    import ctypes as C
+    lgp = lg.ctypes.data_as(C.POINTER(C.c_float))
+    nxt = C.c_int(0)
+    t_start = time.perf_counter()
+    for pos in range(W + 1, W + K + 1):  # each llmk_forward returns after its stream sync
+        if step:
+            rc = lib.llmk_forward_greedy(h, token, pos, C.byref(nxt))
+            token = nxt.value
+        else:
+            rc = lib.llmk_forward(h, token, pos, lgp)
+            token = int(lg.argmax()) + 1
+        if rc:
+            raise SystemExit(f"llmk_forward failed: {rc}")
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not np.all(np.isfinite(lg)):
+        raise SystemExit("non-finite logits")
+
+    tok_s = world * K / elapsed
+    mean_pos = W + (K + 1) / 2.0
+    bpt = bytes_per_token(shape, wtype, mean_pos)
+
+    out = {
+        "metric": "tokens/sec TinyLlama-1.1B decode" if a.shape == "tinyllama" else f"tokens/sec {a.shape} decode",
+        "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.type, "data": "synthetic",
+        "config": {"workload": f"{a.shape} {a.type} decode, greedy, positions {W + 1}..{W + K} (./llm -n {W + K} -t 0)",
+                   "consumer": "device argmax (llmk_forward_greedy)" if step else "logits to host + host argmax (llmk_forward)",
+                   "parallelism": "replicas" if world > 1 else "single GPU", "seed": SEED},
+    }
+    if rank == 0:
+        # dominant kernel: the fused w1|w3 GEMV (92.3 MB of the 176.2 MB a layer streams)
+        kern = 3
+        m.reset()
+        ms, b = m.time_kernel(kern, 10 * shape.n_layers)
+        per_k = {}
+        for k in KERNEL_NAMES:
+            kms, kb = m.time_kernel(k, 5 * shape.n_layers)
+            per_k[KERNEL_NAMES[k]] = {"us": round(kms * 1000, 3), "GBps": round(kb / kms / 1e6, 1)}
+        ach = b / (ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<f32,SWIGLU,NORM> (rmsnorm+w1|w3 GEMV+SwiGLU)",
+                           "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "bytes_per_launch": b, "us_per_launch": ms * 1000, "kernels": per_k}
+        tok_gbs = bpt * (tok_s / world) / 1e9
+        out["token_roofline"] = {"bytes_per_token": bpt, "achieved": tok_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": tok_gbs / HBM_PEAK_GBS, "roofline_tok_s": HBM_PEAK_GBS * 1e9 / bpt}
+        out["setup_s"] = {"weights_gen": round(t_gen, 1), "upload": round(t_up, 1)}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fw, a.shape, wtype)
+        print(json.dumps(out), flush=True)
+    m.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,150 @@
+/*
+ * llmk -- C-ABI of the MI355X-native (gfx950) decode hot path of rbitr/llm.f90.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own: the
+ * seam is the single Fortran call
+ *
+ *     logits = transformer(token,pos,s,weights)            /root/reference/llama2.f90:380
+ *     function transformer(token, pos, s, w) result(logits) /root/reference/llama2.f90:480-485
+ *
+ * plus the weights it reads (type TransformerWeights, /root/reference/weight_module.f90:13-26)
+ * and the per-sequence state it mutates (type RunState, weight_module.f90:33-40, allocated at
+ * llama2.f90:311-319).  A Fortran host binds these entry points with ISO_C_BINDING
+ * (llm.f90_amd/host/llmk_binding.f90; the stub a reference maintainer would add is in
+ * INTEGRATION.md); tests/ and bench.py bind the same symbols with ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns 0 on success, nonzero on error
+ *     (a LLMK_E_* code or, above 1000, 1000 + the hipError_t).  No exceptions, no exit().
+ *     The reference's own convention is print + stop (read_ggml.f90:122-125); the host does that.
+ *   - token and pos are 1-BASED exactly as at llama2.f90:380 (BOS is token 2, llama2.f90:376).
+ *   - weights are COPIED to the device by llmk_upload; host arrays may be freed afterwards.
+ *   - array layout is the reference's: Fortran (in, rows, layer) column-major == C
+ *     [layer][row][in].  No transposition anywhere.
+ *   - one ctx == one sequence (KV cache inside); calls on a ctx are serialised by the caller,
+ *     like the reference's non-reentrant `transformer` (it mutates `s`).
+ *   - there is NO CPU fallback: without a usable HIP device llmk_create fails.
+ */
+#ifndef LLMK_H
+#define LLMK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ggml tensor types accepted for the matmul weights (GGUF tensor-info `type`,
+ * read_ggml.f90:613-635 reads 0 and 1; 2 is the q4_0 of the four_bit_dev branch). */
+#define LLMK_TYPE_F32 0
+#define LLMK_TYPE_F16 1
+#define LLMK_TYPE_Q4_0 2
+
+/* tensor ids for llmk_upload: one per component of TransformerWeights (weight_module.f90:13-26) */
+#define LLMK_TOKEN_EMBEDDING_TABLE 0 /* (E,V)        C [V][E]         always f32            */
+#define LLMK_RMS_ATT_WEIGHT 1        /* (E,L)        C [L][E]         f32                   */
+#define LLMK_RMS_FFN_WEIGHT 2        /* (E,L)        C [L][E]         f32                   */
+#define LLMK_WQKV 3                  /* (E,E+2KV,L)  C [L][E+2KV][E]  rows: Q | K | V       */
+#define LLMK_WO 4                    /* (E,E,L)      C [L][E][E]                            */
+#define LLMK_W13 5                   /* (E,2H,L)     C [L][2H][E]     rows: gate(w1) | up(w3) */
+#define LLMK_W2 6                    /* (H,E,L)      C [L][E][H]                            */
+#define LLMK_RMS_FINAL_WEIGHT 7      /* (E)                           f32                   */
+#define LLMK_WCLS 8                  /* (E,V)        C [V][E]                               */
+#define LLMK_N_TENSORS 9
+
+#define LLMK_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a hipGraph          */
+#define LLMK_FLAG_TIMINGS 2  /* record the reference's 5 section timers (implies NO_GRAPH)      */
+
+/* error codes */
+#define LLMK_OK 0
+#define LLMK_E_ARG 1       /* bad argument (null pointer, id out of range, token/pos out of range) */
+#define LLMK_E_SHAPE 2     /* unsupported or inconsistent model shape                               */
+#define LLMK_E_SIZE 3      /* nbytes does not match the tensor's size for its type                  */
+#define LLMK_E_TYPE 4      /* unsupported ggml type                                                 */
+#define LLMK_E_STATE 5     /* forward before all weights were uploaded                              */
+#define LLMK_E_NODEVICE 6  /* no usable HIP device (there is no CPU fallback)                       */
+#define LLMK_E_NOMEM 7
+#define LLMK_E_HIP 1000    /* 1000 + hipError_t                                                     */
+
+/* Run-time replacement of the reference's compile-time dims (llama2.f90:102-108) and of
+ * type Config (weight_module.f90:28-31). */
+typedef struct llmk_config {
+    int32_t emb_dim;     /* E  */
+    int32_t hidden_dim;  /* H  */
+    int32_t n_layers;    /* L  */
+    int32_t n_heads;     /* nh */
+    int32_t n_kv_heads;  /* nkv */
+    int32_t vocab_size;  /* V  */
+    int32_t seq_len;     /* S: KV-cache capacity (llama2.f90:311-313) */
+    int32_t weight_type; /* LLMK_TYPE_* of wqkv/wo/w13/w2/wcls */
+    int32_t device;      /* HIP device ordinal */
+    int32_t flags;       /* LLMK_FLAG_* */
+} llmk_config;
+
+typedef struct llmk_ctx llmk_ctx;
+
+/* Allocates device weights + RunState (key_cache, value_cache zeroed as at llama2.f90:316-318).
+ * Replaces: the allocations at llama2.f90:311-319 and read_ggml.f90:265-410. */
+int llmk_create(const llmk_config *cfg, llmk_ctx **out);
+
+/* Copy one whole TransformerWeights component to the device.  `host` points at the first
+ * element of the Fortran array (c_loc(w%wqkv) ...); nbytes must equal the full array size for
+ * `ggml_type` (f32: 4 B/weight, f16: 2 B/weight, q4_0: 18 B per 32 weights along `in`).
+ * Norm gains and the embedding table must be f32.  Replaces nothing in the reference (it has no
+ * device); called once after load_ggml returns (llama2.f90:151). */
+int llmk_upload(llmk_ctx *ctx, int tensor_id, const void *host, size_t nbytes, int ggml_type);
+
+/* Same, for `rows` consecutive rows of layer `layer` starting at `row_offset` (lets a loader
+ * stream one GGUF tensor at a time, e.g. attn_k into rows E..E+KV-1 of wqkv, read_ggml.f90:286,
+ * without materialising the fused array on the host). */
+int llmk_upload_rows(llmk_ctx *ctx, int tensor_id, int layer, int row_offset, int rows, const void *host,
+                     size_t nbytes, int ggml_type);
+
+/* RoPE frequency table, n = head_size/2 floats: freqs[j] = 1/10000**((2j+1)/head_size), computed
+ * by the HOST with the reference's own expression (llama2.f90:544-545) so the device angle
+ * pos*freq starts from bit-identical frequencies.  Optional: llmk_create installs the same
+ * table computed with powf. */
+int llmk_set_rope_freqs(llmk_ctx *ctx, const float *freqs, int n);
+
+/* The hot path: one token through the whole stack.  Replaces
+ * `logits = transformer(token,pos,s,weights)` (llama2.f90:380).  token in [1,V], pos in [1,S],
+ * both 1-based; positions must be fed in order 1,2,3,... (each call appends to the KV cache at
+ * pos, llama2.f90:564-565).  logits_out: V floats, caller-owned host memory. */
+int llmk_forward(llmk_ctx *ctx, int token, int pos, float *logits_out);
+
+/* Same pass, but the temperature-0 consumer (`token = maxloc(logits,DIM=1)`, llama2.f90:388) runs
+ * on the device: returns the 1-based argmax (first maximum wins) and skips the logits copy.
+ * SURVEY.md section 8(f) rank 1. */
+int llmk_forward_greedy(llmk_ctx *ctx, int token, int pos, int *next_token);
+
+/* Zero the KV cache (new sequence), as llama2.f90:316-318. */
+int llmk_reset(llmk_ctx *ctx);
+
+/* The reference's five section timers s%times(1:5) (llama2.f90:538,561,599,622,638), accumulated
+ * milliseconds since create/reset; all zero unless LLMK_FLAG_TIMINGS. */
+int llmk_timings(llmk_ctx *ctx, float ms[5]);
+
+/* Measurement hook for bench.py: runs `iters` launches of one kernel of the token pass on the
+ * ctx's stream with HIP events around them and returns the average milliseconds per launch and
+ * the algorithmic bytes one launch moves.  kernel: 0 qkv, 1 attention, 2 wo, 3 w13, 4 w2,
+ * 5 classifier (layer 0's instance of each). */
+int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double *bytes_per_launch);
+
+/* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),
+ * 1 = q (E), 2 = xb (attention output, E), 3 = hb (H), 4 = key_cache row [layer][pos-1] (KV),
+ * 5 = value_cache row (KV). */
+int llmk_peek(llmk_ctx *ctx, int which, int layer, int pos, float *out, int n);
+
+int llmk_destroy(llmk_ctx *ctx);
+
+/* static string for an error code returned by any function above */
+const char *llmk_strerror(int code);
+
+/* library/ABI version: major*10000 + minor*100 + patch */
+int llmk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLMK_H */

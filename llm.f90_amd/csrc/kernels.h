@@ -1,0 +1,460 @@
+// gfx950 (MI355X, CDNA4) device kernels for the llm.f90 single-token forward pass.
+// Each kernel cites the reference lines it replaces (/root/reference/llama2.f90).
+//
+// Shape of the problem: decode is one GEMV after another over weights that are read exactly once
+// per token, 0.5 flop/B -> HBM-bound.  So: every wave streams whole weight rows with 16-byte
+// non-temporal loads straight into VGPRs (no LDS round trip for a stream nobody shares), the
+// 8..22 KB activation vector is staged once per block in LDS, partial sums are reduced with
+// wave64 cross-lane ops, and everything elementwise (rmsnorm, RoPE, KV write, SwiGLU, residual)
+// is fused into the prologue/epilogue of the GEMV that produces or consumes it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace llmk {
+
+constexpr int WAVE = 64;
+constexpr int GEMV_THREADS = 256;  // 4 waves
+constexpr int GEMV_WAVES = GEMV_THREADS / WAVE;
+
+enum WeightType { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2 };
+enum Epilogue {
+    EPI_STORE = 0,    // y[r] = W[r]·x                           classifier, llama2.f90:634-636
+    EPI_RESID = 1,    // y[r] += W[r]·x                          wo :603-605, w2 :618-620
+    EPI_ROPE_KV = 2,  // qkv rows -> RoPE -> q / key_cache / value_cache   :529-565
+    EPI_SWIGLU = 3,   // hb[r] = silu(W[r]·x) * (W[r+H]·x)       :610-616
+};
+
+struct GemvArgs {
+    const void* W;        // this layer's matrix, row-major [rows][K] in the weight type
+    const float* x;       // input vector [K] (global)
+    const float* norm_w;  // rmsnorm gain [K] when NORM
+    float* y;             // STORE/RESID: output [rows]; ROPE_KV: q [E]; SWIGLU: hb [H]
+    int rows;             // number of matrix rows
+    int K;                // row length (in_features)
+    // ROPE_KV
+    const float* rope_freqs;  // [hs/2]
+    const int* tokpos;        // device {token0, pos1}
+    float* kc;                // key_cache   base of this layer [S][KV]
+    float* vc;                // value_cache base of this layer [S][KV]
+    int E, KV, hs;
+    // SWIGLU
+    int H;
+    // q4_0 only: scales live after the nibbles
+    const void* W_scales;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// 16-byte non-temporal global load (weights are read once per token: keep them out of L2's way).
+__device__ __forceinline__ float4 ldg_nt(const float4* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 ldg_nt(const uint4* p) {
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b, float acc) {
+    acc = fmaf(a.x, b.x, acc);
+    acc = fmaf(a.y, b.y, acc);
+    acc = fmaf(a.z, b.z, acc);
+    acc = fmaf(a.w, b.w, acc);
+    return acc;
+}
+__device__ __forceinline__ float2 h2f(unsigned u) {
+    __half2 h = *reinterpret_cast<__half2*>(&u);
+    return __half22float2(h);
+}
+// 8 f16 weights (one uint4) against 8 f32 activations (two float4)
+__device__ __forceinline__ float dot8h(const uint4& w, const float4& x0, const float4& x1, float acc) {
+    float2 a = h2f(w.x), b = h2f(w.y), c = h2f(w.z), d = h2f(w.w);
+    acc = fmaf(a.x, x0.x, acc);
+    acc = fmaf(a.y, x0.y, acc);
+    acc = fmaf(b.x, x0.z, acc);
+    acc = fmaf(b.y, x0.w, acc);
+    acc = fmaf(c.x, x1.x, acc);
+    acc = fmaf(c.y, x1.y, acc);
+    acc = fmaf(d.x, x1.z, acc);
+    acc = fmaf(d.y, x1.w, acc);
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-type traits: how one lane pulls "one vector" (16 B) of a row and dots it against x in LDS.
+//   VE = weights per 16-byte vector.  Row r, vector v  <->  weights [v*VE, (v+1)*VE).
+// x in LDS: f32/f16 natural order (float4 xs[K/4]).
+// q4_0 (device layout, re-packed by llmk_upload): nibbles [rows][K/2] bytes, then f16 scales
+// [rows][K/32]; one vector = the 16 nibble bytes of one 32-weight block, low nibbles = elements
+// 0..15, high nibbles = elements 16..31 (ggml block_q4_0).  x is staged TRANSPOSED for it:
+// xs[m*nblk + b] = x[32b+4m .. 32b+4m+3], so the 8 float4 reads a lane needs are lane-contiguous.
+// ------------------------------------------------------------------------------------------------
+template <int WT> struct WTraits;
+template <> struct WTraits<WT_F32> {
+    static constexpr int VE = 4;
+    typedef float4 vec;
+    static __device__ __forceinline__ size_t row_bytes(int K) { return (size_t)K * 4; }
+};
+template <> struct WTraits<WT_F16> {
+    static constexpr int VE = 8;
+    typedef uint4 vec;
+    static __device__ __forceinline__ size_t row_bytes(int K) { return (size_t)K * 2; }
+};
+template <> struct WTraits<WT_Q4_0> {
+    static constexpr int VE = 32;
+    typedef uint4 vec;
+    static __device__ __forceinline__ size_t row_bytes(int K) { return (size_t)K / 2; }
+};
+
+template <int WT>
+__device__ __forceinline__ float vdot(const typename WTraits<WT>::vec& w, const float4* xs, int v, int nvec,
+                                      float acc);
+template <>
+__device__ __forceinline__ float vdot<WT_F32>(const float4& w, const float4* xs, int v, int, float acc) {
+    return dot4(w, xs[v], acc);
+}
+template <>
+__device__ __forceinline__ float vdot<WT_F16>(const uint4& w, const float4* xs, int v, int, float acc) {
+    return dot8h(w, xs[2 * v], xs[2 * v + 1], acc);
+}
+// q4_0: returns the UNSCALED integer-weighted sum for this block; caller multiplies by d.
+__device__ __forceinline__ float q4_block_dot(const uint4& w, const float4* xs, int b, int nblk) {
+    const unsigned u[4] = {w.x, w.y, w.z, w.w};
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // dword i holds bytes 4i..4i+3: lo nibbles = elems 4i..4i+3, hi = 16+4i..
+        const float4 xl = xs[i * nblk + b];
+        const float4 xh = xs[(4 + i) * nblk + b];
+        const unsigned q = u[i];
+        acc = fmaf((float)((int)(q & 0xF) - 8), xl.x, acc);
+        acc = fmaf((float)((int)((q >> 8) & 0xF) - 8), xl.y, acc);
+        acc = fmaf((float)((int)((q >> 16) & 0xF) - 8), xl.z, acc);
+        acc = fmaf((float)((int)((q >> 24) & 0xF) - 8), xl.w, acc);
+        acc = fmaf((float)((int)((q >> 4) & 0xF) - 8), xh.x, acc);
+        acc = fmaf((float)((int)((q >> 12) & 0xF) - 8), xh.y, acc);
+        acc = fmaf((float)((int)((q >> 20) & 0xF) - 8), xh.z, acc);
+        acc = fmaf((float)((int)((q >> 28) & 0xF) - 8), xh.w, acc);
+    }
+    return acc;
+}
+
+// One wave handles CH vectors per lane of two rows: all 2*CH loads are issued before any use.
+template <int WT, int CH>
+struct Chunk2 {
+    typename WTraits<WT>::vec r0[CH], r1[CH];
+    __half d0[CH], d1[CH];
+    __device__ __forceinline__ void load(const typename WTraits<WT>::vec* __restrict__ w0,
+                                         const typename WTraits<WT>::vec* __restrict__ w1,
+                                         const __half* __restrict__ s0, const __half* __restrict__ s1, int v0) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            r0[j] = ldg_nt(w0 + v0 + j * WAVE);
+            r1[j] = ldg_nt(w1 + v0 + j * WAVE);
+            if constexpr (WT == WT_Q4_0) {
+                d0[j] = s0[v0 + j * WAVE];
+                d1[j] = s1[v0 + j * WAVE];
+            }
+        }
+    }
+    __device__ __forceinline__ void fma(const float4* xs, int v0, int nvec, float& a0, float& a1) const {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if constexpr (WT == WT_Q4_0) {
+                a0 = fmaf(__half2float(d0[j]), q4_block_dot(r0[j], xs, v0 + j * WAVE, nvec), a0);
+                a1 = fmaf(__half2float(d1[j]), q4_block_dot(r1[j], xs, v0 + j * WAVE, nvec), a1);
+            } else {
+                a0 = vdot<WT>(r0[j], xs, v0 + j * WAVE, nvec, a0);
+                a1 = vdot<WT>(r1[j], xs, v0 + j * WAVE, nvec, a1);
+            }
+        }
+    }
+};
+template <int WT, int CH>
+__device__ __forceinline__ void chunk2(const typename WTraits<WT>::vec* __restrict__ w0,
+                                       const typename WTraits<WT>::vec* __restrict__ w1,
+                                       const __half* __restrict__ s0, const __half* __restrict__ s1,
+                                       const float4* xs, int v0, int nvec, float& a0, float& a1) {
+    Chunk2<WT, CH> c;
+    c.load(w0, w1, s0, s1, v0);
+    c.fma(xs, v0, nvec, a0, a1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The GEMV.  One block = 4 waves; one wave = one group of two rows at a time:
+//   STORE/RESID/ROPE_KV: rows (2g, 2g+1)  -- a RoPE pair is (i, i+1), llama2.f90:549-552
+//   SWIGLU:              rows (g, g+H)    -- gate row and its up row, llama2.f90:613-616
+// NORM fuses rmsnorm (llama2.f90:450-457: x*w/sqrt(dot(x,x)/n+1e-5)) into the x staging; every
+// block recomputes the 8 KB reduction from L2 instead of paying a kernel boundary for it.
+// The first 8 vector-columns of the wave's first row pair (the whole pair at K=2048 f32) are
+// requested from HBM BEFORE the block stages x: weights do not depend on activations, so the
+// ~2 us HBM latency overlaps the x load / rmsnorm / LDS write instead of following it.
+// ------------------------------------------------------------------------------------------------
+// vector-columns per row a wave keeps in flight (per chunk, and prefetched ahead of the x staging):
+// 8 x 16 B x 2 rows = 16 KB per wave for f32; fewer for f16/q4_0 whose vectors carry 2x/8x the
+// weights (and FMAs) each, so VGPR pressure stays bounded.
+template <int WT> struct ChunkCfg { static constexpr int PF = (WT == WT_F32) ? 8 : (WT == WT_F16) ? 4 : 2; };
+
+template <int WT, int EPI>
+__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, int r0, int r1, float a0, float a1) {
+    if (EPI == EPI_STORE) {
+        a.y[r0] = a0;
+        a.y[r1] = a1;
+    } else if (EPI == EPI_RESID) {
+        a.y[r0] += a0;
+        a.y[r1] += a1;
+    } else if (EPI == EPI_SWIGLU) {
+        // hb = hb*(1/(1+exp(-hb))); hb = hb*hb2        llama2.f90:615-616
+        float hb = a0 * (1.0f / (1.0f + expf(-a0)));
+        a.y[g] = hb * a1;
+    } else {  // EPI_ROPE_KV
+        const int pos = a.tokpos[1];  // 1-based, as llama2.f90:546 uses it
+        const int E = a.E, KV = a.KV;
+        if (r0 < E + KV) {
+            const int i0 = (r0 < E) ? r0 : r0 - E;  // 0-based even index inside q or k
+            // reference: 1-based odd i, head_dim = mod(i,hs) = 2j+1, freq = 1/10000**(head_dim/hs)
+            const float freq = a.rope_freqs[(i0 % a.hs) >> 1];
+            const float rval = (float)pos * freq;
+            const float fcr = cosf(rval), fci = sinf(rval);
+            const float o0 = a0 * fcr - a1 * fci;
+            const float o1 = a0 * fci + a1 * fcr;
+            float* dst = (r0 < E) ? a.y + i0 : a.kc + (size_t)(pos - 1) * KV + i0;
+            dst[0] = o0;
+            dst[1] = o1;
+        } else {
+            float* dst = a.vc + (size_t)(pos - 1) * KV + (r0 - E - KV);
+            dst[0] = a0;
+            dst[1] = a1;
+        }
+    }
+}
+
+template <int WT, int EPI, bool NORM>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);         // [4] (16 B)
+    float4* xs = reinterpret_cast<float4*>(smem_raw + 16);   // x, K floats
+    typedef typename WTraits<WT>::vec wvec;
+    constexpr int VE = WTraits<WT>::VE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int K = a.K;
+    const int nx4 = K >> 2;    // float4s of x
+    const int nvec = K / VE;   // weight vectors per row
+    const int ncol = nvec / WAVE;  // full wave-wide vector columns
+    const int ngroups = (EPI == EPI_SWIGLU) ? a.H : (a.rows >> 1);
+    const size_t rb = WTraits<WT>::row_bytes(K);
+    const char* Wb = reinterpret_cast<const char*>(a.W);
+    const __half* Sb = reinterpret_cast<const __half*>(a.W_scales);
+
+    int g = blockIdx.x * GEMV_WAVES + wid;
+    constexpr int PF = ChunkCfg<WT>::PF;
+    const bool pf = (g < ngroups) && (ncol >= PF);   // wave-uniform
+    Chunk2<WT, PF> pre;
+    if (pf) {
+        const int r0 = (EPI == EPI_SWIGLU) ? g : 2 * g;
+        const int r1 = (EPI == EPI_SWIGLU) ? g + a.H : 2 * g + 1;
+        pre.load(reinterpret_cast<const wvec*>(Wb + (size_t)r0 * rb), reinterpret_cast<const wvec*>(Wb + (size_t)r1 * rb),
+                 (WT == WT_Q4_0) ? Sb + (size_t)r0 * nvec : nullptr, (WT == WT_Q4_0) ? Sb + (size_t)r1 * nvec : nullptr,
+                 lane);
+    }
+
+    // ---- stage x (optionally rmsnorm'ed) into LDS -------------------------------------------
+    {
+        const float4* xg = reinterpret_cast<const float4*>(a.x);
+        float ss = 0.f;
+        for (int i = tid; i < nx4; i += GEMV_THREADS) {
+            float4 v = xg[i];
+            if (NORM) ss = dot4(v, v, ss);
+            if (WT == WT_Q4_0) {  // transposed staging: element group m of block b
+                xs[(i & 7) * nvec + (i >> 3)] = v;
+            } else {
+                xs[i] = v;
+            }
+        }
+        if (NORM) {
+            ss = wave_sum(ss);
+            if (lane == 0) red[wid] = ss;
+            __syncthreads();
+            ss = red[0] + red[1] + red[2] + red[3];
+            const float xn = sqrtf(ss / (float)K + 1e-5f);
+            const float4* wg = reinterpret_cast<const float4*>(a.norm_w);
+            for (int i = tid; i < nx4; i += GEMV_THREADS) {
+                const int li = (WT == WT_Q4_0) ? ((i & 7) * nvec + (i >> 3)) : i;
+                float4 v = xs[li];
+                const float4 w = wg[i];
+                v.x = v.x * w.x / xn;
+                v.y = v.y * w.y / xn;
+                v.z = v.z * w.z / xn;
+                v.w = v.w * w.w / xn;
+                xs[li] = v;
+            }
+        }
+        __syncthreads();
+    }
+
+    bool first = pf;
+    for (; g < ngroups; g += gridDim.x * GEMV_WAVES) {
+        const int r0 = (EPI == EPI_SWIGLU) ? g : 2 * g;
+        const int r1 = (EPI == EPI_SWIGLU) ? g + a.H : 2 * g + 1;
+        const wvec* w0 = reinterpret_cast<const wvec*>(Wb + (size_t)r0 * rb);
+        const wvec* w1 = reinterpret_cast<const wvec*>(Wb + (size_t)r1 * rb);
+        const __half* s0 = (WT == WT_Q4_0) ? Sb + (size_t)r0 * nvec : nullptr;
+        const __half* s1 = (WT == WT_Q4_0) ? Sb + (size_t)r1 * nvec : nullptr;
+        float a0 = 0.f, a1 = 0.f;
+        int v = lane;
+        int rem = ncol;
+        if (first) {  // consume the chunk requested before the x staging
+            pre.fma(xs, v, nvec, a0, a1);
+            v += PF * WAVE;
+            rem -= PF;
+            first = false;
+        }
+        while (rem >= PF) { chunk2<WT, PF>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += PF * WAVE; rem -= PF; }
+        if (PF > 4 && rem >= 4) { chunk2<WT, 4>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += 4 * WAVE; rem -= 4; }
+        if (PF > 2 && rem >= 2) { chunk2<WT, 2>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += 2 * WAVE; rem -= 2; }
+        if (rem >= 1) { chunk2<WT, 1>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += WAVE; }
+        if (v < nvec) chunk2<WT, 1>(w0, w1, s0, s1, xs, v, nvec, a0, a1);  // ragged tail (small shapes)
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) gemv_epilogue<WT, EPI>(a, g, r0, r1, a0, a1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention for one query head per block (llama2.f90:572-598 + softmax :468-478).
+// GQA: head h reads kv head h/kv_mul (the intended semantics of the slice at :581/:591).
+// Scores: HS/4 lanes share one timestep (16-byte K reads, contiguous per timestep);
+// PV: lane <-> output dim, timesteps strided over 256/HS slices, reduced through LDS.
+// ------------------------------------------------------------------------------------------------
+template <int HS>
+__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                   const float* __restrict__ vc, float* __restrict__ xb,
+                                                   const int* __restrict__ tokpos, int KV, int kv_mul) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);   // [256]
+    float* red4 = red + 256;                           // [4]
+    float* att = red + 260;                            // [pos] (capacity S); offset 1040 B = 65*16
+    constexpr int LPT = HS / 4;    // lanes per timestep
+    constexpr int TPW = 64 / LPT;  // timesteps per wave-iteration
+    constexpr int NSL = 256 / HS;  // PV timestep slices
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int h = blockIdx.x, g = h / kv_mul;
+    const int pos = tokpos[1];
+    const int sub = lane % LPT, tl = lane / LPT;
+    const float4 qv = reinterpret_cast<const float4*>(q + (size_t)h * HS)[sub];
+    const float scale = sqrtf((float)HS);
+    const float* kg = kc + (size_t)g * HS;
+    const float* vg = vc + (size_t)g * HS;
+
+    for (int t0 = wid * TPW; t0 < pos; t0 += 4 * TPW) {
+        const int t = t0 + tl;
+        float d = 0.f;
+        if (t < pos) {
+            const float4 kv = reinterpret_cast<const float4*>(kg + (size_t)t * KV)[sub];
+            d = dot4(qv, kv, 0.f);
+        }
+#pragma unroll
+        for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if (sub == 0 && t < pos) att[t] = d / scale;  // dot_product(q_t,k_t)/sqrt(real(head_size))  :582
+    }
+    __syncthreads();
+
+    float m = -INFINITY;
+    for (int t = tid; t < pos; t += 256) m = fmaxf(m, att[t]);
+    m = wave_max(m);
+    if (lane == 0) red4[wid] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red4[0], red4[1]), fmaxf(red4[2], red4[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int t = tid; t < pos; t += 256) {
+        const float e = expf(att[t] - m);
+        att[t] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red4[wid] = s;
+    __syncthreads();
+    s = red4[0] + red4[1] + red4[2] + red4[3];
+    for (int t = tid; t < pos; t += 256) att[t] = att[t] / s;  // p(:s) = xi/sum(xi)   :476
+    __syncthreads();
+
+    const int d = tid % HS, sl = tid / HS;
+    float acc = 0.f;
+    for (int t = sl; t < pos; t += NSL) acc = fmaf(att[t], vg[(size_t)t * KV + d], acc);
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < HS) {
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < NSL; ++i) o += red[i * HS + tid];
+        xb[(size_t)h * HS + tid] = o;
+    }
+}
+
+// x = token_embedding_table(:,token)   llama2.f90:520
+__global__ void embed_kernel(const float* __restrict__ table, const int* __restrict__ tokpos, float* __restrict__ x,
+                             int E) {
+    const int tok = tokpos[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x)
+        x[i] = table[(size_t)tok * E + i];
+}
+
+// token = maxloc(logits,DIM=1)   llama2.f90:388 -- first maximum wins; writes the 1-based id.
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int n, int* __restrict__ out) {
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = logits[i];
+        if (v > best) { best = v; idx = i; }  // ascending i per thread: keeps the first maximum
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { bv[wid] = best; bi[wid] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+        out[0] = idx + 1;
+    }
+}
+
+// q4_0 re-pack on upload: ggml blocks {f16 d; u8 qs[16]} (18 B, 2-byte aligned) -> 16-byte aligned
+// nibble vectors + a separate f16 scale plane, so the GEMV issues dwordx4 loads.
+__global__ void q4_repack_kernel(const uint8_t* __restrict__ src, uint4* __restrict__ nib, __half* __restrict__ sc,
+                                 size_t nblocks) {
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (size_t)gridDim.x * blockDim.x) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(src + b * 18);
+        uint16_t h = p[0];
+        sc[b] = *reinterpret_cast<__half*>(&h);
+        uint4 v;
+        v.x = (unsigned)p[1] | ((unsigned)p[2] << 16);
+        v.y = (unsigned)p[3] | ((unsigned)p[4] << 16);
+        v.z = (unsigned)p[5] | ((unsigned)p[6] << 16);
+        v.w = (unsigned)p[7] | ((unsigned)p[8] << 16);
+        nib[b] = v;
+    }
+}
+
+}  // namespace llmk

@@ -1,0 +1,562 @@
+// llmk C-ABI shim (include/llmk.h): device memory, weight upload, the per-token launch sequence
+// (captured once into a hipGraph and replayed), measurement hooks.  gfx950 only; no CPU path.
+//
+// Token pass (replaces `transformer`, /root/reference/llama2.f90:480-640), 5 launches per layer:
+//   embed                                   x = table(:,token)                      :520
+//   per layer l:
+//     gemv<NORM,ROPE_KV>   rmsnorm -> fused QKV GEMV -> RoPE -> q, key/value cache   :527-565
+//     attn                 scores, softmax, PV per head (GQA)                        :572-598
+//     gemv<RESID>          x += wo . xb                                              :603-605
+//     gemv<NORM,SWIGLU>    rmsnorm -> fused w1|w3 GEMV -> silu(g)*u                  :608-616
+//     gemv<RESID>          x += w2 . hb                                              :618-620
+//   gemv<NORM,STORE>       final rmsnorm -> classifier                               :627-636
+//   (greedy only) argmax                                                             :388
+#include "../../include/llmk.h"
+#include "kernels.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+using namespace llmk;
+
+#define HIPCHK(expr)                                          \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return LLMK_E_HIP + (int)e_;    \
+    } while (0)
+
+namespace {
+
+struct TensorDesc {
+    bool layered;   // has a leading layer dimension
+    int rows;       // rows per layer (1 for vectors)
+    int K;          // row length
+    bool matrix;    // streamed matmul weight (may be f16/q4_0); else always f32
+};
+
+struct DevTensor {
+    void* data = nullptr;    // f32/f16 rows, or q4_0 nibble plane
+    void* scales = nullptr;  // q4_0 f16 scale plane
+    size_t row_bytes = 0;    // bytes per row in `data`
+    size_t scale_row_bytes = 0;
+    int type = LLMK_TYPE_F32;
+    bool uploaded = false;
+    size_t rows_uploaded = 0;
+};
+
+}  // namespace
+
+struct llmk_ctx {
+    llmk_config cfg;
+    int E, H, L, nh, nkv, V, S, hs, KV, kv_mul;
+    TensorDesc desc[LLMK_N_TENSORS];
+    DevTensor t[LLMK_N_TENSORS];
+    float *d_kc = nullptr, *d_vc = nullptr;  // [L][S][KV]  (RunState, weight_module.f90:33-40)
+    float *d_x = nullptr, *d_q = nullptr, *d_xb = nullptr, *d_hb = nullptr, *d_logits = nullptr, *d_rope = nullptr;
+    int *d_tokpos = nullptr, *d_next = nullptr;
+    int* h_tokpos = nullptr;  // pinned {token0, pos1}
+    float* h_logits = nullptr;  // pinned [V]
+    int* h_next = nullptr;      // pinned
+    hipStream_t stream = nullptr;
+    hipGraphExec_t graph_logits = nullptr, graph_greedy = nullptr;
+    hipEvent_t ev[8] = {};
+    float times[5] = {0, 0, 0, 0, 0};
+    int n_cu = 256;
+};
+
+namespace {
+
+size_t row_bytes_for(int type, int K) {
+    switch (type) {
+        case LLMK_TYPE_F32: return (size_t)K * 4;
+        case LLMK_TYPE_F16: return (size_t)K * 2;
+        case LLMK_TYPE_Q4_0: return (size_t)K / 32 * 18;
+    }
+    return 0;
+}
+
+template <int WT, int EPI, bool NORM>
+hipError_t launch_gemv(hipStream_t st, const GemvArgs& a, int n_cu) {
+    const int ngroups = (EPI == EPI_SWIGLU) ? a.H : a.rows / 2;
+    int blocks = (ngroups + GEMV_WAVES - 1) / GEMV_WAVES;
+    const int cap = n_cu * 8;  // beyond 8 blocks per CU the waves loop over further row groups
+    if (blocks > cap) blocks = cap;
+    const size_t smem = 16 + (size_t)a.K * sizeof(float);
+    hipLaunchKernelGGL((gemv_kernel<WT, EPI, NORM>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a);
+    return hipGetLastError();
+}
+
+template <int EPI, bool NORM>
+hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
+    switch (wt) {
+        case LLMK_TYPE_F32: return launch_gemv<WT_F32, EPI, NORM>(st, a, n_cu);
+        case LLMK_TYPE_F16: return launch_gemv<WT_F16, EPI, NORM>(st, a, n_cu);
+        default: return launch_gemv<WT_Q4_0, EPI, NORM>(st, a, n_cu);
+    }
+}
+
+hipError_t launch_attn(llmk_ctx* c, int l) {
+    const float* kc = c->d_kc + (size_t)l * c->S * c->KV;
+    const float* vc = c->d_vc + (size_t)l * c->S * c->KV;
+    const size_t smem = (260 + (size_t)c->S) * sizeof(float);
+#define ATT(HS_)                                                                                                 \
+    hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nh), dim3(256), smem, c->stream, c->d_q, kc, vc, c->d_xb,      \
+                       c->d_tokpos, c->KV, c->kv_mul)
+    switch (c->hs) {
+        case 16: ATT(16); break;
+        case 32: ATT(32); break;
+        case 64: ATT(64); break;
+        case 128: ATT(128); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef ATT
+    return hipGetLastError();
+}
+
+GemvArgs base_args(llmk_ctx* c, int tid, int l, const float* x, const float* norm_w, float* y) {
+    GemvArgs a;
+    memset(&a, 0, sizeof(a));
+    const DevTensor& t = c->t[tid];
+    const TensorDesc& d = c->desc[tid];
+    const size_t lrows = d.layered ? (size_t)l * d.rows : 0;
+    a.W = (const char*)t.data + lrows * t.row_bytes;
+    a.W_scales = t.scales ? (const char*)t.scales + lrows * t.scale_row_bytes : nullptr;
+    a.x = x;
+    a.norm_w = norm_w;
+    a.y = y;
+    a.rows = d.rows;
+    a.K = d.K;
+    a.rope_freqs = c->d_rope;
+    a.tokpos = c->d_tokpos;
+    a.E = c->E;
+    a.KV = c->KV;
+    a.hs = c->hs;
+    a.H = c->H;
+    return a;
+}
+
+hipError_t launch_qkv(llmk_ctx* c, int l) {
+    GemvArgs a = base_args(c, LLMK_WQKV, l, c->d_x, (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * c->E, c->d_q);
+    a.kc = c->d_kc + (size_t)l * c->S * c->KV;
+    a.vc = c->d_vc + (size_t)l * c->S * c->KV;
+    return launch_gemv_t<EPI_ROPE_KV, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
+}
+hipError_t launch_wo(llmk_ctx* c, int l) {
+    GemvArgs a = base_args(c, LLMK_WO, l, c->d_xb, nullptr, c->d_x);
+    return launch_gemv_t<EPI_RESID, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
+}
+hipError_t launch_w13(llmk_ctx* c, int l) {
+    GemvArgs a = base_args(c, LLMK_W13, l, c->d_x, (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * c->E, c->d_hb);
+    return launch_gemv_t<EPI_SWIGLU, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
+}
+hipError_t launch_w2(llmk_ctx* c, int l) {
+    GemvArgs a = base_args(c, LLMK_W2, l, c->d_hb, nullptr, c->d_x);
+    return launch_gemv_t<EPI_RESID, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
+}
+hipError_t launch_cls(llmk_ctx* c) {
+    GemvArgs a = base_args(c, LLMK_WCLS, 0, c->d_x, (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data, c->d_logits);
+    return launch_gemv_t<EPI_STORE, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
+}
+hipError_t launch_embed(llmk_ctx* c) {
+    hipLaunchKernelGGL(embed_kernel, dim3((c->E + 255) / 256), dim3(256), 0, c->stream,
+                       (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data, c->d_tokpos, c->d_x, c->E);
+    return hipGetLastError();
+}
+
+#define HIPRET(expr)                     \
+    do {                                 \
+        hipError_t e_ = (expr);          \
+        if (e_ != hipSuccess) return e_; \
+    } while (0)
+
+// Enqueue one token pass on c->stream.  timed: bracket the reference's five sections with events.
+hipError_t enqueue_token(llmk_ctx* c, bool greedy, bool timed) {
+    HIPRET(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPRET(launch_embed(c));
+    for (int l = 0; l < c->L; ++l) {
+        if (timed) HIPRET(hipEventRecord(c->ev[0], c->stream));
+        HIPRET(launch_qkv(c, l));
+        if (timed) HIPRET(hipEventRecord(c->ev[1], c->stream));
+        HIPRET(launch_attn(c, l));
+        if (timed) HIPRET(hipEventRecord(c->ev[2], c->stream));
+        HIPRET(launch_wo(c, l));
+        HIPRET(launch_w13(c, l));
+        HIPRET(launch_w2(c, l));
+        if (timed) {
+            HIPRET(hipEventRecord(c->ev[3], c->stream));
+            HIPRET(hipEventSynchronize(c->ev[3]));
+            float ms;
+            // section 1 = rmsnorm+QKV (:526-538); 2 = RoPE (:541-561) is fused into 1's epilogue;
+            // 3 = attention (:570-599); 4 = wo+FFN (:601-622)
+            HIPRET(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->times[0] += ms;
+            HIPRET(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->times[2] += ms;
+            HIPRET(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->times[3] += ms;
+        }
+    }
+    if (timed) HIPRET(hipEventRecord(c->ev[4], c->stream));
+    HIPRET(launch_cls(c));
+    if (timed) {
+        HIPRET(hipEventRecord(c->ev[5], c->stream));
+        HIPRET(hipEventSynchronize(c->ev[5]));
+        float ms;
+        HIPRET(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); c->times[4] += ms;  // 5 = final norm + classifier
+    }
+    if (greedy) {
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_logits, c->V, c->d_next);
+        HIPRET(hipGetLastError());
+        HIPRET(hipMemcpyAsync(c->h_next, c->d_next, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPRET(hipMemcpyAsync(c->h_logits, c->d_logits, (size_t)c->V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    return hipSuccess;
+}
+
+int build_graph(llmk_ctx* c, bool greedy, hipGraphExec_t* out) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = enqueue_token(c, greedy, false);
+    hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+    if (e != hipSuccess) { if (g) hipGraphDestroy(g); return LLMK_E_HIP + (int)e; }
+    HIPCHK(e2);
+    e = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+    hipGraphDestroy(g);
+    HIPCHK(e);
+    return LLMK_OK;
+}
+
+int check_ready(llmk_ctx* c) {
+    if (!c) return LLMK_E_ARG;
+    for (int i = 0; i < LLMK_N_TENSORS; ++i)
+        if (!c->t[i].uploaded) return LLMK_E_STATE;
+    return LLMK_OK;
+}
+
+int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (token < 1 || token > c->V || pos < 1 || pos > c->S) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    c->h_tokpos[0] = token - 1;
+    c->h_tokpos[1] = pos;
+    const bool timed = (c->cfg.flags & LLMK_FLAG_TIMINGS) != 0;
+    if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
+        HIPCHK(enqueue_token(c, greedy, timed));
+    } else {
+        hipGraphExec_t* g = greedy ? &c->graph_greedy : &c->graph_logits;
+        if (!*g) {
+            rc = build_graph(c, greedy, g);
+            if (rc) return rc;
+        }
+        HIPCHK(hipGraphLaunch(*g, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LLMK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int llmk_version(void) { return 100; }
+
+const char* llmk_strerror(int code) {
+    switch (code) {
+        case LLMK_OK: return "ok";
+        case LLMK_E_ARG: return "llmk: bad argument";
+        case LLMK_E_SHAPE: return "llmk: unsupported model shape";
+        case LLMK_E_SIZE: return "llmk: byte count does not match tensor size";
+        case LLMK_E_TYPE: return "llmk: unsupported ggml tensor type";
+        case LLMK_E_STATE: return "llmk: forward called before all weights were uploaded";
+        case LLMK_E_NODEVICE: return "llmk: no usable HIP device (there is no CPU fallback)";
+        case LLMK_E_NOMEM: return "llmk: out of memory";
+    }
+    if (code >= LLMK_E_HIP) return hipGetErrorString((hipError_t)(code - LLMK_E_HIP));
+    return "llmk: unknown error";
+}
+
+int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
+    if (!cfg || !out) return LLMK_E_ARG;
+    *out = nullptr;
+    const int E = cfg->emb_dim, H = cfg->hidden_dim, L = cfg->n_layers, nh = cfg->n_heads, nkv = cfg->n_kv_heads;
+    const int V = cfg->vocab_size, S = cfg->seq_len;
+    if (E <= 0 || H <= 0 || L <= 0 || nh <= 0 || nkv <= 0 || V <= 0 || S <= 0) return LLMK_E_SHAPE;
+    if (E % nh || nh % nkv) return LLMK_E_SHAPE;
+    const int hs = E / nh;
+    if (hs != 16 && hs != 32 && hs != 64 && hs != 128) return LLMK_E_SHAPE;
+    if (E % 32 || H % 32 || (V & 1)) return LLMK_E_SHAPE;  // 16-byte vectors, q4_0 blocks, row pairs
+    if (cfg->weight_type != LLMK_TYPE_F32 && cfg->weight_type != LLMK_TYPE_F16 && cfg->weight_type != LLMK_TYPE_Q4_0)
+        return LLMK_E_TYPE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LLMK_E_NODEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return LLMK_E_NODEVICE;
+    HIPCHK(hipSetDevice(cfg->device));
+
+    llmk_ctx* c = new (std::nothrow) llmk_ctx();
+    if (!c) return LLMK_E_NOMEM;
+    c->cfg = *cfg;
+    c->E = E; c->H = H; c->L = L; c->nh = nh; c->nkv = nkv; c->V = V; c->S = S;
+    c->hs = hs; c->KV = nkv * hs; c->kv_mul = nh / nkv;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+        c->n_cu = prop.multiProcessorCount;
+
+    const int KV = c->KV;
+    c->desc[LLMK_TOKEN_EMBEDDING_TABLE] = {false, V, E, false};
+    c->desc[LLMK_RMS_ATT_WEIGHT] = {true, 1, E, false};
+    c->desc[LLMK_RMS_FFN_WEIGHT] = {true, 1, E, false};
+    c->desc[LLMK_WQKV] = {true, E + 2 * KV, E, true};
+    c->desc[LLMK_WO] = {true, E, E, true};
+    c->desc[LLMK_W13] = {true, 2 * H, E, true};
+    c->desc[LLMK_W2] = {true, E, H, true};
+    c->desc[LLMK_RMS_FINAL_WEIGHT] = {false, 1, E, false};
+    c->desc[LLMK_WCLS] = {false, V, E, true};
+
+    int rc = LLMK_OK;
+#define CK(expr)                                                        \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess && rc == LLMK_OK) rc = LLMK_E_HIP + (int)e_; \
+    } while (0)
+    for (int i = 0; i < LLMK_N_TENSORS && rc == LLMK_OK; ++i) {
+        const TensorDesc& d = c->desc[i];
+        DevTensor& t = c->t[i];
+        t.type = d.matrix ? cfg->weight_type : LLMK_TYPE_F32;
+        const size_t rows = (size_t)d.rows * (d.layered ? L : 1);
+        if (t.type == LLMK_TYPE_Q4_0) {
+            t.row_bytes = (size_t)d.K / 2;
+            t.scale_row_bytes = (size_t)d.K / 32 * 2;
+            CK(hipMalloc(&t.data, rows * t.row_bytes));
+            CK(hipMalloc(&t.scales, rows * t.scale_row_bytes));
+        } else {
+            t.row_bytes = row_bytes_for(t.type, d.K);
+            CK(hipMalloc(&t.data, rows * t.row_bytes));
+        }
+    }
+    const size_t kvn = (size_t)L * S * KV;
+    CK(hipMalloc(&c->d_kc, kvn * sizeof(float)));
+    CK(hipMalloc(&c->d_vc, kvn * sizeof(float)));
+    CK(hipMalloc(&c->d_x, (size_t)E * sizeof(float)));
+    CK(hipMalloc(&c->d_q, (size_t)E * sizeof(float)));
+    CK(hipMalloc(&c->d_xb, (size_t)E * sizeof(float)));
+    CK(hipMalloc(&c->d_hb, (size_t)H * sizeof(float)));
+    CK(hipMalloc(&c->d_logits, (size_t)V * sizeof(float)));
+    CK(hipMalloc(&c->d_rope, (size_t)(hs / 2) * sizeof(float)));
+    CK(hipMalloc(&c->d_tokpos, 2 * sizeof(int)));
+    CK(hipMalloc(&c->d_next, sizeof(int)));
+    CK(hipHostMalloc(&c->h_tokpos, 2 * sizeof(int), hipHostMallocDefault));
+    CK(hipHostMalloc(&c->h_logits, (size_t)V * sizeof(float), hipHostMallocDefault));
+    CK(hipHostMalloc(&c->h_next, sizeof(int), hipHostMallocDefault));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));
+    if (rc == LLMK_OK) {
+        CK(hipMemset(c->d_kc, 0, kvn * sizeof(float)));  // s%key_cache(:,:,:) = 0   llama2.f90:317
+        CK(hipMemset(c->d_vc, 0, kvn * sizeof(float)));
+        CK(hipMemset(c->d_x, 0, (size_t)E * sizeof(float)));
+        CK(hipMemset(c->d_q, 0, (size_t)E * sizeof(float)));
+        CK(hipMemset(c->d_xb, 0, (size_t)E * sizeof(float)));
+        CK(hipMemset(c->d_hb, 0, (size_t)H * sizeof(float)));
+        // default RoPE table: freq_j = 1/10000**((2j+1)/hs)   (llama2.f90:544-545)
+        float fr[64];
+        for (int j = 0; j < hs / 2; ++j) fr[j] = 1.0f / powf(10000.0f, (float)(2 * j + 1) / (float)hs);
+        CK(hipMemcpy(c->d_rope, fr, (size_t)(hs / 2) * sizeof(float), hipMemcpyHostToDevice));
+        CK(hipDeviceSynchronize());
+    }
+#undef CK
+    if (rc != LLMK_OK) {
+        llmk_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return LLMK_OK;
+}
+
+int llmk_upload_rows(llmk_ctx* c, int tid, int layer, int row_offset, int rows, const void* host, size_t nbytes,
+                     int ggml_type) {
+    if (!c || !host || tid < 0 || tid >= LLMK_N_TENSORS) return LLMK_E_ARG;
+    const TensorDesc& d = c->desc[tid];
+    DevTensor& t = c->t[tid];
+    const int nl = d.layered ? c->L : 1;
+    if (layer < 0 || layer >= nl || row_offset < 0 || rows <= 0 || row_offset + rows > d.rows) return LLMK_E_ARG;
+    if (ggml_type != t.type) return LLMK_E_TYPE;
+    if (nbytes != (size_t)rows * row_bytes_for(ggml_type, d.K)) return LLMK_E_SIZE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t first_row = (size_t)layer * d.rows + row_offset;
+    if (t.type == LLMK_TYPE_Q4_0) {
+        // stage raw ggml blocks, then split them into the 16-byte-aligned nibble plane + scale plane
+        const size_t blocks_per_row = (size_t)d.K / 32;
+        const size_t chunk_rows_max = ((size_t)256 << 20) / (blocks_per_row * 18) + 1;
+        uint8_t* tmp = nullptr;
+        const size_t cr0 = (size_t)rows < chunk_rows_max ? (size_t)rows : chunk_rows_max;
+        HIPCHK(hipMalloc(&tmp, cr0 * blocks_per_row * 18));
+        for (size_t r = 0; r < (size_t)rows; r += cr0) {
+            const size_t cr = ((size_t)rows - r) < cr0 ? ((size_t)rows - r) : cr0;
+            const size_t nb = cr * blocks_per_row;
+            hipError_t e = hipMemcpy(tmp, (const uint8_t*)host + r * blocks_per_row * 18, nb * 18, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                uint4* nib = (uint4*)((char*)t.data + (first_row + r) * t.row_bytes);
+                __half* sc = (__half*)((char*)t.scales + (first_row + r) * t.scale_row_bytes);
+                hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, tmp, nib, sc, nb);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+            if (e != hipSuccess) { hipFree(tmp); return LLMK_E_HIP + (int)e; }
+        }
+        HIPCHK(hipFree(tmp));
+    } else {
+        HIPCHK(hipMemcpy((char*)t.data + first_row * t.row_bytes, host, nbytes, hipMemcpyHostToDevice));
+    }
+    t.rows_uploaded += (size_t)rows;
+    if (t.rows_uploaded >= (size_t)d.rows * nl) t.uploaded = true;
+    return LLMK_OK;
+}
+
+int llmk_upload(llmk_ctx* c, int tid, const void* host, size_t nbytes, int ggml_type) {
+    if (!c || !host || tid < 0 || tid >= LLMK_N_TENSORS) return LLMK_E_ARG;
+    const TensorDesc& d = c->desc[tid];
+    const int nl = d.layered ? c->L : 1;
+    if (ggml_type != c->t[tid].type) return LLMK_E_TYPE;
+    const size_t per_layer = (size_t)d.rows * row_bytes_for(ggml_type, d.K);
+    if (nbytes != per_layer * nl) return LLMK_E_SIZE;
+    c->t[tid].rows_uploaded = 0;
+    c->t[tid].uploaded = false;
+    for (int l = 0; l < nl; ++l) {
+        int rc = llmk_upload_rows(c, tid, l, 0, d.rows, (const char*)host + (size_t)l * per_layer, per_layer, ggml_type);
+        if (rc) return rc;
+    }
+    return LLMK_OK;
+}
+
+int llmk_set_rope_freqs(llmk_ctx* c, const float* freqs, int n) {
+    if (!c || !freqs || n != c->hs / 2) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpy(c->d_rope, freqs, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    return LLMK_OK;
+}
+
+int llmk_forward(llmk_ctx* c, int token, int pos, float* logits_out) {
+    if (!c || !logits_out) return LLMK_E_ARG;
+    int rc = run_token(c, token, pos, false);
+    if (rc) return rc;
+    memcpy(logits_out, c->h_logits, (size_t)c->V * sizeof(float));
+    return LLMK_OK;
+}
+
+int llmk_forward_greedy(llmk_ctx* c, int token, int pos, int* next_token) {
+    if (!c || !next_token) return LLMK_E_ARG;
+    int rc = run_token(c, token, pos, true);
+    if (rc) return rc;
+    *next_token = *c->h_next;
+    return LLMK_OK;
+}
+
+int llmk_reset(llmk_ctx* c) {
+    if (!c) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t kvn = (size_t)c->L * c->S * c->KV * sizeof(float);
+    HIPCHK(hipMemsetAsync(c->d_kc, 0, kvn, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_vc, 0, kvn, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 5; ++i) c->times[i] = 0.f;
+    return LLMK_OK;
+}
+
+int llmk_timings(llmk_ctx* c, float ms[5]) {
+    if (!c || !ms) return LLMK_E_ARG;
+    for (int i = 0; i < 5; ++i) ms[i] = c->times[i];
+    return LLMK_OK;
+}
+
+int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* bytes_per_launch) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (kernel < 0 || kernel > 5 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    // Successive launches walk the layers so the weight stream never re-hits the 256 MiB Infinity
+    // Cache (the classifier has one matrix: its figure is cache-assisted beyond the first launch).
+    // NOTE: this overwrites x / caches at h_tokpos' position; call llmk_reset afterwards.
+    if (c->h_tokpos[1] < 1) { c->h_tokpos[0] = 0; c->h_tokpos[1] = 1; }
+    HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    auto one = [&](int i) -> hipError_t {
+        const int l = i % c->L;
+        switch (kernel) {
+            case 0: return launch_qkv(c, l);
+            case 1: return launch_attn(c, l);
+            case 2: return launch_wo(c, l);
+            case 3: return launch_w13(c, l);
+            case 4: return launch_w2(c, l);
+            default: return launch_cls(c);
+        }
+    };
+    for (int i = 0; i < 3; ++i) HIPCHK(one(i));
+    HIPCHK(hipEventRecord(c->ev[6], c->stream));
+    for (int i = 0; i < iters; ++i) HIPCHK(one(i + 3));
+    HIPCHK(hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(hipEventSynchronize(c->ev[7]));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
+    *avg_ms = ms / (float)iters;
+    if (bytes_per_launch) {
+        const int tids[6] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS};
+        double b = 0;
+        if (kernel == 1) {
+            b = 2.0 * c->KV * 4.0 * c->h_tokpos[1];  // K and V rows 1..pos of one layer
+        } else {
+            const TensorDesc& d = c->desc[tids[kernel]];
+            b = (double)d.rows * (double)row_bytes_for(c->t[tids[kernel]].type, d.K);
+        }
+        *bytes_per_launch = b;
+    }
+    return LLMK_OK;
+}
+
+int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
+    if (!c || !out || n <= 0) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const float* src = nullptr;
+    int len = 0;
+    switch (which) {
+        case 0: src = c->d_x; len = c->E; break;
+        case 1: src = c->d_q; len = c->E; break;
+        case 2: src = c->d_xb; len = c->E; break;
+        case 3: src = c->d_hb; len = c->H; break;
+        case 4:
+        case 5:
+            if (layer < 0 || layer >= c->L || pos < 1 || pos > c->S) return LLMK_E_ARG;
+            src = (which == 4 ? c->d_kc : c->d_vc) + ((size_t)layer * c->S + (pos - 1)) * c->KV;
+            len = c->KV;
+            break;
+        default: return LLMK_E_ARG;
+    }
+    if (n > len) return LLMK_E_ARG;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return LLMK_OK;
+}
+
+int llmk_destroy(llmk_ctx* c) {
+    if (!c) return LLMK_E_ARG;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->graph_logits) hipGraphExecDestroy(c->graph_logits);
+    if (c->graph_greedy) hipGraphExecDestroy(c->graph_greedy);
+    for (int i = 0; i < LLMK_N_TENSORS; ++i) {
+        if (c->t[i].data) hipFree(c->t[i].data);
+        if (c->t[i].scales) hipFree(c->t[i].scales);
+    }
+    void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next};
+    for (void* p : dev)
+        if (p) hipFree(p);
+    if (c->h_tokpos) hipHostFree(c->h_tokpos);
+    if (c->h_logits) hipHostFree(c->h_logits);
+    if (c->h_next) hipHostFree(c->h_next);
+    for (int i = 0; i < 8; ++i)
+        if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return LLMK_OK;
+}
+
+}  // extern "C"

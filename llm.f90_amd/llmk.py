@@ -1,0 +1,167 @@
+"""ctypes binding of the llmk C-ABI (include/llmk.h) -- the same symbols the Fortran host binds
+with ISO_C_BINDING (host/llmk_binding.f90).  Used by tests/ and bench.py.
+
+There is no fallback: if libllmk.so is missing or no HIP device is usable this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libllmk.so")
+
+TENSOR_IDS = {
+    "token_embedding_table": 0, "rms_att_weight": 1, "rms_ffn_weight": 2, "wqkv": 3, "wo": 4, "w13": 5, "w2": 6,
+    "rms_final_weight": 7, "wcls": 8,
+}
+FLAG_NO_GRAPH, FLAG_TIMINGS = 1, 2
+# every symbol include/llmk.h declares
+SYMBOLS = ["llmk_create", "llmk_upload", "llmk_upload_rows", "llmk_set_rope_freqs", "llmk_forward",
+           "llmk_forward_greedy", "llmk_reset", "llmk_timings", "llmk_time_kernel", "llmk_peek", "llmk_destroy",
+           "llmk_strerror", "llmk_version"]
+
+
+class LlmkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"llmk error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("emb_dim", "hidden_dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size",
+                                         "seq_len", "weight_type", "device", "flags")]
+
+
+def build_lib(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> csrc/libllmk.so (cross-compiles without a GPU)."""
+    subprocess.run(["make", "-s", "-C", _HERE, "lib"] + (["-B"] if force else []), check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built (run `make -C llm.f90_amd lib`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, ci, cf = C.c_void_p, C.c_int, C.POINTER(C.c_float)
+        L.llmk_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.llmk_upload.argtypes = [vp, ci, vp, C.c_size_t, ci]
+        L.llmk_upload_rows.argtypes = [vp, ci, ci, ci, ci, vp, C.c_size_t, ci]
+        L.llmk_set_rope_freqs.argtypes = [vp, cf, ci]
+        L.llmk_forward.argtypes = [vp, ci, ci, cf]
+        L.llmk_forward_greedy.argtypes = [vp, ci, ci, C.POINTER(ci)]
+        L.llmk_reset.argtypes = [vp]
+        L.llmk_timings.argtypes = [vp, cf]
+        L.llmk_time_kernel.argtypes = [vp, ci, ci, cf, C.POINTER(C.c_double)]
+        L.llmk_peek.argtypes = [vp, ci, ci, ci, cf, ci]
+        L.llmk_destroy.argtypes = [vp]
+        L.llmk_strerror.argtypes = [ci]
+        L.llmk_strerror.restype = C.c_char_p
+        L.llmk_version.argtypes = []
+        for s in SYMBOLS:
+            if s != "llmk_strerror":
+                getattr(L, s).restype = ci
+        _lib = L
+    return _lib
+
+
+def _ck(rc):
+    if rc != 0:
+        raise LlmkError(rc, lib().llmk_strerror(rc).decode())
+
+
+class Llmk:
+    """One sequence on one GPU. `fw` is tools.gguf.FusedWeights (weight_module layout)."""
+
+    def __init__(self, fw, device: int = 0, flags: int = 0, seq_len: int | None = None):
+        s = fw.shape
+        self.shape = s
+        self.V = s.vocab_size
+        cfg = Config(s.emb_dim, s.hidden_dim, s.n_layers, s.n_heads, s.n_kv_heads, s.vocab_size,
+                     seq_len or s.seq_len, fw.ggml_type, device, flags)
+        self._h = C.c_void_p()
+        _ck(lib().llmk_create(C.byref(cfg), C.byref(self._h)))
+        for name, tid in TENSOR_IDS.items():
+            a = np.ascontiguousarray(getattr(fw, name))
+            is_mat = name in ("wqkv", "wo", "w13", "w2", "wcls")
+            _ck(lib().llmk_upload(self._h, tid, a.ctypes.data, a.nbytes, fw.ggml_type if is_mat else 0))
+        # the reference's own f32 expression for the RoPE frequencies (llama2.f90:544-545)
+        hs = s.head_size
+        fr = np.float32(1.0) / np.power(np.float32(10000.0), (np.arange(1, hs, 2, dtype=np.float32) / np.float32(hs)),
+                                        dtype=np.float32)
+        self.set_rope_freqs(fr)
+        self._logits = np.empty(self.V, np.float32)
+
+    def set_rope_freqs(self, fr):
+        fr = np.ascontiguousarray(fr, np.float32)
+        _ck(lib().llmk_set_rope_freqs(self._h, fr.ctypes.data_as(C.POINTER(C.c_float)), len(fr)))
+
+    def forward(self, token: int, pos: int) -> np.ndarray:
+        """1-based token and pos, as `transformer(token,pos,s,weights)` (llama2.f90:380)."""
+        _ck(lib().llmk_forward(self._h, token, pos, self._logits.ctypes.data_as(C.POINTER(C.c_float))))
+        return self._logits.copy()
+
+    def forward_raw(self, token: int, pos: int) -> int:
+        """Hot loop for bench.py: no copy of the result, returns the status code."""
+        return lib().llmk_forward(self._h, token, pos, self._logits.ctypes.data_as(C.POINTER(C.c_float)))
+
+    def forward_greedy(self, token: int, pos: int) -> int:
+        nxt = C.c_int(0)
+        _ck(lib().llmk_forward_greedy(self._h, token, pos, C.byref(nxt)))
+        return nxt.value
+
+    def generate(self, n: int, prompt=(), want_logits: bool = True, greedy_on_device: bool = False):
+        """The reference generation loop at temperature 0 (llama2.f90:376-402)."""
+        self.reset()
+        toks = np.zeros(n, np.int32)
+        logits = np.empty((n, self.V), np.float32) if want_logits else None
+        token = 2
+        p = list(prompt)
+        for pos in range(1, n + 1):
+            if greedy_on_device:
+                nxt = self.forward_greedy(token, pos)
+            else:
+                lg = self.forward(token, pos)
+                if want_logits:
+                    logits[pos - 1] = lg
+                nxt = int(np.argmax(lg)) + 1
+            token = p[pos - 1] if pos <= len(p) else nxt
+            toks[pos - 1] = token
+        return toks, logits
+
+    def reset(self):
+        _ck(lib().llmk_reset(self._h))
+
+    def timings(self):
+        t = (C.c_float * 5)()
+        _ck(lib().llmk_timings(self._h, t))
+        return list(t)
+
+    def time_kernel(self, kernel: int, iters: int):
+        ms, b = C.c_float(0), C.c_double(0)
+        _ck(lib().llmk_time_kernel(self._h, kernel, iters, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
+
+    def peek(self, which: int, n: int, layer: int = 0, pos: int = 1):
+        out = np.empty(n, np.float32)
+        _ck(lib().llmk_peek(self._h, which, layer, pos, out.ctypes.data_as(C.POINTER(C.c_float)), n))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().llmk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

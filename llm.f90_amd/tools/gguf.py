@@ -17,6 +17,7 @@ knowledge, not citable inside /root/reference.
 """
 from __future__ import annotations
 
+import os
 import struct
 from dataclasses import dataclass, field
 from typing import Dict, List, Tuple
@@ -83,18 +84,29 @@ def _splitmix64(x: np.ndarray) -> np.ndarray:
         return z ^ (z >> np.uint64(31))
 
 
-def det_uniform(seed: int, stream: int, n: int, lo: float, hi: float, chunk: int = 1 << 24) -> np.ndarray:
+def _det_chunk(out: np.ndarray, base: np.uint64, s: int, e: int, lo: float, hi: float) -> None:
+    idx = np.arange(s, e, dtype=np.uint64) + base
+    u24 = (_splitmix64(idx) >> np.uint64(40)).astype(np.float32)  # exact: < 2**24
+    u24 *= np.float32(1.0 / (1 << 24))
+    u24 *= np.float32(hi - lo)
+    u24 += np.float32(lo)
+    out[s:e] = u24
+
+
+def det_uniform(seed: int, stream: int, n: int, lo: float, hi: float, chunk: int = 1 << 22) -> np.ndarray:
     """n float32 values uniform in [lo, hi): element i = hash(seed, stream, i). Pure integer
-    arithmetic up to the final affine map, so identical on every numpy build."""
+    arithmetic up to the final affine map (three correctly-rounded f32 ops), so identical on
+    every numpy build and independent of chunking/threading."""
     out = np.empty(n, dtype=np.float32)
     base = np.uint64((seed * 0x9E3779B1 + stream * 0x85EBCA77) & 0xFFFFFFFF) << np.uint64(32)
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        idx = np.arange(s, e, dtype=np.uint64) + base
-        u24 = (_splitmix64(idx) >> np.uint64(40)).astype(np.float32)  # exact: < 2**24
-        out[s:e] = u24 * np.float32(1.0 / (1 << 24))
-    out *= np.float32(hi - lo)
-    out += np.float32(lo)
+    spans = [(s, min(n, s + chunk)) for s in range(0, n, chunk)]
+    if len(spans) <= 2:
+        for s, e in spans:
+            _det_chunk(out, base, s, e, lo, hi)
+    else:  # numpy releases the GIL inside ufuncs: threads scale on the big shapes
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda se: _det_chunk(out, base, se[0], se[1], lo, hi), spans))
     return out
 
 
@@ -281,9 +293,30 @@ def vocab_strings(V: int) -> List[bytes]:
     return out
 
 
-def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = GGML_F32,
-                     alignment: int = 32, version: int = 3) -> None:
-    """Synthetic Llama GGUF. With ggml_type == GGML_F32 the reference loader reads it as is."""
+def _tensor_source(fw: "FusedWeights", name: str) -> np.ndarray:
+    """Encoded bytes of one GGUF tensor, sliced out of the fused arrays (inverse of load_fused)."""
+    s = fw.shape
+    E, H, KV = s.emb_dim, s.hidden_dim, s.kv_dim
+    if name == "token_embd.weight":
+        return fw.token_embedding_table
+    if name == "output_norm.weight":
+        return fw.rms_final_weight
+    if name == "output.weight":
+        return fw.wcls
+    _, li, rest = name.split(".", 2)
+    li = int(li)
+    return {
+        "attn_norm.weight": lambda: fw.rms_att_weight[li], "ffn_norm.weight": lambda: fw.rms_ffn_weight[li],
+        "attn_q.weight": lambda: fw.wqkv[li, 0:E], "attn_k.weight": lambda: fw.wqkv[li, E:E + KV],
+        "attn_v.weight": lambda: fw.wqkv[li, E + KV:E + 2 * KV], "attn_output.weight": lambda: fw.wo[li],
+        "ffn_gate.weight": lambda: fw.w13[li, 0:H], "ffn_up.weight": lambda: fw.w13[li, H:2 * H],
+        "ffn_down.weight": lambda: fw.w2[li],
+    }[rest]()
+
+
+def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int = 3) -> None:
+    """Write fused weights as a Llama GGUF. With f32 matrices the reference loader reads it as is."""
+    shape, ggml_type = fw.shape, fw.ggml_type
     names = tensor_names(shape)
     vocab = vocab_strings(shape.vocab_size)
     kvs = [
@@ -315,12 +348,11 @@ def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = G
         _w_str(f, b"tokenizer.ggml.scores")
         f.write(struct.pack("<IIQ", T_ARR, T_F32, len(vocab)))
         f.write((-np.arange(len(vocab), dtype="<f4")).tobytes())
-        # tensor infos
         offset = 0
         infos = []
         for name, dims, kind in names:
             tt = ggml_type if kind == "mat" else GGML_F32
-            nbytes = encode(np.zeros((1, dims[-1]), np.float32), tt).nbytes * (int(np.prod(dims[:-1])) if len(dims) > 1 else 1)
+            nbytes = _tensor_source(fw, name).nbytes
             infos.append((tt, offset, nbytes))
             _w_str(f, name.encode())
             f.write(struct.pack("<I", len(dims)))
@@ -328,16 +360,18 @@ def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = G
                 f.write(struct.pack("<Q", d))
             f.write(struct.pack("<IQ", tt, offset))
             offset += (nbytes + alignment - 1) // alignment * alignment
-        pad = (-f.tell()) % alignment
-        f.write(b"\0" * pad)
+        f.write(b"\0" * ((-f.tell()) % alignment))
         data_start = f.tell()
-        for index, ((name, dims, kind), (tt, off, nbytes)) in enumerate(zip(names, infos)):
+        for (name, dims, kind), (tt, off, nbytes) in zip(names, infos):
             assert f.tell() == data_start + off
-            t = synth_tensor(shape, seed, index, dims, kind)
-            raw = encode(t, tt)
-            assert raw.nbytes == nbytes
-            f.write(raw.tobytes())
+            f.write(np.ascontiguousarray(_tensor_source(fw, name)).data)
             f.write(b"\0" * ((-nbytes) % alignment))
+
+
+def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = GGML_F32,
+                     alignment: int = 32, version: int = 3) -> None:
+    """Synthetic Llama GGUF: tensor bytes are a pure function of (shape, seed, type)."""
+    write_gguf(path, synth_fused(shape, seed, ggml_type), alignment, version)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -31,6 +31,8 @@ def build(force: bool = False) -> None:
 def _lib(flavour: str):
     name = {"strict": "liboracle.so", "omp": "liboracle_omp.so", "fast": "liboracle_fast.so"}[flavour]
     path = os.path.join(_HERE, "_build", name)
+    if flavour == "omp":  # many-core hosts: do not oversubscribe small shapes with 256 threads
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 1)))
     if not os.path.exists(path):
         subprocess.run(["make", "-s", "-C", _HERE, os.path.join("_build", name)], check=True)
     lib = C.CDLL(path)
