@@ -151,64 +151,44 @@ __device__ __forceinline__ float q4_block_dot(const uint4& w, const float4* xs, 
     return acc;
 }
 
-// One wave handles CH vectors per lane of two rows: all 2*CH loads are issued before any use.
-template <int WT, int CH>
-struct Chunk2 {
-    typename WTraits<WT>::vec r0[CH], r1[CH];
-    __half d0[CH], d1[CH];
-    __device__ __forceinline__ void load(const typename WTraits<WT>::vec* __restrict__ w0,
-                                         const typename WTraits<WT>::vec* __restrict__ w1,
-                                         const __half* __restrict__ s0, const __half* __restrict__ s1, int v0) {
+// A register tile: N vector-columns of ROWS rows per lane; all ROWS*N loads are issued before any use.
+template <int WT, int ROWS, int N>
+struct Tile {
+    typename WTraits<WT>::vec r[ROWS][N];
+    __half d[ROWS][N];
+    __device__ __forceinline__ void load(const typename WTraits<WT>::vec* const (&w)[ROWS],
+                                         const __half* const (&sc)[ROWS], int v0) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            r0[j] = ldg_nt(w0 + v0 + j * WAVE);
-            r1[j] = ldg_nt(w1 + v0 + j * WAVE);
-            if constexpr (WT == WT_Q4_0) {
-                d0[j] = s0[v0 + j * WAVE];
-                d1[j] = s1[v0 + j * WAVE];
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                r[i][j] = ldg_nt(w[i] + v0 + j * WAVE);
+                if constexpr (WT == WT_Q4_0) d[i][j] = sc[i][v0 + j * WAVE];
             }
-        }
     }
-    __device__ __forceinline__ void fma(const float4* xs, int v0, int nvec, float& a0, float& a1) const {
+    __device__ __forceinline__ void fma(const float4* xs, int v0, int nvec, float (&acc)[ROWS]) const {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if constexpr (WT == WT_Q4_0) {
-                a0 = fmaf(__half2float(d0[j]), q4_block_dot(r0[j], xs, v0 + j * WAVE, nvec), a0);
-                a1 = fmaf(__half2float(d1[j]), q4_block_dot(r1[j], xs, v0 + j * WAVE, nvec), a1);
-            } else {
-                a0 = vdot<WT>(r0[j], xs, v0 + j * WAVE, nvec, a0);
-                a1 = vdot<WT>(r1[j], xs, v0 + j * WAVE, nvec, a1);
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                if constexpr (WT == WT_Q4_0)
+                    acc[i] = fmaf(__half2float(d[i][j]), q4_block_dot(r[i][j], xs, v0 + j * WAVE, nvec), acc[i]);
+                else
+                    acc[i] = vdot<WT>(r[i][j], xs, v0 + j * WAVE, nvec, acc[i]);
             }
-        }
     }
 };
-template <int WT, int CH>
-__device__ __forceinline__ void chunk2(const typename WTraits<WT>::vec* __restrict__ w0,
-                                       const typename WTraits<WT>::vec* __restrict__ w1,
-                                       const __half* __restrict__ s0, const __half* __restrict__ s1,
-                                       const float4* xs, int v0, int nvec, float& a0, float& a1) {
-    Chunk2<WT, CH> c;
-    c.load(w0, w1, s0, s1, v0);
-    c.fma(xs, v0, nvec, a0, a1);
+template <int WT, int ROWS, int N>
+__device__ __forceinline__ void tile_step(const typename WTraits<WT>::vec* const (&w)[ROWS],
+                                          const __half* const (&sc)[ROWS], const float4* xs, int v0, int nvec,
+                                          float (&acc)[ROWS]) {
+    Tile<WT, ROWS, N> t;
+    t.load(w, sc, v0);
+    t.fma(xs, v0, nvec, acc);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The GEMV.  One block = 4 waves; one wave = one group of two rows at a time:
-//   STORE/RESID/ROPE_KV: rows (2g, 2g+1)  -- a RoPE pair is (i, i+1), llama2.f90:549-552
-//   SWIGLU:              rows (g, g+H)    -- gate row and its up row, llama2.f90:613-616
-// NORM fuses rmsnorm (llama2.f90:450-457: x*w/sqrt(dot(x,x)/n+1e-5)) into the x staging; every
-// block recomputes the 8 KB reduction from L2 instead of paying a kernel boundary for it.
-// The first 8 vector-columns of the wave's first row pair (the whole pair at K=2048 f32) are
-// requested from HBM BEFORE the block stages x: weights do not depend on activations, so the
-// ~2 us HBM latency overlaps the x load / rmsnorm / LDS write instead of following it.
-// ------------------------------------------------------------------------------------------------
-// vector-columns per row a wave keeps in flight (per chunk, and prefetched ahead of the x staging):
-// 8 x 16 B x 2 rows = 16 KB per wave for f32; fewer for f16/q4_0 whose vectors carry 2x/8x the
-// weights (and FMAs) each, so VGPR pressure stays bounded.
-template <int WT> struct ChunkCfg { static constexpr int PF = (WT == WT_F32) ? 8 : (WT == WT_F16) ? 4 : 2; };
-
-template <int WT, int EPI>
-__device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, int r0, int r1, float a0, float a1) {
+template <int EPI>
+__device__ __forceinline__ void gemv_epilogue2(const GemvArgs& a, int g, int r0, int r1, float a0, float a1) {
     if (EPI == EPI_STORE) {
         a.y[r0] = a0;
         a.y[r1] = a1;
@@ -241,8 +221,23 @@ __device__ __forceinline__ void gemv_epilogue(const GemvArgs& a, int g, int r0, 
     }
 }
 
-template <int WT, int EPI, bool NORM>
+// ------------------------------------------------------------------------------------------------
+// The GEMV.  One block = 4 waves, ONE JOB PER WAVE (no loop over jobs): a job is
+//   ROWS=2, STORE/RESID/ROPE_KV: rows (2g, 2g+1)  -- a RoPE pair is (i, i+1), llama2.f90:549-552
+//   ROWS=2, SWIGLU:              rows (g, g+H)    -- gate row and its up row, llama2.f90:613-616
+//   ROWS=1, STORE/RESID:         row g            -- long rows (w2, K = hidden_dim)
+// so that ALL of a kernel's weight bytes are requested from HBM the moment its waves start: a
+// 20-90 MB GEMV is a latency problem as much as a bandwidth one (one kernel = 3-15 us of
+// streaming), and a wave that loops pays the ~2 us loaded HBM latency once per round.
+// The first NCH vector-columns per row (the whole row for the hot shapes) are requested BEFORE
+// the block stages x: weights do not depend on activations, so HBM latency overlaps the
+// x load / rmsnorm / LDS write instead of following it.
+// NORM fuses rmsnorm (llama2.f90:450-457: x*w/sqrt(dot(x,x)/n+1e-5)) into the x staging; every
+// block recomputes the 8 KB reduction from L2 instead of paying a kernel boundary for it.
+// ------------------------------------------------------------------------------------------------
+template <int WT, int EPI, bool NORM, int ROWS, int NCH>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
+    static_assert(ROWS == 2 || EPI == EPI_STORE || EPI == EPI_RESID, "row pairs required");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);         // [4] (16 B)
     float4* xs = reinterpret_cast<float4*>(smem_raw + 16);   // x, K floats
@@ -251,25 +246,29 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = a.K;
-    const int nx4 = K >> 2;    // float4s of x
-    const int nvec = K / VE;   // weight vectors per row
+    const int nx4 = K >> 2;        // float4s of x
+    const int nvec = K / VE;       // weight vectors per row
     const int ncol = nvec / WAVE;  // full wave-wide vector columns
-    const int ngroups = (EPI == EPI_SWIGLU) ? a.H : (a.rows >> 1);
+    const int njobs = (EPI == EPI_SWIGLU) ? a.H : (a.rows / ROWS);
     const size_t rb = WTraits<WT>::row_bytes(K);
     const char* Wb = reinterpret_cast<const char*>(a.W);
     const __half* Sb = reinterpret_cast<const __half*>(a.W_scales);
 
-    int g = blockIdx.x * GEMV_WAVES + wid;
-    constexpr int PF = ChunkCfg<WT>::PF;
-    const bool pf = (g < ngroups) && (ncol >= PF);   // wave-uniform
-    Chunk2<WT, PF> pre;
-    if (pf) {
-        const int r0 = (EPI == EPI_SWIGLU) ? g : 2 * g;
-        const int r1 = (EPI == EPI_SWIGLU) ? g + a.H : 2 * g + 1;
-        pre.load(reinterpret_cast<const wvec*>(Wb + (size_t)r0 * rb), reinterpret_cast<const wvec*>(Wb + (size_t)r1 * rb),
-                 (WT == WT_Q4_0) ? Sb + (size_t)r0 * nvec : nullptr, (WT == WT_Q4_0) ? Sb + (size_t)r1 * nvec : nullptr,
-                 lane);
+    const int g = blockIdx.x * GEMV_WAVES + wid;
+    const bool active = g < njobs;                 // wave-uniform
+    int rows[ROWS];
+    const wvec* w[ROWS];
+    const __half* sc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        rows[i] = (ROWS == 1) ? g : (EPI == EPI_SWIGLU ? g + i * a.H : 2 * g + i);
+        const int r = active ? rows[i] : 0;
+        w[i] = reinterpret_cast<const wvec*>(Wb + (size_t)r * rb);
+        sc[i] = (WT == WT_Q4_0) ? Sb + (size_t)r * nvec : nullptr;
     }
+    const bool pf = active && (ncol >= NCH);
+    Tile<WT, ROWS, NCH> pre;
+    if (pf) pre.load(w, sc, lane);
 
     // ---- stage x (optionally rmsnorm'ed) into LDS -------------------------------------------
     {
@@ -294,62 +293,67 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
             for (int i = tid; i < nx4; i += GEMV_THREADS) {
                 const int li = (WT == WT_Q4_0) ? ((i & 7) * nvec + (i >> 3)) : i;
                 float4 v = xs[li];
-                const float4 w = wg[i];
-                v.x = v.x * w.x / xn;
-                v.y = v.y * w.y / xn;
-                v.z = v.z * w.z / xn;
-                v.w = v.w * w.w / xn;
+                const float4 nw = wg[i];
+                v.x = v.x * nw.x / xn;
+                v.y = v.y * nw.y / xn;
+                v.z = v.z * nw.z / xn;
+                v.w = v.w * nw.w / xn;
                 xs[li] = v;
             }
         }
         __syncthreads();
     }
+    if (!active) return;
 
-    bool first = pf;
-    for (; g < ngroups; g += gridDim.x * GEMV_WAVES) {
-        const int r0 = (EPI == EPI_SWIGLU) ? g : 2 * g;
-        const int r1 = (EPI == EPI_SWIGLU) ? g + a.H : 2 * g + 1;
-        const wvec* w0 = reinterpret_cast<const wvec*>(Wb + (size_t)r0 * rb);
-        const wvec* w1 = reinterpret_cast<const wvec*>(Wb + (size_t)r1 * rb);
-        const __half* s0 = (WT == WT_Q4_0) ? Sb + (size_t)r0 * nvec : nullptr;
-        const __half* s1 = (WT == WT_Q4_0) ? Sb + (size_t)r1 * nvec : nullptr;
-        float a0 = 0.f, a1 = 0.f;
-        int v = lane;
-        int rem = ncol;
-        if (first) {  // consume the chunk requested before the x staging
-            pre.fma(xs, v, nvec, a0, a1);
-            v += PF * WAVE;
-            rem -= PF;
-            first = false;
+    float acc[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+    int v = lane, rem = ncol;
+    if (pf) {
+        pre.fma(xs, v, nvec, acc);
+        v += NCH * WAVE;
+        rem -= NCH;
+    }
+    while (rem >= NCH) { tile_step<WT, ROWS, NCH>(w, sc, xs, v, nvec, acc); v += NCH * WAVE; rem -= NCH; }
+    if (NCH > 8 && rem >= 8) { tile_step<WT, ROWS, 8>(w, sc, xs, v, nvec, acc); v += 8 * WAVE; rem -= 8; }
+    if (NCH > 4 && rem >= 4) { tile_step<WT, ROWS, 4>(w, sc, xs, v, nvec, acc); v += 4 * WAVE; rem -= 4; }
+    if (NCH > 2 && rem >= 2) { tile_step<WT, ROWS, 2>(w, sc, xs, v, nvec, acc); v += 2 * WAVE; rem -= 2; }
+    if (NCH > 1 && rem >= 1) { tile_step<WT, ROWS, 1>(w, sc, xs, v, nvec, acc); v += WAVE; }
+    if (v < nvec) tile_step<WT, ROWS, 1>(w, sc, xs, v, nvec, acc);  // ragged tail (small shapes)
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+        if constexpr (ROWS == 2) {
+            gemv_epilogue2<EPI>(a, g, rows[0], rows[1], acc[0], acc[1]);
+        } else {
+            if (EPI == EPI_RESID) a.y[g] += acc[0]; else a.y[g] = acc[0];
         }
-        while (rem >= PF) { chunk2<WT, PF>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += PF * WAVE; rem -= PF; }
-        if (PF > 4 && rem >= 4) { chunk2<WT, 4>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += 4 * WAVE; rem -= 4; }
-        if (PF > 2 && rem >= 2) { chunk2<WT, 2>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += 2 * WAVE; rem -= 2; }
-        if (rem >= 1) { chunk2<WT, 1>(w0, w1, s0, s1, xs, v, nvec, a0, a1); v += WAVE; }
-        if (v < nvec) chunk2<WT, 1>(w0, w1, s0, s1, xs, v, nvec, a0, a1);  // ragged tail (small shapes)
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        if (lane == 0) gemv_epilogue<WT, EPI>(a, g, r0, r1, a0, a1);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Attention for one query head per block (llama2.f90:572-598 + softmax :468-478).
 // GQA: head h reads kv head h/kv_mul (the intended semantics of the slice at :581/:591).
-// Scores: HS/4 lanes share one timestep (16-byte K reads, contiguous per timestep);
-// PV: lane <-> output dim, timesteps strided over 256/HS slices, reduced through LDS.
+// Decode attention is a latency problem, not a bandwidth one (pos*512 B per head): every K (and
+// V) vector a thread needs for a 16-deep batch is requested before the first one is used, with
+// the timestep CLAMPED to pos-1 instead of predicated (a predicate would make hipcc branch around
+// each load and drain vmcnt per element).  HS/4 lanes share one timestep (16-byte reads, one
+// contiguous head row per timestep); the same lane mapping serves QK^T and PV.
 // ------------------------------------------------------------------------------------------------
+constexpr int ATT_U = 16;  // timestep batches in flight per thread
+
 template <int HS>
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                    const float* __restrict__ vc, float* __restrict__ xb,
                                                    const int* __restrict__ tokpos, int KV, int kv_mul) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* red = reinterpret_cast<float*>(smem_raw);   // [256]
-    float* red4 = red + 256;                           // [4]
-    float* att = red + 260;                            // [pos] (capacity S); offset 1040 B = 65*16
-    constexpr int LPT = HS / 4;    // lanes per timestep
-    constexpr int TPW = 64 / LPT;  // timesteps per wave-iteration
-    constexpr int NSL = 256 / HS;  // PV timestep slices
+    float4* red = reinterpret_cast<float4*>(smem_raw);            // [4 waves][HS/4] float4  (<= 2 KB)
+    float* red4 = reinterpret_cast<float*>(smem_raw) + 512;       // [4]
+    float* att = reinterpret_cast<float*>(smem_raw) + 516;        // [pos] (capacity S)
+    constexpr int LPT = HS / 4;         // lanes per timestep
+    constexpr int TPW = 64 / LPT;       // timesteps per wave-instruction
+    constexpr int TPB = 4 * TPW;        // timesteps per block-instruction
+    constexpr int TILE = TPB * ATT_U;   // timesteps per batch
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, g = h / kv_mul;
@@ -357,22 +361,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
     const int sub = lane % LPT, tl = lane / LPT;
     const float4 qv = reinterpret_cast<const float4*>(q + (size_t)h * HS)[sub];
     const float scale = sqrtf((float)HS);
-    const float* kg = kc + (size_t)g * HS;
-    const float* vg = vc + (size_t)g * HS;
+    const float4* kg = reinterpret_cast<const float4*>(kc + (size_t)g * HS) + sub;
+    const float4* vg = reinterpret_cast<const float4*>(vc + (size_t)g * HS) + sub;
+    const int kv4 = KV >> 2;            // float4 stride between timesteps
+    const int tb = wid * TPW + tl;      // this thread's timestep within a block-instruction
 
-    for (int t0 = wid * TPW; t0 < pos; t0 += 4 * TPW) {
-        const int t = t0 + tl;
-        float d = 0.f;
-        if (t < pos) {
-            const float4 kv = reinterpret_cast<const float4*>(kg + (size_t)t * KV)[sub];
-            d = dot4(qv, kv, 0.f);
+    // ---- scores: att[t] = q.k_t / sqrt(hs)                                       :578-583
+    for (int base = 0; base < pos; base += TILE) {
+        float4 kv[ATT_U];
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int t = min(base + u * TPB + tb, pos - 1);
+            kv[u] = kg[(size_t)t * kv4];
         }
 #pragma unroll
-        for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-        if (sub == 0 && t < pos) att[t] = d / scale;  // dot_product(q_t,k_t)/sqrt(real(head_size))  :582
+        for (int u = 0; u < ATT_U; ++u) {
+            const int t = base + u * TPB + tb;
+            float d = dot4(qv, kv[u], 0.f);
+#pragma unroll
+            for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (sub == 0 && t < pos) att[t] = d / scale;
+        }
     }
+    // first V batch is requested before the softmax: it does not depend on the scores
+    float4 vv[ATT_U];
+#pragma unroll
+    for (int u = 0; u < ATT_U; ++u) vv[u] = vg[(size_t)min(u * TPB + tb, pos - 1) * kv4];
     __syncthreads();
 
+    // ---- softmax over t < pos                                                    :468-478
     float m = -INFINITY;
     for (int t = tid; t < pos; t += 256) m = fmaxf(m, att[t]);
     m = wave_max(m);
@@ -393,16 +410,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
     for (int t = tid; t < pos; t += 256) att[t] = att[t] / s;  // p(:s) = xi/sum(xi)   :476
     __syncthreads();
 
-    const int d = tid % HS, sl = tid / HS;
-    float acc = 0.f;
-    for (int t = sl; t < pos; t += NSL) acc = fmaf(att[t], vg[(size_t)t * KV + d], acc);
-    red[tid] = acc;
-    __syncthreads();
-    if (tid < HS) {
-        float o = 0.f;
+    // ---- xb_h = sum_t p_t * v_t                                                  :589-596
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < pos; base += TILE) {
+        if (base > 0) {
 #pragma unroll
-        for (int i = 0; i < NSL; ++i) o += red[i * HS + tid];
-        xb[(size_t)h * HS + tid] = o;
+            for (int u = 0; u < ATT_U; ++u) vv[u] = vg[(size_t)min(base + u * TPB + tb, pos - 1) * kv4];
+        }
+#pragma unroll
+        for (int u = 0; u < ATT_U; ++u) {
+            const int t = base + u * TPB + tb;
+            const float p = (t < pos) ? att[t] : 0.f;
+            acc.x = fmaf(p, vv[u].x, acc.x);
+            acc.y = fmaf(p, vv[u].y, acc.y);
+            acc.z = fmaf(p, vv[u].z, acc.z);
+            acc.w = fmaf(p, vv[u].w, acc.w);
+        }
+    }
+#pragma unroll
+    for (int o = LPT; o < 64; o <<= 1) {  // fold the TPW timestep groups of the wave
+        acc.x += __shfl_xor(acc.x, o, 64);
+        acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64);
+        acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (tl == 0) red[wid * LPT + sub] = acc;
+    __syncthreads();
+    if (tid < LPT) {
+        float4 a = red[tid], b = red[LPT + tid], c = red[2 * LPT + tid], d = red[3 * LPT + tid];
+        float4 o;
+        o.x = (a.x + b.x) + (c.x + d.x);
+        o.y = (a.y + b.y) + (c.y + d.y);
+        o.z = (a.z + b.z) + (c.z + d.z);
+        o.w = (a.w + b.w) + (c.w + d.w);
+        reinterpret_cast<float4*>(xb + (size_t)h * HS)[tid] = o;
     }
 }
 

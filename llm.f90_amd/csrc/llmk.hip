@@ -78,30 +78,43 @@ size_t row_bytes_for(int type, int K) {
     return 0;
 }
 
-template <int WT, int EPI, bool NORM>
-hipError_t launch_gemv(hipStream_t st, const GemvArgs& a, int n_cu) {
-    const int ngroups = (EPI == EPI_SWIGLU) ? a.H : a.rows / 2;
-    int blocks = (ngroups + GEMV_WAVES - 1) / GEMV_WAVES;
-    const int cap = n_cu * 8;  // beyond 8 blocks per CU the waves loop over further row groups
-    if (blocks > cap) blocks = cap;
+template <int WT, int EPI, bool NORM, int ROWS, int NCH>
+hipError_t launch_gemv(hipStream_t st, const GemvArgs& a) {
+    const int njobs = (EPI == EPI_SWIGLU) ? a.H : a.rows / ROWS;
+    const int blocks = (njobs + GEMV_WAVES - 1) / GEMV_WAVES;
     const size_t smem = 16 + (size_t)a.K * sizeof(float);
-    hipLaunchKernelGGL((gemv_kernel<WT, EPI, NORM>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a);
+    hipLaunchKernelGGL((gemv_kernel<WT, EPI, NORM, ROWS, NCH>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a);
     return hipGetLastError();
 }
 
+// Tile shapes: ROWS x NCH 16-byte vectors per lane are requested up front (<= ~88 VGPRs).
+//   f32  K=2048: 2 rows x 8 = the whole pair (16 KB/wave);  K=5632 (w2): 1 row x 22 = whole row
+//   f16  K=2048: 2 x 4;                                      K=5632: 1 x 11
+//   q4_0 K=4096: 2 x 2
 template <int EPI, bool NORM>
-hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
+hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int /*n_cu*/) {
+    constexpr bool single_ok = (EPI == EPI_STORE || EPI == EPI_RESID) && !NORM;
     switch (wt) {
-        case LLMK_TYPE_F32: return launch_gemv<WT_F32, EPI, NORM>(st, a, n_cu);
-        case LLMK_TYPE_F16: return launch_gemv<WT_F16, EPI, NORM>(st, a, n_cu);
-        default: return launch_gemv<WT_Q4_0, EPI, NORM>(st, a, n_cu);
+        case LLMK_TYPE_F32: {
+            const int ncol = a.K / 4 / WAVE;
+            if constexpr (single_ok)
+                if (ncol % 22 == 0) return launch_gemv<WT_F32, EPI, NORM, 1, 22>(st, a);
+            return launch_gemv<WT_F32, EPI, NORM, 2, 8>(st, a);
+        }
+        case LLMK_TYPE_F16: {
+            const int ncol = a.K / 8 / WAVE;
+            if constexpr (single_ok)
+                if (ncol % 11 == 0) return launch_gemv<WT_F16, EPI, NORM, 1, 11>(st, a);
+            return launch_gemv<WT_F16, EPI, NORM, 2, 4>(st, a);
+        }
+        default: return launch_gemv<WT_Q4_0, EPI, NORM, 2, 2>(st, a);
     }
 }
 
 hipError_t launch_attn(llmk_ctx* c, int l) {
     const float* kc = c->d_kc + (size_t)l * c->S * c->KV;
     const float* vc = c->d_vc + (size_t)l * c->S * c->KV;
-    const size_t smem = (260 + (size_t)c->S) * sizeof(float);
+    const size_t smem = (516 + (size_t)c->S) * sizeof(float);
 #define ATT(HS_)                                                                                                 \
     hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nh), dim3(256), smem, c->stream, c->d_q, kc, vc, c->d_xb,      \
                        c->d_tokpos, c->KV, c->kv_mul)
