@@ -1,0 +1,475 @@
+! GGUF model loader for the Fortran host.  Drop-in for the reference's
+!   call load_ggml(filename, w, c, vocab, scores, token_lengths, v)     (/root/reference/read_ggml.f90:53-60)
+! same module name, same argument list, same fused weight layout (Q|K|V rows in wqkv, gate|up
+! rows in w13: read_ggml.f90:272,286,300,347,376), same console output in the non-verbose case
+! (the unconditional " data offset" line, read_ggml.f90:196).
+!
+! Written from the GGUF file format, not from the reference's code.  Differences on purpose:
+!   * every GGUF metadata value type is understood (the reference stops on anything but
+!     int32/uint32/float32/string/array, read_ggml.f90:663-685) so stock llama.cpp files load;
+!   * matrices of ggml type 1 (f16) and 2 (q4_0) are kept as raw bytes (w%*_raw, w%wtype) and
+!     go to the GPU undecoded; the embedding table (gathered, not streamed) is always widened
+!     to f32 on the host;
+!   * positioning uses standard stream I/O (read(..., pos=)) instead of the GNU fseek extension.
+module read_ggml
+  use iso_c_binding
+  use precision_module
+  use weight_module
+  implicit none
+  private
+  public :: load_ggml, half_bits_to_real
+
+  integer(4), parameter :: GGUF_MAGIC = 1179993927     ! "GGUF", read_ggml.f90:122
+  integer, parameter :: NAME_LEN = 64                  ! reference truncates names/tokens to 64 chars
+  integer, parameter :: GT_F32 = 0, GT_F16 = 1, GT_Q4_0 = 2
+
+  type :: tensor_entry
+     character(len=NAME_LEN) :: name = ""
+     integer :: ndim = 0
+     integer(8) :: dims(4) = 1
+     integer :: ttype = 0
+     integer(8) :: offset = 0
+  end type tensor_entry
+
+  type(tensor_entry), allocatable :: dir(:)
+  integer(8) :: data_pos          ! 1-based stream position of the tensor data section
+  integer :: u                    ! unit
+
+contains
+
+  subroutine load_ggml(filename, w, c, vocab, scores, token_lengths, v)
+    character(len=*), intent(in) :: filename
+    type(TransformerWeights), intent(out) :: w
+    type(Config), intent(out) :: c
+    real(kind=wp), allocatable, intent(out) :: scores(:)
+    character(:), dimension(:), allocatable, intent(out) :: vocab
+    integer(4), allocatable, intent(out) :: token_lengths(:)
+    logical, intent(in) :: v
+
+    integer(4) :: magic, version, vtype, etype
+    integer(8) :: n_tensors, n_kv, i, j, n, slen, p, tokens_pos, n_tokens, ival
+    integer :: alignment, ios, width, l
+    integer(4) :: n_layers, emb, ctx_len, n_heads, n_kv_heads, ffn, vocab_size
+    character(len=:), allocatable :: key, str
+    logical :: have_kv_heads
+    integer :: E, H, KV, hs, mt
+    integer(1) :: b3(3)
+    character(len=NAME_LEN) :: tname
+
+    alignment = 32; n_layers = 0; emb = 0; ctx_len = 0; n_heads = 0; n_kv_heads = 0; ffn = 0
+    vocab_size = 0; tokens_pos = 0; n_tokens = 0; have_kv_heads = .false.
+
+    open(newunit=u, file=filename, form="unformatted", access="stream", status="old", action="read", iostat=ios)
+    if (ios /= 0) then
+       print *, "cannot open model file ", trim(filename)
+       stop 1
+    end if
+
+    read(u) magic, version, n_tensors, n_kv
+    if (v) then
+       print *, "GGUF Header Info"
+       print *, "Magic number: ", magic
+       print *, "Version: ", version
+       print *, "Tensor Count: ", n_tensors
+       print *, "Key-Value Pairs: ", n_kv
+    end if
+    if (magic /= GGUF_MAGIC) then
+       print *, "Magic numbers do not match, exiting"
+       stop
+    end if
+
+    ! ---- metadata ---------------------------------------------------------------------------
+    do i = 1, n_kv
+       call read_string(key)
+       read(u) vtype
+       select case (vtype)
+       case (8)
+          call read_string(str)
+          if (v) print *, key, " = ", str
+       case (9)
+          read(u) etype, n
+          if (key == "tokenizer.ggml.tokens" .and. etype == 8) then
+             inquire(unit=u, pos=tokens_pos)
+             n_tokens = n
+             vocab_size = int(n, 4)
+             do j = 1, n                      ! first pass: only skip (lengths are re-read below)
+                read(u) slen
+                inquire(unit=u, pos=p)
+                read(u, pos=p + slen - 1) b3(1)
+             end do
+          else if (key == "tokenizer.ggml.scores" .and. etype == 6) then
+             allocate(scores(n))
+             read(u) scores
+          else
+             call skip_array(etype, n)
+          end if
+          if (v) print *, key, " : array of", n
+       case default
+          ival = read_scalar(vtype)
+          if (v) print *, key, " = ", ival
+          select case (key)
+          case ("general.alignment");               alignment = int(ival)
+          case ("llama.block_count");                n_layers = int(ival, 4)
+          case ("llama.embedding_length");           emb = int(ival, 4)
+          case ("llama.attention.head_count");       n_heads = int(ival, 4)
+          case ("llama.attention.head_count_kv");    n_kv_heads = int(ival, 4); have_kv_heads = .true.
+          case ("llama.context_length");             ctx_len = int(ival, 4)
+          case ("llama.feed_forward_length");        ffn = int(ival, 4)
+          end select
+       end select
+    end do
+    if (.not. have_kv_heads) n_kv_heads = n_heads
+    if (n_layers <= 0 .or. emb <= 0 .or. n_heads <= 0 .or. ffn <= 0 .or. vocab_size <= 0) then
+       print *, "model file lacks llama.* shape keys or a tokenizer"
+       stop 1
+    end if
+
+    ! ---- tensor directory -------------------------------------------------------------------
+    allocate(dir(n_tensors))
+    do i = 1, n_tensors
+       call read_string(str)
+       dir(i)%name = str
+       read(u) dir(i)%ndim
+       if (dir(i)%ndim > 4) then
+          print *, "Ndims not supported", dir(i)%ndim
+          stop 1
+       end if
+       do j = 1, dir(i)%ndim
+          read(u) dir(i)%dims(j)
+       end do
+       read(u) dir(i)%ttype
+       read(u) dir(i)%offset
+    end do
+
+    ! data section starts at the next multiple of `alignment` (0-based offset), read_ggml.f90:176-194
+    inquire(unit=u, pos=p)
+    data_pos = ((p - 1 + alignment - 1) / alignment) * alignment + 1
+    if (v) then
+       print *, "Position", p
+       print *, "Deficit", mod(p - 1, int(alignment, 8))
+    end if
+    print *, "data offset", int(data_pos, 4)
+
+    E = emb; H = ffn; hs = emb / n_heads; KV = n_kv_heads * hs
+    c%emb_dim = emb; c%hidden_dim = ffn; c%n_layers = n_layers; c%n_heads = n_heads
+    c%n_kv_heads = n_kv_heads; c%vocab_size = vocab_size; c%seq_len = ctx_len; c%kv_head_size = KV
+    if (v) then
+       print *, "Embedding dimension: ", emb
+       print *, "Hidden dimension: ", ffn
+       print *, "Layers: ", n_layers
+       print *, "Heads: ", n_heads
+       print *, "kv Heads: ", n_kv_heads
+       print *, "Vocabulary Size: ", vocab_size
+       print *, "Sequence Length: ", ctx_len
+       print *, "head size ", hs
+       print *, "kv head Size ", KV
+    end if
+
+    ! ---- weights ----------------------------------------------------------------------------
+    mt = dir(find("blk.0.attn_q.weight"))%ttype
+    if (mt /= GT_F32 .and. mt /= GT_F16 .and. mt /= GT_Q4_0) then
+       print *, "Type not supported", mt
+       stop 1
+    end if
+    w%wtype = mt
+
+    allocate(w%token_embedding_table(E, vocab_size))
+    call read_matrix_as_f32("token_embd.weight", w%token_embedding_table, E, vocab_size)
+    if (v) print *, "loaded embedding weights:", size(w%token_embedding_table)
+
+    allocate(w%rms_att_weight(E, n_layers), w%rms_ffn_weight(E, n_layers), w%rms_final_weight(E))
+    do l = 1, n_layers
+       call read_vector(layer_name(l, "attn_norm.weight"), w%rms_att_weight(:, l), E)
+       call read_vector(layer_name(l, "ffn_norm.weight"), w%rms_ffn_weight(:, l), E)
+    end do
+    call read_vector("output_norm.weight", w%rms_final_weight, E)
+    if (v) print *, "loaded rms weights:", size(w%rms_att_weight), size(w%rms_ffn_weight), size(w%rms_final_weight)
+
+    if (mt == GT_F32) then
+       allocate(w%wqkv(E, E + 2*KV, n_layers), w%wo(E, E, n_layers), w%w13(E, 2*H, n_layers), &
+                w%w2(H, E, n_layers), w%wcls(E, vocab_size))
+       do l = 1, n_layers
+          call read_f32(layer_name(l, "attn_q.weight"), w%wqkv(:, 1:E, l), E, E)
+          call read_f32(layer_name(l, "attn_k.weight"), w%wqkv(:, E+1:E+KV, l), E, KV)
+          call read_f32(layer_name(l, "attn_v.weight"), w%wqkv(:, E+KV+1:E+2*KV, l), E, KV)
+          call read_f32(layer_name(l, "attn_output.weight"), w%wo(:, :, l), E, E)
+          call read_f32(layer_name(l, "ffn_gate.weight"), w%w13(:, 1:H, l), E, H)
+          call read_f32(layer_name(l, "ffn_up.weight"), w%w13(:, H+1:2*H, l), E, H)
+          call read_f32(layer_name(l, "ffn_down.weight"), w%w2(:, :, l), H, E)
+       end do
+       call read_f32("output.weight", w%wcls, E, vocab_size)
+    else
+       allocate(w%wqkv_raw(rowbytes(mt, E) * (E + 2*KV) * n_layers), w%wo_raw(rowbytes(mt, E) * E * n_layers), &
+                w%w13_raw(rowbytes(mt, E) * 2*H * n_layers), w%w2_raw(rowbytes(mt, H) * E * n_layers), &
+                w%wcls_raw(rowbytes(mt, E) * vocab_size))
+       do l = 1, n_layers
+          call read_raw(layer_name(l, "attn_q.weight"), w%wqkv_raw, mt, E, E, int(l-1, 8) * (E + 2*KV))
+          call read_raw(layer_name(l, "attn_k.weight"), w%wqkv_raw, mt, E, KV, int(l-1, 8) * (E + 2*KV) + E)
+          call read_raw(layer_name(l, "attn_v.weight"), w%wqkv_raw, mt, E, KV, int(l-1, 8) * (E + 2*KV) + E + KV)
+          call read_raw(layer_name(l, "attn_output.weight"), w%wo_raw, mt, E, E, int(l-1, 8) * E)
+          call read_raw(layer_name(l, "ffn_gate.weight"), w%w13_raw, mt, E, H, int(l-1, 8) * 2*H)
+          call read_raw(layer_name(l, "ffn_up.weight"), w%w13_raw, mt, E, H, int(l-1, 8) * 2*H + H)
+          call read_raw(layer_name(l, "ffn_down.weight"), w%w2_raw, mt, H, E, int(l-1, 8) * E)
+       end do
+       call read_raw("output.weight", w%wcls_raw, mt, E, vocab_size, 0_8)
+    end if
+    if (v) print *, "loaded matmul weights, ggml type", mt
+
+    ! ---- vocabulary (second visit of the tokens array) ---------------------------------------
+    if (tokens_pos == 0 .or. .not. allocated(scores)) then
+       print *, "model file has no tokenizer.ggml.tokens / tokenizer.ggml.scores"
+       stop 1
+    end if
+    width = NAME_LEN
+    allocate(character(len=width) :: vocab(n_tokens))
+    allocate(token_lengths(n_tokens))
+    p = tokens_pos
+    do j = 1, n_tokens
+       read(u, pos=p) slen
+       allocate(character(len=int(slen)) :: str)
+       if (slen > 0) read(u) str
+       p = p + 8 + slen
+       n = min(slen, int(width, 8))
+       vocab(j) = str(1:n)
+       token_lengths(j) = int(n, 4)
+       ! sentencepiece's U+2581 (bytes E2 96 81) in front of a token stands for a space (read_ggml.f90:479-497)
+       if (n >= 3) then
+          if (iachar(str(1:1)) == 226 .and. iachar(str(2:2)) == 150 .and. iachar(str(3:3)) == 129) then
+             vocab(j) = " " // str(4:n)
+             token_lengths(j) = int(n - 2, 4)
+          end if
+       end if
+       deallocate(str)
+    end do
+    if (v) then
+       write (*, "(A,I0,A)") "found ", size(vocab), " tokens"
+       write (*, "(A,I0,A)") "found ", size(scores), " scores"
+       print *, "maximum token length ", maxval(token_lengths)
+    end if
+
+    close(u)
+    deallocate(dir)
+
+  contains
+
+    function layer_name(l1, suffix) result(nm)
+      integer, intent(in) :: l1
+      character(len=*), intent(in) :: suffix
+      character(len=NAME_LEN) :: nm
+      write (nm, "(A,I0,A,A)") "blk.", l1 - 1, ".", suffix
+    end function
+
+  end subroutine load_ggml
+
+  ! ---------------------------------------------------------------------------------------------
+  subroutine read_string(s)
+    character(len=:), allocatable, intent(out) :: s
+    integer(8) :: n
+    read(u) n
+    allocate(character(len=int(n)) :: s)
+    if (n > 0) read(u) s
+  end subroutine
+
+  ! any non-string, non-array GGUF value as a 64-bit integer (floats are truncated; unused)
+  function read_scalar(vtype) result(val)
+    integer(4), intent(in) :: vtype
+    integer(8) :: val
+    integer(1) :: i1
+    integer(2) :: i2
+    integer(4) :: i4
+    integer(8) :: i8
+    real(4) :: r4
+    real(8) :: r8
+    select case (vtype)
+    case (0, 1, 7)                 ! uint8, int8, bool
+       read(u) i1; val = iand(int(i1, 8), 255_8)
+    case (2, 3)                    ! uint16, int16
+       read(u) i2; val = iand(int(i2, 8), 65535_8)
+    case (4, 5)                    ! uint32, int32
+       read(u) i4; val = int(i4, 8)
+    case (6)
+       read(u) r4; val = int(r4, 8)
+    case (10, 11)
+       read(u) i8; val = i8
+    case (12)
+       read(u) r8; val = int(r8, 8)
+    case default
+       print *, "Not implemented", vtype          ! the reference's message, read_ggml.f90:683
+       stop
+    end select
+  end function
+
+  subroutine skip_array(etype, n)
+    integer(4), intent(in) :: etype
+    integer(8), intent(in) :: n
+    integer(8) :: j, slen, p, esz
+    integer(4) :: sub_t
+    integer(8) :: sub_n
+    integer(1) :: b
+    select case (etype)
+    case (0, 1, 7);  esz = 1
+    case (2, 3);     esz = 2
+    case (4, 5, 6);  esz = 4
+    case (10, 11, 12); esz = 8
+    case (8)
+       do j = 1, n
+          read(u) slen
+          if (slen > 0) then
+             inquire(unit=u, pos=p)
+             read(u, pos=p + slen - 1) b
+          end if
+       end do
+       return
+    case (9)
+       do j = 1, n
+          read(u) sub_t, sub_n
+          call skip_array(sub_t, sub_n)
+       end do
+       return
+    case default
+       print *, "Not implemented", etype
+       stop
+    end select
+    if (n * esz > 0) then
+       inquire(unit=u, pos=p)
+       read(u, pos=p + n * esz - 1) b
+    end if
+  end subroutine
+
+  function find(name) result(idx)
+    character(len=*), intent(in) :: name
+    integer :: idx
+    do idx = 1, size(dir)
+       if (dir(idx)%name == name) return
+    end do
+    print *, "key not found", name                 ! read_ggml.f90:571
+    stop
+  end function
+
+  pure function rowbytes(t, k) result(nb)
+    integer, intent(in) :: t, k
+    integer(8) :: nb
+    select case (t)
+    case (GT_F16);  nb = 2_8 * k
+    case (GT_Q4_0); nb = int(k / 32, 8) * 18_8
+    case default;   nb = 4_8 * k
+    end select
+  end function
+
+  subroutine check_shape(idx, cols, rows)
+    integer, intent(in) :: idx, cols, rows
+    if (dir(idx)%dims(1) /= cols .or. product(dir(idx)%dims(2:max(2, dir(idx)%ndim))) /= rows) then
+       print *, "unexpected tensor shape for ", trim(dir(idx)%name), dir(idx)%dims(1:dir(idx)%ndim)
+       stop 1
+    end if
+  end subroutine
+
+  subroutine read_vector(name, dst, n)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    real(kind=wp), intent(out) :: dst(n)
+    integer :: idx
+    idx = find(name)
+    if (dir(idx)%ttype /= GT_F32 .or. dir(idx)%dims(1) /= n) then
+       print *, "Type not supported", dir(idx)%ttype, " for ", trim(name)
+       stop 1
+    end if
+    read(u, pos=data_pos + dir(idx)%offset) dst
+  end subroutine
+
+  subroutine read_f32(name, dst, cols, rows)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: cols, rows
+    real(kind=wp), intent(out) :: dst(cols, rows)
+    integer :: idx
+    idx = find(name)
+    call check_shape(idx, cols, rows)
+    if (dir(idx)%ttype /= GT_F32) then
+       print *, "Type not supported", dir(idx)%ttype, " (mixed matrix types) for ", trim(name)
+       stop 1
+    end if
+    read(u, pos=data_pos + dir(idx)%offset) dst
+  end subroutine
+
+  subroutine read_raw(name, dst, t, cols, rows, first_row)
+    character(len=*), intent(in) :: name
+    integer(c_int8_t), intent(inout) :: dst(:)
+    integer, intent(in) :: t, cols, rows
+    integer(8), intent(in) :: first_row
+    integer :: idx
+    integer(8) :: b0, nb
+    idx = find(name)
+    call check_shape(idx, cols, rows)
+    if (dir(idx)%ttype /= t) then
+       print *, "Type not supported", dir(idx)%ttype, " (mixed matrix types) for ", trim(name)
+       stop 1
+    end if
+    b0 = first_row * rowbytes(t, cols)
+    nb = rows * rowbytes(t, cols)
+    read(u, pos=data_pos + dir(idx)%offset) dst(b0 + 1:b0 + nb)
+  end subroutine
+
+  ! the embedding table is gathered on the device as f32 whatever its file type
+  subroutine read_matrix_as_f32(name, dst, cols, rows)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: cols, rows
+    real(kind=wp), intent(out) :: dst(cols, rows)
+    integer :: idx, r, b, k
+    integer(2), allocatable :: hrow(:)
+    integer(1), allocatable :: qrow(:)
+    real(kind=wp) :: d
+    integer :: q
+    idx = find(name)
+    call check_shape(idx, cols, rows)
+    select case (dir(idx)%ttype)
+    case (GT_F32)
+       read(u, pos=data_pos + dir(idx)%offset) dst
+    case (GT_F16)
+       allocate(hrow(cols))
+       read(u, pos=data_pos + dir(idx)%offset)
+       do r = 1, rows
+          read(u) hrow
+          do k = 1, cols
+             dst(k, r) = half_bits_to_real(hrow(k))
+          end do
+       end do
+    case (GT_Q4_0)                 ! ggml block_q4_0: f16 d, 16 bytes; lo nibbles = 0..15, hi = 16..31
+       allocate(qrow(cols / 32 * 18))
+       read(u, pos=data_pos + dir(idx)%offset)
+       do r = 1, rows
+          read(u) qrow
+          do b = 0, cols / 32 - 1
+             d = half_bits_to_real(transfer(qrow(b*18 + 1:b*18 + 2), 0_2))
+             do k = 1, 16
+                q = iand(int(qrow(b*18 + 2 + k)), 255)
+                dst(b*32 + k, r) = real(iand(q, 15) - 8, wp) * d
+                dst(b*32 + 16 + k, r) = real(ishft(q, -4) - 8, wp) * d
+             end do
+          end do
+       end do
+    case default
+       print *, "Type not supported", dir(idx)%ttype
+       stop 1
+    end select
+  end subroutine
+
+  ! IEEE binary16 bit pattern -> f32 (exact)
+  elemental function half_bits_to_real(h) result(x)
+    integer(2), intent(in) :: h
+    real(kind=wp) :: x
+    integer(4) :: bits, s, e, m
+    bits = iand(int(h, 4), 65535)
+    s = ishft(iand(bits, 32768), 16)
+    e = iand(ishft(bits, -10), 31)
+    m = iand(bits, 1023)
+    if (e == 0) then
+       x = real(m, wp) * 2.0_wp**(-24)            ! zero / subnormal
+       if (s /= 0) x = -x
+    else if (e == 31) then
+       x = transfer(ior(s, ior(int(z'7F800000', 4), ishft(m, 13))), x)
+    else
+       x = transfer(ior(s, ior(ishft(e + 112, 23), ishft(m, 13))), x)
+    end if
+  end function
+
+end module read_ggml

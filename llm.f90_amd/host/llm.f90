@@ -1,0 +1,316 @@
+! `llm` -- the reference's command line (/root/reference/llama2.f90:4-83, :87-411) on top of the
+! MI355X decode path.  Same flags and defaults, same console output; the one call that did all the
+! work, `logits = transformer(token,pos,s,weights)` (llama2.f90:380), is now
+! `llmk_forward(ctx, token, pos, logits)` into hand-written gfx950 kernels (include/llmk.h).
+! Model dims come from the GGUF metadata at run time (the reference hard-codes TinyLlama's,
+! llama2.f90:102-108).  There is no CPU forward pass in this program.
+!
+!   ./llm -m model.gguf [-p prompt] [-n tokens] [-t temperature] [-s tokenizer.bin] [-v]
+!         [-d device] [--device-argmax]
+module arg_parse
+  implicit none
+
+  type args
+     real :: temperature
+     character(:), allocatable :: model_file
+     character(:), allocatable :: prompt
+     character(:), allocatable :: tokenizer
+     logical :: verbose, ak
+     integer :: n
+     integer :: device            ! extension: HIP device ordinal
+     logical :: device_argmax     ! extension: greedy pick on the GPU (SURVEY.md 8f rank 1)
+  end type args
+
+contains
+
+  subroutine parse_args(a)
+    type(args), intent(out) :: a
+    integer :: i, nargs
+    character(len=1024) :: opt, val
+
+    a%temperature = 0               ! defaults: llama2.f90:26-32
+    a%model_file = "stories15M.bin"
+    a%prompt = ""
+    a%tokenizer = ""
+    a%verbose = .false.
+    a%ak = .false.
+    a%n = 256
+    a%device = 0
+    a%device_argmax = .false.
+
+    nargs = command_argument_count()
+    i = 1
+    do while (i <= nargs)
+       call get_command_argument(i, opt)
+       val = ""
+       if (i < nargs) call get_command_argument(i + 1, val)
+       select case (trim(opt))
+       case ("-m", "--model");       a%model_file = trim(val); i = i + 2
+       case ("-p", "--prompt");      a%prompt = trim(val);     i = i + 2
+       case ("-s", "--tokenizer");   a%tokenizer = trim(val);  i = i + 2
+       case ("-t", "--temperature"); read (val, *) a%temperature; i = i + 2
+       case ("-n", "--num_tokens");  read (val, *) a%n;           i = i + 2
+       case ("-d", "--device");      read (val, *) a%device;      i = i + 2
+       case ("-v", "--verbose");     a%verbose = .true.;       i = i + 1
+       case ("--ak");                a%ak = .true.;            i = i + 1
+       case ("--device-argmax");     a%device_argmax = .true.; i = i + 1
+       case default
+          print *, "Unrecognized option:", trim(opt)
+          stop
+       end select
+    end do
+  end subroutine parse_args
+
+end module arg_parse
+
+
+program llm
+  use iso_c_binding
+  use precision_module
+  use weight_module
+  use arg_parse
+  use read_ggml, only: load_ggml
+  use llmk_binding
+  implicit none
+
+  type(args) :: opts
+  type(TransformerWeights), target :: weights
+  type(Config) :: conf
+  type(RunState) :: s
+  type(llmk_config) :: kcfg
+  type(c_ptr) :: ctx
+  real(kind=wp), allocatable, target :: logits(:)
+  real(kind=wp), allocatable :: scores(:), freqs(:), probs(:)
+  character(:), dimension(:), allocatable :: vocab
+  integer(4), allocatable :: vocab_len(:)
+  integer, allocatable :: prompt_tokens(:)
+  integer :: seq_len, pos, token, next_tok, l, hs, j, max_len
+  integer(c_int) :: flags, rc
+  real(kind=wp) :: t_start, t_end
+  real(c_float) :: ktimes(5)
+
+  call parse_args(opts)
+  if (opts%ak) then
+     print *, "--ak (llama2.c flat format) is not supported on the GPU path yet; use a GGUF file"
+     stop 1
+  end if
+
+  call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose)
+  if (opts%verbose) print *, "Loaded weights"
+  if (opts%tokenizer /= "") call read_tokenizer_bin(opts%tokenizer)
+  max_len = maxval(vocab_len)
+
+  ! ---- device context + one-time weight upload (the host arrays are not needed afterwards) -----
+  flags = 0
+  if (opts%verbose) flags = LLMK_FLAG_TIMINGS       ! the 5 section timers cost a sync per section
+  kcfg = llmk_config(conf%emb_dim, conf%hidden_dim, conf%n_layers, conf%n_heads, conf%n_kv_heads, &
+                     conf%vocab_size, conf%seq_len, weights%wtype, opts%device, flags)
+  call llmk_check(llmk_create(kcfg, ctx), "llmk_create")
+  call upload_weights()
+
+  ! RoPE frequencies with the reference's own expression (llama2.f90:544-545): for 1-based odd i,
+  ! head_dim = mod(i,head_size) = 1,3,5,...; freq = 1/10000**(head_dim/head_size)
+  hs = conf%emb_dim / conf%n_heads
+  allocate(freqs(hs / 2))
+  do j = 1, hs / 2
+     freqs(j) = 1.0 / (10000.0 ** (real(2*j - 1, kind=wp) / hs))
+  end do
+  call llmk_check(llmk_set_rope_freqs(ctx, freqs, int(hs / 2, c_int)), "llmk_set_rope_freqs")
+
+  allocate(logits(conf%vocab_size), probs(conf%vocab_size))
+  s%times = 0
+
+  seq_len = conf%seq_len
+  if (opts%n <= seq_len) then                        ! llama2.f90:363-368
+     seq_len = opts%n
+  else
+     print *, opts%n, "greater than maxinum squence length"
+     print *, "set to", seq_len
+  end if
+
+  prompt_tokens = bpe_encode(opts%prompt)
+
+  ! ---- generation loop (llama2.f90:376-402) -------------------------------------------------------
+  t_start = 0
+  token = 2                                          ! BOS: 1-based index of <s>
+  do pos = 1, seq_len
+     if (opts%device_argmax .and. opts%temperature == 0 .and. pos > size(prompt_tokens)) then
+        call llmk_check(llmk_forward_greedy(ctx, int(token, c_int), int(pos, c_int), rc), "llmk_forward_greedy")
+        next_tok = rc
+     else
+        call llmk_check(llmk_forward(ctx, int(token, c_int), int(pos, c_int), logits), "llmk_forward")
+        if (pos <= size(prompt_tokens)) then
+           next_tok = prompt_tokens(pos)
+        else if (opts%temperature == 0) then
+           next_tok = maxloc(logits, dim=1)
+        else
+           probs = softmax_t(logits / opts%temperature)
+           next_tok = sample(probs)
+        end if
+     end if
+     token = next_tok
+     write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
+     if (t_start == 0) t_start = time_ms()           ! clock starts after the first token
+  end do
+  t_end = time_ms()
+
+  call llmk_check(llmk_timings(ctx, ktimes), "llmk_timings")
+  s%times = ktimes
+  print *, ""
+  print *, "Inference time: ", (t_end - t_start) / 1000, " seconds"
+  print *, 1000 * (seq_len - 1) / (t_end - t_start), "tokens/second"
+  print *, "Timings"
+  do l = 1, 5
+     print *, l, s%times(l) / seq_len
+  end do
+  rc = llmk_destroy(ctx)
+
+contains
+
+  subroutine upload_weights()
+    integer(c_size_t) :: f4
+    f4 = 4
+    call llmk_check(llmk_upload(ctx, LLMK_TOKEN_EMBEDDING_TABLE, c_loc(weights%token_embedding_table), &
+         f4 * size(weights%token_embedding_table, kind=c_size_t), LLMK_TYPE_F32), "upload token_embedding_table")
+    call llmk_check(llmk_upload(ctx, LLMK_RMS_ATT_WEIGHT, c_loc(weights%rms_att_weight), &
+         f4 * size(weights%rms_att_weight, kind=c_size_t), LLMK_TYPE_F32), "upload rms_att_weight")
+    call llmk_check(llmk_upload(ctx, LLMK_RMS_FFN_WEIGHT, c_loc(weights%rms_ffn_weight), &
+         f4 * size(weights%rms_ffn_weight, kind=c_size_t), LLMK_TYPE_F32), "upload rms_ffn_weight")
+    call llmk_check(llmk_upload(ctx, LLMK_RMS_FINAL_WEIGHT, c_loc(weights%rms_final_weight), &
+         f4 * size(weights%rms_final_weight, kind=c_size_t), LLMK_TYPE_F32), "upload rms_final_weight")
+    if (weights%wtype == LLMK_TYPE_F32) then
+       call llmk_check(llmk_upload(ctx, LLMK_WQKV, c_loc(weights%wqkv), f4 * size(weights%wqkv, kind=c_size_t), &
+            LLMK_TYPE_F32), "upload wqkv")
+       call llmk_check(llmk_upload(ctx, LLMK_WO, c_loc(weights%wo), f4 * size(weights%wo, kind=c_size_t), &
+            LLMK_TYPE_F32), "upload wo")
+       call llmk_check(llmk_upload(ctx, LLMK_W13, c_loc(weights%w13), f4 * size(weights%w13, kind=c_size_t), &
+            LLMK_TYPE_F32), "upload w13")
+       call llmk_check(llmk_upload(ctx, LLMK_W2, c_loc(weights%w2), f4 * size(weights%w2, kind=c_size_t), &
+            LLMK_TYPE_F32), "upload w2")
+       call llmk_check(llmk_upload(ctx, LLMK_WCLS, c_loc(weights%wcls), f4 * size(weights%wcls, kind=c_size_t), &
+            LLMK_TYPE_F32), "upload wcls")
+       deallocate(weights%wqkv, weights%wo, weights%w13, weights%w2, weights%wcls)
+    else
+       call llmk_check(llmk_upload(ctx, LLMK_WQKV, c_loc(weights%wqkv_raw), size(weights%wqkv_raw, kind=c_size_t), &
+            int(weights%wtype, c_int)), "upload wqkv")
+       call llmk_check(llmk_upload(ctx, LLMK_WO, c_loc(weights%wo_raw), size(weights%wo_raw, kind=c_size_t), &
+            int(weights%wtype, c_int)), "upload wo")
+       call llmk_check(llmk_upload(ctx, LLMK_W13, c_loc(weights%w13_raw), size(weights%w13_raw, kind=c_size_t), &
+            int(weights%wtype, c_int)), "upload w13")
+       call llmk_check(llmk_upload(ctx, LLMK_W2, c_loc(weights%w2_raw), size(weights%w2_raw, kind=c_size_t), &
+            int(weights%wtype, c_int)), "upload w2")
+       call llmk_check(llmk_upload(ctx, LLMK_WCLS, c_loc(weights%wcls_raw), size(weights%wcls_raw, kind=c_size_t), &
+            int(weights%wtype, c_int)), "upload wcls")
+       deallocate(weights%wqkv_raw, weights%wo_raw, weights%w13_raw, weights%w2_raw, weights%wcls_raw)
+    end if
+    deallocate(weights%token_embedding_table)
+  end subroutine upload_weights
+
+  ! wall clock in ms, 4-byte count like the reference (llama2.f90:417-423)
+  function time_ms() result(t_ms)
+    real(kind=wp) :: t_ms
+    integer(4) :: ticks
+    call system_clock(ticks)
+    t_ms = real(ticks)
+  end function time_ms
+
+  ! llama2.c tokenizer.bin: max_len, then (f32 score, i32 len, bytes) per token (llama2.f90:321-356)
+  subroutine read_tokenizer_bin(path)
+    character(len=*), intent(in) :: path
+    integer :: tu, n, tl, width
+    real(kind=wp) :: sc
+    character(len=:), allocatable :: buf
+    open(newunit=tu, file=path, form="unformatted", access="stream", status="old", action="read")
+    read(tu) width
+    if (allocated(vocab)) deallocate(vocab, scores, vocab_len)
+    allocate(character(len=width) :: vocab(conf%vocab_size))
+    allocate(scores(conf%vocab_size), vocab_len(conf%vocab_size))
+    do n = 1, conf%vocab_size
+       read(tu) sc
+       read(tu) tl
+       allocate(character(len=tl) :: buf)
+       read(tu) buf
+       vocab(n) = buf
+       scores(n) = sc
+       vocab_len(n) = tl
+       deallocate(buf)
+    end do
+    close(tu)
+  end subroutine read_tokenizer_bin
+
+  ! exact-match vocabulary lookup honouring the true token length (trailing blanks are data)
+  function lookup(str, n) result(idx)
+    character(len=*), intent(in) :: str
+    integer, intent(in) :: n
+    integer :: idx
+    do idx = 1, size(vocab)
+       if (vocab_len(idx) == n) then
+          if (vocab(idx)(1:n) == str(1:n)) return
+       end if
+    end do
+    idx = -1
+  end function lookup
+
+  ! llama2.c-style BPE (behaviour of llama2.f90:658-724): start from one token per byte, then
+  ! repeatedly fuse the adjacent pair whose concatenation is the best-scoring vocabulary entry.
+  function bpe_encode(text) result(tokens)
+    character(len=*), intent(in) :: text
+    integer, allocatable :: tokens(:)
+    integer :: n, i, best_i, best_tok, cand, la, lb
+    real(kind=wp) :: best_score
+    character(len=:), allocatable :: pair
+
+    n = len(text)
+    allocate(tokens(n))
+    do i = 1, n
+       tokens(i) = lookup(text(i:i), 1)
+    end do
+    do
+       best_score = -1e10
+       best_i = -1
+       best_tok = -1
+       do i = 1, n - 1
+          if (tokens(i) < 1 .or. tokens(i + 1) < 1) cycle
+          la = vocab_len(tokens(i))
+          lb = vocab_len(tokens(i + 1))
+          pair = vocab(tokens(i))(1:la) // vocab(tokens(i + 1))(1:lb)
+          cand = lookup(pair, la + lb)
+          if (cand > 0) then
+             if (scores(cand) > best_score) then
+                best_score = scores(cand)
+                best_i = i
+                best_tok = cand
+             end if
+          end if
+       end do
+       if (best_i < 0) exit
+       tokens(best_i) = best_tok
+       tokens(best_i + 1:n - 1) = tokens(best_i + 2:n)
+       n = n - 1
+    end do
+    tokens = tokens(1:n)
+  end function bpe_encode
+
+  ! softmax over the whole vocabulary for temperature sampling (llama2.f90:390, :468-478)
+  function softmax_t(x) result(p)
+    real(kind=wp), intent(in) :: x(:)
+    real(kind=wp) :: p(size(x))
+    p = exp(x - maxval(x))
+    p = p / sum(p)
+  end function softmax_t
+
+  ! inverse-CDF draw (llama2.f90:428-447)
+  function sample(p) result(idx)
+    real(kind=wp), intent(in) :: p(:)
+    integer :: idx
+    real(kind=wp) :: r, cdf
+    call random_number(r)
+    cdf = 0
+    do idx = 1, size(p)
+       cdf = cdf + p(idx)
+       if (r < cdf) return
+    end do
+    idx = size(p)
+  end function sample
+
+end program llm

@@ -1,0 +1,101 @@
+! ISO_C_BINDING interface to the llmk C-ABI (include/llmk.h).  One explicit interface per
+! exported symbol; constants mirror the header.  This is the whole device boundary of the host:
+! the call `logits = transformer(token,pos,s,weights)` (/root/reference/llama2.f90:380) becomes
+! `rc = llmk_forward(ctx, token, pos, logits)`.
+module llmk_binding
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: LLMK_TYPE_F32 = 0, LLMK_TYPE_F16 = 1, LLMK_TYPE_Q4_0 = 2
+  integer(c_int), parameter :: LLMK_TOKEN_EMBEDDING_TABLE = 0, LLMK_RMS_ATT_WEIGHT = 1, LLMK_RMS_FFN_WEIGHT = 2, &
+       LLMK_WQKV = 3, LLMK_WO = 4, LLMK_W13 = 5, LLMK_W2 = 6, LLMK_RMS_FINAL_WEIGHT = 7, LLMK_WCLS = 8
+  integer(c_int), parameter :: LLMK_FLAG_NO_GRAPH = 1, LLMK_FLAG_TIMINGS = 2
+
+  type, bind(C) :: llmk_config
+     integer(c_int32_t) :: emb_dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, seq_len
+     integer(c_int32_t) :: weight_type, device, flags
+  end type llmk_config
+
+  interface
+     integer(c_int) function llmk_create(cfg, ctx) bind(C, name="llmk_create")
+       import :: c_int, c_ptr, llmk_config
+       type(llmk_config), intent(in) :: cfg
+       type(c_ptr), intent(out) :: ctx
+     end function
+     integer(c_int) function llmk_upload(ctx, tensor_id, host, nbytes, ggml_type) bind(C, name="llmk_upload")
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: tensor_id
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: nbytes
+       integer(c_int), value :: ggml_type
+     end function
+     integer(c_int) function llmk_upload_rows(ctx, tensor_id, layer, row_offset, rows, host, nbytes, ggml_type) &
+          bind(C, name="llmk_upload_rows")
+       import :: c_int, c_ptr, c_size_t
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: tensor_id, layer, row_offset, rows
+       type(c_ptr), value :: host
+       integer(c_size_t), value :: nbytes
+       integer(c_int), value :: ggml_type
+     end function
+     integer(c_int) function llmk_set_rope_freqs(ctx, freqs, n) bind(C, name="llmk_set_rope_freqs")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       real(c_float), intent(in) :: freqs(*)
+       integer(c_int), value :: n
+     end function
+     integer(c_int) function llmk_forward(ctx, token, pos, logits) bind(C, name="llmk_forward")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: token, pos
+       real(c_float), intent(out) :: logits(*)
+     end function
+     integer(c_int) function llmk_forward_greedy(ctx, token, pos, next_token) bind(C, name="llmk_forward_greedy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: token, pos
+       integer(c_int), intent(out) :: next_token
+     end function
+     integer(c_int) function llmk_reset(ctx) bind(C, name="llmk_reset")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     integer(c_int) function llmk_timings(ctx, ms) bind(C, name="llmk_timings")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       real(c_float), intent(out) :: ms(5)
+     end function
+     integer(c_int) function llmk_destroy(ctx) bind(C, name="llmk_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
+     type(c_ptr) function llmk_strerror(code) bind(C, name="llmk_strerror")
+       import :: c_int, c_ptr
+       integer(c_int), value :: code
+     end function
+     integer(c_int) function llmk_version() bind(C, name="llmk_version")
+       import :: c_int
+     end function
+  end interface
+
+contains
+
+  ! print + stop, the reference's own error convention (read_ggml.f90:122-125)
+  subroutine llmk_check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: what
+    character(kind=c_char), pointer :: msg(:)
+    integer :: n
+    if (rc == 0) return
+    call c_f_pointer(llmk_strerror(rc), msg, [256])
+    n = 0
+    do while (n < 256)
+       if (msg(n+1) == c_null_char) exit
+       n = n + 1
+    end do
+    print *, what, ": ", msg(1:n), " (code", rc, ")"
+    stop 1
+  end subroutine
+
+end module llmk_binding

@@ -1,0 +1,68 @@
+"""End to end through the drop-in surface: the Fortran `llm` CLI (ISO_C_BINDING -> libllmk.so ->
+gfx950 kernels) must print exactly what the real reference printed for the same GGUF and flags
+(tests/golden/*.npz hold the reference's stdout): the ' data offset' line and the token text."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+LLM = os.path.join(ROOT, "llm.f90_amd", "host", "llm")
+
+
+def _run(args, cwd):
+    r = subprocess.run([LLM] + args, capture_output=True, cwd=cwd, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+@pytest.mark.parametrize("tag", GOLDEN_CASES)
+def test_cli_output_matches_reference_transcript(tag, gguf, tmp_path):
+    assert os.path.exists(LLM), "host/llm not built (amdflang) -- the drop-in CLI is part of the product"
+    g = load_golden(tag)
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+    args = ["-m", path, "-n", str(int(g["n"])), "-t", "0"]
+    if str(g["prompt"]):
+        args += ["-p", str(g["prompt"])]
+    out = _run(args, str(tmp_path)).split(b"\n")
+    ref = bytes(g["stdout"]).split(b"\n")
+    assert out[0] == ref[0]                       # " data offset N"
+    assert out[1] == ref[1]                       # the generated text, token for token
+    k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
+    assert out[:k] == ref[:k]                     # everything up to the timing report, byte for byte
+    assert out[k].startswith(b" Inference time:") and b"tokens/second" in out[k + 1] and out[k + 2].strip() == b"Timings"
+    assert [l.split()[0] for l in out[k + 3:k + 8]] == [b"1", b"2", b"3", b"4", b"5"]   # same 5 timer lines
+
+
+def test_cli_device_argmax_and_verbose_timings(gguf, tmp_path):
+    g = load_golden("tiny-hs64")
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, gguf.SHAPES["tiny-hs64"], int(g["seed"]))
+    ref = bytes(g["stdout"]).split(b"\n")
+    out = _run(["-m", path, "-n", str(int(g["n"])), "--device-argmax"], str(tmp_path)).split(b"\n")
+    assert out[1] == ref[1]
+    out = _run(["-m", path, "-n", str(int(g["n"])), "-v"], str(tmp_path))
+    assert ref[1] in out
+    t = [float(x) for x in re.findall(rb"^\s+[1-5]\s+([0-9.Ee+-]+)\s*$", out, re.M)]
+    assert len(t) == 5 and t[0] > 0 and t[3] > 0 and t[4] > 0    # hipEvent section timers are live under -v
+
+
+@pytest.mark.parametrize("wtype", [1, 2], ids=["f16", "q4_0"])
+def test_cli_runs_f16_and_q4_files(wtype, gguf, tmp_path):
+    """Same tokens as the python binding on the same quantised file (which is pinned to the oracle in
+    test_parity_gpu.py)."""
+    from llm_f90_amd import llmk
+    s = gguf.SHAPES["tiny-hs64"]
+    path = str(tmp_path / "q.gguf")
+    gguf.write_synth_gguf(path, s, 11, wtype)
+    out = _run(["-m", path, "-n", "12"], str(tmp_path)).split(b"\n")
+    m = llmk.Llmk(gguf.load_fused(path))
+    toks, _ = m.generate(12)
+    vocab = gguf.vocab_strings(s.vocab_size)
+    assert out[1].rstrip(b" ") == b"".join(vocab[t - 1] for t in toks).rstrip(b" ")
+    m.close()
