@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--shape", default="tinyllama", choices=sorted(gguf.SHAPES))
     ap.add_argument("--type", default="f32", choices=["f32", "f16", "q4_0"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling aid)")
     ap.add_argument("--greedy-on-device", action="store_true", help="time llmk_forward_greedy instead")
     a = ap.parse_args()
 
@@ -117,7 +118,7 @@ def main():
     t0 = time.perf_counter()
     fw = gguf.synth_fused(shape, SEED, wtype)
     t_gen = time.perf_counter() - t0
-    m = llmk.Llmk(fw, device=local)
+    m = llmk.Llmk(fw, device=local, flags=llmk.FLAG_NO_GRAPH if a.no_graph else 0)
     t_up = time.perf_counter() - t0 - t_gen
 
     def barrier():
