@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import llm_f90_amd  # noqa: E402,F401
 from llm_f90_amd import llmk  # noqa: E402
+from llm_f90_amd.replicas import Replicas  # noqa: E402
 from llm_f90_amd.tools import gguf  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
@@ -52,7 +53,22 @@ def bytes_per_token(s: gguf.LlamaShape, wtype: int, mean_pos: float) -> float:
             + V * 4)                             # logits write
 
 
-def cpu_baseline(fw, shape_name: str, wtype: int, n_ref: int = 24):
+def pmc_traffic(kernel_substr: str):
+    """HBM read bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC pass
+    (profiles/rNN_pmc_fetch_size.csv: FETCH_SIZE x 2 x 1024, the gfx950 correction of
+    MI355X_MICROARCH.md); None when no profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.csv")))
+    if not files:
+        return None
+    import csv
+    for row in csv.DictReader(open(files[-1])):
+        if kernel_substr in row["kernel"]:
+            return float(row["avg_FETCH_SIZE"]) * 2 * 1024
+    return None
+
+
+def cpu_baseline(fw, shape_name: str, wtype: int, n_ref: int = 128):
     """Reference timed on this box's host cores, 1 thread, bounded sample (10-30 s of CPU work)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "llm_ref")
     if shape_name == "tinyllama" and wtype == 0 and os.path.exists(ref):
@@ -99,15 +115,8 @@ def main():
     ap.add_argument("--greedy-on-device", action="store_true", help="time llmk_forward_greedy instead")
     a = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    rep = Replicas()
+    rank, world, local = rep.rank, rep.world, rep.local
 
     shape = gguf.SHAPES[a.shape]
     wtype = {"f32": 0, "f16": 1, "q4_0": 2}[a.type]
@@ -121,11 +130,7 @@ def main():
     m = llmk.Llmk(fw, device=local, flags=llmk.FLAG_NO_GRAPH if a.no_graph else 0)
     t_up = time.perf_counter() - t0 - t_gen
 
-    def barrier():
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+    barrier = rep.barrier
 
     step = m.forward_greedy if a.greedy_on_device else None
     token = 2
@@ -150,12 +155,7 @@ def main():
         if rc:
             raise SystemExit(f"llmk_forward failed: {rc}")
     barrier()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = rep.max_over_ranks(time.perf_counter() - t_start)
     if not np.all(np.isfinite(lg)):
         raise SystemExit("non-finite logits")
 
@@ -184,7 +184,7 @@ def main():
         ach = b / (ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<f32,SWIGLU,NORM> (rmsnorm+w1|w3 GEMV+SwiGLU)",
                            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "bytes_per_launch": b, "us_per_launch": ms * 1000, "kernels": per_k}
+                           "traffic": pmc_traffic("gemv_kernel<0, 3, true"), "bytes_per_launch": b, "us_per_launch": ms * 1000, "kernels": per_k}
         tok_gbs = bpt * (tok_s / world) / 1e9
         out["token_roofline"] = {"bytes_per_token": bpt, "achieved": tok_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": tok_gbs / HBM_PEAK_GBS, "roofline_tok_s": HBM_PEAK_GBS * 1e9 / bpt}
@@ -193,8 +193,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(fw, a.shape, wtype)
         print(json.dumps(out), flush=True)
     m.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    rep.close()
 
 
 if __name__ == "__main__":
