@@ -55,6 +55,7 @@ extern "C" {
 
 #define LLMK_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a hipGraph          */
 #define LLMK_FLAG_TIMINGS 2  /* record the reference's 5 section timers (implies NO_GRAPH)      */
+#define LLMK_FLAG_MULTI_KERNEL 4 /* never use the persistent whole-token kernel (5 launches/layer) */
 
 /* error codes */
 #define LLMK_OK 0
@@ -65,6 +66,7 @@ extern "C" {
 #define LLMK_E_STATE 5     /* forward before all weights were uploaded                              */
 #define LLMK_E_NODEVICE 6  /* no usable HIP device (there is no CPU fallback)                       */
 #define LLMK_E_NOMEM 7
+#define LLMK_E_TIMEOUT 8   /* an in-kernel exchange timed out (GPU shared with other work?)        */
 #define LLMK_E_HIP 1000    /* 1000 + hipError_t                                                     */
 
 /* Run-time replacement of the reference's compile-time dims (llama2.f90:102-108) and of
@@ -128,7 +130,8 @@ int llmk_timings(llmk_ctx *ctx, float ms[5]);
 /* Measurement hook for bench.py: runs `iters` launches of one kernel of the token pass on the
  * ctx's stream with HIP events around them and returns the average milliseconds per launch and
  * the algorithmic bytes one launch moves.  kernel: 0 qkv, 1 attention, 2 wo, 3 w13, 4 w2,
- * 5 classifier (layer 0's instance of each). */
+ * 5 classifier (successive launches walk the layers), 6 the persistent whole-token kernel
+ * (LLMK_E_ARG when the ctx runs the multi-kernel path). */
 int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double *bytes_per_launch);
 
 /* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),

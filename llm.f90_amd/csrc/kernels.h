@@ -45,15 +45,33 @@ struct GemvArgs {
     const void* W_scales;
 };
 
+// Wave64 reductions on the DPP crossbar (quad_perm / row_shr / row_bcast), result broadcast through
+// v_readlane: ~10 VALU ops.  The __shfl_xor ladder compiles to six dependent ds_bpermute_b32 (an
+// LDS-crossbar round trip each, ~700 cycles per reduction), which showed up as the per-tile cost of
+// the streaming waves.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                  CTRL, ROW_MASK, 0xf, BOUND));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1, 0xf, true>(0.f, v);    // quad_perm:[1,0,3,2]
+    v += dpp_mov<0x4E, 0xf, true>(0.f, v);    // quad_perm:[2,3,0,1]
+    v += dpp_mov<0x114, 0xf, true>(0.f, v);   // row_shr:4
+    v += dpp_mov<0x118, 0xf, true>(0.f, v);   // row_shr:8   -> lanes 12..15 of each row hold the row sum
+    v += dpp_mov<0x142, 0xa, true>(0.f, v);   // row_bcast:15 into rows 1,3
+    v += dpp_mov<0x143, 0xc, true>(0.f, v);   // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    constexpr float NI = -__builtin_huge_valf();
+    v = fmaxf(v, dpp_mov<0xB1, 0xf, false>(NI, v));
+    v = fmaxf(v, dpp_mov<0x4E, 0xf, false>(NI, v));
+    v = fmaxf(v, dpp_mov<0x114, 0xf, false>(NI, v));
+    v = fmaxf(v, dpp_mov<0x118, 0xf, false>(NI, v));
+    v = fmaxf(v, dpp_mov<0x142, 0xa, false>(NI, v));
+    v = fmaxf(v, dpp_mov<0x143, 0xc, false>(NI, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // 16-byte non-temporal global load (weights are read once per token: keep them out of L2's way).

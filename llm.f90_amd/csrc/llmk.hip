@@ -13,6 +13,7 @@
 //   (greedy only) argmax                                                             :388
 #include "../../include/llmk.h"
 #include "kernels.h"
+#include "token_kernel.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -65,6 +66,12 @@ struct llmk_ctx {
     hipEvent_t ev[8] = {};
     float times[5] = {0, 0, 0, 0, 0};
     int n_cu = 256;
+    // persistent whole-token kernel (token_kernel.h)
+    bool use_tk = false;
+    unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x
+    float4* d_zeros = nullptr;
+    unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
+    size_t tk_lds = 0;
 };
 
 namespace {
@@ -185,9 +192,59 @@ hipError_t launch_embed(llmk_ctx* c) {
         if (e_ != hipSuccess) return e_; \
     } while (0)
 
+hipError_t launch_token_kernel(llmk_ctx* c) {
+    typedef TkTinyLlama TK;
+    TokenArgs a;
+    a.emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
+    a.rms_att = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;
+    a.rms_ffn = (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data;
+    a.rms_final = (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data;
+    a.wqkv = (const float*)c->t[LLMK_WQKV].data;
+    a.wo = (const float*)c->t[LLMK_WO].data;
+    a.w13 = (const float*)c->t[LLMK_W13].data;
+    a.w2 = (const float*)c->t[LLMK_W2].data;
+    a.wcls = (const float*)c->t[LLMK_WCLS].data;
+    a.kc = c->d_kc;
+    a.vc = c->d_vc;
+    a.rope = c->d_rope;
+    a.tokpos = c->d_tokpos;
+    a.g_qkv = c->d_gran;
+    a.g_xb = a.g_qkv + TK::QKV;
+    a.g_xa = a.g_xb + TK::E;
+    a.g_hb = a.g_xa + TK::E;
+    a.g_x = a.g_hb + TK::H;
+    a.logits = c->d_logits;
+    a.err = reinterpret_cast<unsigned*>(c->d_logits + c->V);
+    a.zeros = c->d_zeros;
+    a.trace = c->d_trace;
+    a.L = c->L;
+    a.S = c->S;
+    a.nosync = getenv("LLMK_TK_NOSYNC") ? 1 : 0;
+    hipLaunchKernelGGL((token_kernel<TK>), dim3(TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
+    return hipGetLastError();
+}
+
+__global__ void bump_serial_kernel(int* tokpos) { tokpos[2] += 1; }
+
+hipError_t enqueue_tail(llmk_ctx* c, bool greedy) {
+    if (greedy) {
+        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_logits, c->V, c->d_next);
+        HIPRET(hipGetLastError());
+        HIPRET(hipMemcpyAsync(c->h_next, c->d_next, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPRET(hipMemcpyAsync(c->h_next + 1, c->d_logits + c->V, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        HIPRET(hipMemcpyAsync(c->h_logits, c->d_logits, ((size_t)c->V + 1) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    return hipSuccess;
+}
+
 // Enqueue one token pass on c->stream.  timed: bracket the reference's five sections with events.
 hipError_t enqueue_token(llmk_ctx* c, bool greedy, bool timed) {
-    HIPRET(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPRET(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (c->use_tk) {
+        HIPRET(launch_token_kernel(c));
+        return enqueue_tail(c, greedy);
+    }
     HIPRET(launch_embed(c));
     for (int l = 0; l < c->L; ++l) {
         if (timed) HIPRET(hipEventRecord(c->ev[0], c->stream));
@@ -217,14 +274,7 @@ hipError_t enqueue_token(llmk_ctx* c, bool greedy, bool timed) {
         float ms;
         HIPRET(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); c->times[4] += ms;  // 5 = final norm + classifier
     }
-    if (greedy) {
-        hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, c->stream, c->d_logits, c->V, c->d_next);
-        HIPRET(hipGetLastError());
-        HIPRET(hipMemcpyAsync(c->h_next, c->d_next, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    } else {
-        HIPRET(hipMemcpyAsync(c->h_logits, c->d_logits, (size_t)c->V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    }
-    return hipSuccess;
+    return enqueue_tail(c, greedy);
 }
 
 int build_graph(llmk_ctx* c, bool greedy, hipGraphExec_t* out) {
@@ -254,6 +304,7 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
     HIPCHK(hipSetDevice(c->cfg.device));
     c->h_tokpos[0] = token - 1;
     c->h_tokpos[1] = pos;
+    c->h_tokpos[2] += 1;  // token serial: makes every exchange epoch of this pass unique
     const bool timed = (c->cfg.flags & LLMK_FLAG_TIMINGS) != 0;
     if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
         HIPCHK(enqueue_token(c, greedy, timed));
@@ -266,6 +317,10 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
         HIPCHK(hipGraphLaunch(*g, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->use_tk) {
+        const unsigned err = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
+        if (err != 0) return LLMK_E_TIMEOUT;
+    }
     return LLMK_OK;
 }
 
@@ -285,6 +340,7 @@ const char* llmk_strerror(int code) {
         case LLMK_E_STATE: return "llmk: forward called before all weights were uploaded";
         case LLMK_E_NODEVICE: return "llmk: no usable HIP device (there is no CPU fallback)";
         case LLMK_E_NOMEM: return "llmk: out of memory";
+        case LLMK_E_TIMEOUT: return "llmk: device-side exchange timed out (persistent kernel not fully resident?)";
     }
     if (code >= LLMK_E_HIP) return hipGetErrorString((hipError_t)(code - LLMK_E_HIP));
     return "llmk: unknown error";
@@ -355,16 +411,36 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
     CK(hipMalloc(&c->d_q, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_xb, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_hb, (size_t)H * sizeof(float)));
-    CK(hipMalloc(&c->d_logits, (size_t)V * sizeof(float)));
+    CK(hipMalloc(&c->d_logits, ((size_t)V + 4) * sizeof(float)));  // [V] = sticky device error word
     CK(hipMalloc(&c->d_rope, (size_t)(hs / 2) * sizeof(float)));
-    CK(hipMalloc(&c->d_tokpos, 2 * sizeof(int)));
-    CK(hipMalloc(&c->d_next, sizeof(int)));
-    CK(hipHostMalloc(&c->h_tokpos, 2 * sizeof(int), hipHostMallocDefault));
-    CK(hipHostMalloc(&c->h_logits, (size_t)V * sizeof(float), hipHostMallocDefault));
-    CK(hipHostMalloc(&c->h_next, sizeof(int), hipHostMallocDefault));
+    CK(hipMalloc(&c->d_tokpos, 4 * sizeof(int)));
+    CK(hipMalloc(&c->d_next, 2 * sizeof(int)));
+    CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
+    CK(hipHostMalloc(&c->h_logits, ((size_t)V + 4) * sizeof(float), hipHostMallocDefault));
+    CK(hipHostMalloc(&c->h_next, 2 * sizeof(int), hipHostMallocDefault));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));
+    // The whole-token persistent kernel serves the shapes it is instantiated for, on a full 256-CU part
+    typedef TkTinyLlama TK;
+    c->use_tk = !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && cfg->weight_type == LLMK_TYPE_F32 &&
+                c->n_cu == TK_NCU && E == TK::E && H == TK::H && nh == TK::NH && nkv == TK::NKV && V == TK::V;
+    if (c->use_tk) {
+        const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H;
+        CK(hipMalloc(&c->d_gran, ngran * sizeof(unsigned long long)));
+        CK(hipMalloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
+        if (getenv("LLMK_TK_TRACE")) CK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));
+        if (rc == LLMK_OK) {
+            CK(hipMemset(c->d_gran, 0, ngran * sizeof(unsigned long long)));
+            CK(hipMemset(c->d_zeros, 0, (size_t)TK_NCU * TK_WAVES * 1024));
+        }
+        c->tk_lds = (size_t)TkLds<TK>::ATT_S + (size_t)S * sizeof(float);
+        if (c->tk_lds < 96 * 1024) c->tk_lds = 96 * 1024;   // > 80 KB: never two workgroups on one CU
+        if (c->tk_lds > 160 * 1024) c->use_tk = false;
+        else CK(hipFuncSetAttribute((const void*)token_kernel<TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
+    }
     if (rc == LLMK_OK) {
+        CK(hipMemset(c->d_logits, 0, ((size_t)V + 4) * sizeof(float)));
+        c->h_tokpos[0] = 0; c->h_tokpos[1] = 0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
         CK(hipMemset(c->d_kc, 0, kvn * sizeof(float)));  // s%key_cache(:,:,:) = 0   llama2.f90:317
         CK(hipMemset(c->d_vc, 0, kvn * sizeof(float)));
         CK(hipMemset(c->d_x, 0, (size_t)E * sizeof(float)));
@@ -485,15 +561,20 @@ int llmk_timings(llmk_ctx* c, float ms[5]) {
 int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* bytes_per_launch) {
     int rc = check_ready(c);
     if (rc) return rc;
-    if (kernel < 0 || kernel > 5 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
+    if (kernel < 0 || kernel > 6 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
+    if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     // Successive launches walk the layers so the weight stream never re-hits the 256 MiB Infinity
     // Cache (the classifier has one matrix: its figure is cache-assisted beyond the first launch).
     // NOTE: this overwrites x / caches at h_tokpos' position; call llmk_reset afterwards.
     if (c->h_tokpos[1] < 1) { c->h_tokpos[0] = 0; c->h_tokpos[1] = 1; }
-    HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 2 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
     auto one = [&](int i) -> hipError_t {
         const int l = i % c->L;
+        if (kernel == 6) {  // whole-token kernel: fresh exchange epochs for every launch
+            hipLaunchKernelGGL(bump_serial_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tokpos);
+            return launch_token_kernel(c);
+        }
         switch (kernel) {
             case 0: return launch_qkv(c, l);
             case 1: return launch_attn(c, l);
@@ -512,9 +593,15 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
     *avg_ms = ms / (float)iters;
     if (bytes_per_launch) {
-        const int tids[6] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS};
+        const int tids[7] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS, -1};
         double b = 0;
-        if (kernel == 1) {
+        if (kernel == 6) {
+            double w = 0;
+            const int mats[5] = {LLMK_WQKV, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS};
+            for (int m : mats) w += (double)c->desc[m].rows * (c->desc[m].layered ? c->L : 1) * (double)c->t[m].row_bytes;
+            b = w + (2.0 * c->L + 1) * c->E * 4 + c->E * 4 + 2.0 * c->L * c->KV * 4.0 * c->h_tokpos[1] +
+                2.0 * c->L * c->KV * 4 + c->V * 4.0;
+        } else if (kernel == 1) {
             b = 2.0 * c->KV * 4.0 * c->h_tokpos[1];  // K and V rows 1..pos of one layer
         } else {
             const TensorDesc& d = c->desc[tids[kernel]];
@@ -541,6 +628,10 @@ int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
             src = (which == 4 ? c->d_kc : c->d_vc) + ((size_t)layer * c->S + (pos - 1)) * c->KV;
             len = c->KV;
             break;
+        case 6:  // debug: raw trace stamps reinterpret as floats (2 per stamp)
+            if (!c->d_trace) return LLMK_E_ARG;
+            src = (const float*)c->d_trace; len = TK_NCU * TK_TRACE_N * 2;
+            break;
         default: return LLMK_E_ARG;
     }
     if (n > len) return LLMK_E_ARG;
@@ -559,7 +650,8 @@ int llmk_destroy(llmk_ctx* c) {
         if (c->t[i].data) hipFree(c->t[i].data);
         if (c->t[i].scales) hipFree(c->t[i].scales);
     }
-    void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next};
+    void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,
+                   c->d_gran, c->d_zeros, c->d_trace};
     for (void* p : dev)
         if (p) hipFree(p);
     if (c->h_tokpos) hipHostFree(c->h_tokpos);

@@ -1,0 +1,708 @@
+// Persistent whole-token kernel for gfx950: the complete `transformer` pass
+// (/root/reference/llama2.f90:480-640) in ONE launch, one 16-wave workgroup per CU.
+//
+// Why: with one kernel per GEMV the token is bounded by ~1.55 us of boundary + ramp per launch
+// (5 launches per layer) -- the weight stream stops at every dependency.  Weights
+// do not depend on activations, so here the stream never stops: each of the 15 STREAMING waves of
+// a CU walks a static list of 8 KB row tiles (its share of qkv, wo, w1|w3, w2 of every layer, then
+// the classifier) and always has two tiles requested ahead in registers (non-temporal 16-byte
+// loads), across phase boundaries.  The one SERVICE wave per CU never touches the weight stream
+// (so its polls are not queued behind 16 KB of outstanding loads -- vmcnt retires in order): it
+// gathers the phase's input vector from the exchange buffers into LDS, applies rmsnorm, and after
+// the streaming waves have dotted their tiles against it, runs the epilogue (RoPE / SwiGLU /
+// residual) and publishes the CU's 8-44 outputs.
+//
+// Exchange = 8-byte {value, epoch-tag} granules written with ONE agent-scope (sc1, write-through)
+// store and swept with agent-scope loads until every tag matches: no flags, no fences, placement
+// independent (cdna_hip_programming.md Guideline 16, form R2).  Epochs are unique per
+// (token serial, phase), so buffers are never reset.  Every spin is bounded; a timeout raises a
+// sticky error word and lets the kernel drain.
+//
+// Work split per phase, CU c of NCU: rows [c*R/NCU, (c+1)*R/NCU) of the phase's matrix; tile t of
+// that range goes to streaming wave t % 15.  A tile is one row x up to 2048 columns; its wave-
+// reduced partial dot goes to LDS and the service wave folds the parts of a row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace llmk {
+
+constexpr int TK_NCU = 256;               // one workgroup per CU
+constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
+constexpr int TK_NB = 4;                  // register tiles a streaming wave keeps requested ahead (4 x 8 KB)
+constexpr int TK_NS = TK_WAVES - 1;
+constexpr int TK_THREADS = TK_WAVES * WAVE;
+constexpr int TK_TCOLS = 8;               // 16-byte vector columns per tile (8 x 64 lanes x 4 floats = 2048)
+constexpr unsigned TK_SPIN_LIMIT = 1u << 22;
+constexpr int TK_TRACE_N = 16 * 64;       // stamps per CU: 16 per layer, first 64 layers
+
+struct TokenArgs {
+    const float* emb;        // [V][E]
+    const float* rms_att;    // [L][E]
+    const float* rms_ffn;    // [L][E]
+    const float* rms_final;  // [E]
+    const float* wqkv;       // [L][E+2KV][E]
+    const float* wo;         // [L][E][E]
+    const float* w13;        // [L][2H][E]
+    const float* w2;         // [L][E][H]
+    const float* wcls;       // [V][E]
+    float* kc;               // [L][S][KV]
+    float* vc;
+    const float* rope;       // [hs/2]
+    const int* tokpos;       // {token0, pos1, serial}
+    unsigned long long* g_qkv;  // granules [E+2KV]
+    unsigned long long* g_xb;   // [E]   attention output
+    unsigned long long* g_xa;   // [E]   x after attention residual
+    unsigned long long* g_hb;   // [H]
+    unsigned long long* g_x;    // [E]   x after FFN residual
+    float* logits;           // [V]
+    unsigned* err;           // sticky error word (0 = ok)
+    const float4* zeros;     // [NCU*TK_WAVES] 1 KB blocks of zeros: what empty ring slots / ragged row ends read
+    unsigned long long* trace;  // optional [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave (debug)
+    int L, S;
+    int nosync;              // debug: do not wait for exchange tags (wrong results; measures the pure streaming rate)
+};
+
+template <int E_, int H_, int NH_, int NKV_, int V_>
+struct TkShape {
+    static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_;
+    static constexpr int HS = E / NH, KV = NKV * HS, KVMUL = NH / NKV, QKV = E + 2 * KV;
+    // rows per CU and tiles per CU for each phase
+    static constexpr int R_Q = QKV / TK_NCU, R_O = E / TK_NCU, R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU, R_C = V / TK_NCU;
+    static constexpr int TPR_E = (E / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = E
+    static constexpr int TPR_H = (H / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = H
+    static constexpr int NT_Q = R_Q * TPR_E, NT_O = R_O * TPR_E, NT_A = R_A * TPR_E, NT_D = R_D * TPR_H, NT_C = R_C * TPR_E;
+    static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
+                         SL_A = (NT_A + TK_NS - 1) / TK_NS, SL_D = (NT_D + TK_NS - 1) / TK_NS,
+                         SL_C = (NT_C + TK_NS - 1) / TK_NS;
+    static constexpr int SL_LAYER = SL_Q + SL_O + SL_A + SL_D;
+    static constexpr int NC_E_LAST = E / 4 / WAVE - (TPR_E - 1) * TK_TCOLS;  // columns in a row's last tile
+    static constexpr int NC_H_LAST = H / 4 / WAVE - (TPR_H - 1) * TK_TCOLS;
+    static constexpr int MAXP = (NT_A > NT_C ? NT_A : NT_C) > NT_D ? (NT_A > NT_C ? NT_A : NT_C) : NT_D;
+    static_assert(QKV % TK_NCU == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % TK_NCU == 0, "rows must split over CUs");
+    static_assert(R_Q % 2 == 0, "RoPE pairs must not straddle CUs");
+    static_assert(E % 256 == 0 && H % 256 == 0, "rows are whole 1 KB segments");
+    static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
+    static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
+    static_assert(HS == 64, "in-kernel attention is written for head_size 64");
+};
+
+// LDS carve (bytes): xs (streaming input, up to H floats) | xraw (E) | partial | attention scratch
+template <class SH>
+struct TkLds {
+    static constexpr int XS = 0;
+    static constexpr int XRAW = XS + SH::H * 4;
+    static constexpr int PART = XRAW + SH::E * 4;
+    static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
+    static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
+    static constexpr int ATT_R4 = ATT_RED + TK_WAVES * SH::HS * 4;         // [16] floats
+    static constexpr int ROPE = ATT_R4 + 64;                               // cos[HS/2] | sin[HS/2] of pos*freq
+    static constexpr int ATT_S = ROPE + SH::HS * 4;                        // scores [S]
+};
+
+__device__ __forceinline__ void tk_barrier() {
+    // LDS traffic ordered by lgkmcnt; outstanding global LOADS deliberately stay in flight across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ void tk_publish(unsigned long long* g, unsigned epoch, float v) {
+    __hip_atomic_store(g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+typedef unsigned tk_v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tk_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// Service wave: collect N granules (N % 128 == 0) whose tag == epoch; values -> dst (LDS, N floats).
+// A single wave pulls only a few GB/s through agent-scope loads when it waits per batch (the price
+// list's handoff-payload row), so: 16-byte sc1 loads (two granules each), ALL of a lane's NL loads in
+// flight at once, so a pass costs one round trip.
+// Returns false on timeout / sticky error.
+template <int NL>
+__device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* dst,
+                                               unsigned* err, int lane, unsigned long long* dbg = nullptr) {
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long tp0 = dbg > reinterpret_cast<unsigned long long*>(1) ? wall_clock64() : 0;
+        tk_v4u r[NL];
+        // NO predicate on the loads: a per-load condition makes hipcc branch around each one and wait
+        // vmcnt(0) per element (NL dependent round trips instead of one)
+#pragma unroll
+        for (int k = 0; k < NL; ++k)
+            r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane + k * WAVE) * 16, 0, 16);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
+            const int i = 2 * (first_pair + lane + k * WAVE);
+            *reinterpret_cast<float2*>(dst + i) = make_float2(__uint_as_float(r[k].x), __uint_as_float(r[k].z));
+        }
+        if (__all(ok) || (dbg == reinterpret_cast<unsigned long long*>(1))) {
+            if (dbg > reinterpret_cast<unsigned long long*>(1) && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
+            return true;
+        }
+        if ((spin & 63) == 63) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spin > TK_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(err, 0x100u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+template <int N>
+__device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
+                                          int lane, unsigned long long* dbg = nullptr) {
+    static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
+    constexpr int NL = N / 128;   // 16-byte loads per lane
+    const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
+    if constexpr (NL <= 24) {
+        return tk_gather_part<NL>(rs, 0, epoch, dst, err, lane, dbg);
+    } else {      // long vectors in two register-sized halves
+        constexpr int H0 = NL / 2, H1 = NL - H0;
+        const bool a = tk_gather_part<H0>(rs, 0, epoch, dst, err, lane, dbg);
+        const bool b = tk_gather_part<H1>(rs, H0 * WAVE, epoch, dst, err, lane,
+                                            dbg > reinterpret_cast<unsigned long long*>(1) ? dbg + 2 : dbg);
+        return a && b;
+    }
+}
+
+// rmsnorm on one wave, lane <-> 4 consecutive elements per 256: the gains are requested (plain
+// loads, static data) BEFORE the exchange is polled, so their HBM latency hides under the gather.
+//   xs = x*w/sqrt(mean(x^2)+1e-5)                                         llama2.f90:450-457
+template <int E>
+struct TkNorm {
+    static constexpr int PER = E / (4 * WAVE);
+    float4 w[PER];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ gains, int lane) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) w[k] = reinterpret_cast<const float4*>(gains)[lane + k * WAVE];
+    }
+    // Stages xs = x*w and returns xn = sqrt(mean(x^2)+1e-5).  The division by xn is linear in the dot
+    // product, so it is applied ONCE to each finished row sum (W.(x*w))/xn by the epilogue instead
+    // of 2048 times here -- the service wave is the serial section of every phase.
+    __device__ __forceinline__ float apply(const float* xraw, float* xs, int lane) const {
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const float4 x = reinterpret_cast<const float4*>(xraw)[lane + k * WAVE];
+            ss = dot4(x, x, ss);
+            float4 o;
+            o.x = x.x * w[k].x;
+            o.y = x.y * w[k].y;
+            o.z = x.z * w[k].z;
+            o.w = x.w * w[k].w;
+            reinterpret_cast<float4*>(xs)[lane + k * WAVE] = o;
+        }
+        ss = wave_sum(ss);
+        return sqrtf(ss / (float)E + 1e-5f);
+    }
+};
+
+// Every ring slot is exactly TK_TCOLS unconditional loads: a slot with no tile, and the columns past a
+// ragged row end, read a 1 KB block of ZEROS (L2-resident) instead of being skipped.  With no control
+// flow around the loads hipcc can count them, so consuming the oldest of the TK_NB tiles waits with
+// vmcnt(24) and leaves the three younger tiles in flight; a skipped load would force vmcnt(0).
+struct TkTile {
+    const float4* p;  // row base + first column of the tile (the zero block when the slot is empty)
+    int xoff;         // float4 offset of the tile's first column in xs
+    int ncol;         // real vector columns (0..8); columns >= ncol read zeros
+    int pidx;         // partial index (tile index within the CU's phase; MAXP = junk slot)
+};
+
+__device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t, const float4* zp, int lane) {
+#pragma unroll
+    for (int j = 0; j < TK_TCOLS; ++j) {
+        const float4* pj = (j < t.ncol) ? t.p + j * WAVE : zp;   // wave-uniform select, no branch
+        b[j] = ldg_nt(pj + lane);
+    }
+}
+__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, float* part,
+                                           int lane) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < TK_TCOLS; ++j) {
+        const int xj = (j < t.ncol) ? t.xoff + j * WAVE : 0;      // zero weights: any finite x will do
+        acc = dot4(b[j], xs[xj + lane], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) part[t.pidx] = acc;
+}
+
+// Static per-wave schedule: SLP slots per layer (padded to an even count so the 2-deep ring has the
+// same parity at every layer start), then the classifier slots.  Slot K (compile-time) belongs to
+// one phase; the s-th slot of a phase is tile s*15 + sw of the CU's tile range of that phase
+// (null when past the end).  Everything but l, c, sw is a compile-time constant.
+template <class SH>
+struct TkSched {
+    static constexpr int SLP = (SH::SL_LAYER + TK_NB - 1) / TK_NB * TK_NB;   // padded slots per layer
+    static constexpr int KQ = 0, KO = KQ + SH::SL_Q, KA = KO + SH::SL_O, KD = KA + SH::SL_A, KP = KD + SH::SL_D;
+};
+
+template <int JUNK>
+__device__ __forceinline__ TkTile tk_null(const float4* zp) {
+    TkTile t;
+    t.p = zp; t.xoff = 0; t.ncol = 0; t.pidx = JUNK;
+    return t;
+}
+
+template <int K_, int TPR, int NT, int JUNK>
+__device__ __forceinline__ TkTile tk_mk(const float* mat, long long row, int ti, const float4* zp) {
+    TkTile t;
+    const bool live = ti < NT;
+    const int part = (TPR == 1) ? 0 : ti % TPR;
+    t.xoff = live ? part * TK_TCOLS * WAVE : 0;
+    t.ncol = live ? min(TK_TCOLS, K_ / 4 / WAVE - part * TK_TCOLS) : 0;
+    t.p = live ? reinterpret_cast<const float4*>(mat + row * K_) + part * TK_TCOLS * WAVE : zp;
+    t.pidx = live ? ti : JUNK;
+    return t;
+}
+
+template <class SH, int K>
+__device__ __forceinline__ TkTile tk_cls_at(const TokenArgs& a, int c, int sw) {
+    if constexpr (K < SH::SL_C) {
+        const int ti = K * TK_NS + sw;
+        return tk_mk<SH::E, SH::TPR_E, SH::NT_C, SH::MAXP>(a.wcls, (long long)c * SH::R_C + ti / SH::TPR_E, ti, a.zeros);
+    } else {
+        return tk_null<SH::MAXP>(a.zeros);
+    }
+}
+
+// descriptor of slot K (compile-time) of layer l; K >= SLP looks into layer l+1; past the last
+// layer the stream continues with the classifier slots
+template <class SH, int K>
+__device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw) {
+    typedef TkSched<SH> SC;
+    static_assert(K < 2 * SC::SLP, "lookahead of at most one layer");
+    if constexpr (K >= SC::SLP) {
+        return tk_at<SH, K - SC::SLP>(a, l + 1, c, sw);
+    } else {
+        if (l >= a.L) return tk_cls_at<SH, K>(a, c, sw);
+        if constexpr (K < SC::KO) {
+            const int ti = (K - SC::KQ) * TK_NS + sw;
+            return tk_mk<SH::E, SH::TPR_E, SH::NT_Q, SH::MAXP>(a.wqkv, (long long)l * SH::QKV + c * SH::R_Q + ti / SH::TPR_E, ti, a.zeros);
+        } else if constexpr (K < SC::KA) {
+            const int ti = (K - SC::KO) * TK_NS + sw;
+            return tk_mk<SH::E, SH::TPR_E, SH::NT_O, SH::MAXP>(a.wo, (long long)l * SH::E + c * SH::R_O + ti / SH::TPR_E, ti, a.zeros);
+        } else if constexpr (K < SC::KD) {
+            const int ti = (K - SC::KA) * TK_NS + sw;
+            const int r = ti / SH::TPR_E;  // 0..R_A-1: (gate0, up0, gate1, up1, ...)
+            return tk_mk<SH::E, SH::TPR_E, SH::NT_A, SH::MAXP>(
+                a.w13, (long long)l * 2 * SH::H + (r & 1) * SH::H + c * (SH::R_A / 2) + (r >> 1), ti, a.zeros);
+        } else if constexpr (K < SC::KP) {
+            const int ti = (K - SC::KD) * TK_NS + sw;
+            return tk_mk<SH::H, SH::TPR_H, SH::NT_D, SH::MAXP>(a.w2, (long long)l * SH::E + c * SH::R_D + ti / SH::TPR_H, ti, a.zeros);
+        } else {
+            return tk_null<SH::MAXP>(a.zeros);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-kernel attention for one head on one CU, all 16 waves (llama2.f90:572-598).  q_h, k_pos, v_pos
+// arrive through the exchange (LDS); rows t < pos-1 come from the caches written by earlier launches.
+// ------------------------------------------------------------------------------------------------
+template <class SH>
+struct TkAtt {
+    static constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = (TK_NB > 4 ? 4 : 8), TILE = TPB * U;
+    float4 kv[U], vv[U];
+    // K and V rows of the first TILE timesteps (written by earlier launches) are requested at the START
+    // of the layer, long before q exists: by attention time they have crossed the loaded memory system
+    __device__ __forceinline__ void prefetch(const TokenArgs& a, int l, int h, int pos, int tid) {
+        const int lane = tid & 63, wid = tid >> 6;
+        const int g = h / SH::KVMUL, sub = lane % LPT, tl = lane / LPT;
+        const float4* kg = reinterpret_cast<const float4*>(a.kc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
+        const float4* vg = reinterpret_cast<const float4*>(a.vc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
+        const int tb = wid * TPW + tl, tmax = max(pos - 2, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) kv[u] = kg[(size_t)min(u * TPB + tb, tmax) * (SH::KV / 4)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = vg[(size_t)min(u * TPB + tb, tmax) * (SH::KV / 4)];
+    }
+};
+
+template <class SH>
+__device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int l, int h, int pos, int tid, TkAtt<SH>& pa,
+                                             unsigned long long* dbg = nullptr) {
+    constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = TkAtt<SH>::U, TILE = TPB * U;
+    float4 (&kv)[U] = pa.kv;
+    float4 (&vv)[U] = pa.vv;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int g = h / SH::KVMUL;
+    const float* qs = reinterpret_cast<const float*>(lds + TkLds<SH>::ATT_Q);
+    const float4* kcur = reinterpret_cast<const float4*>(qs + HS);
+    const float4* vcur = reinterpret_cast<const float4*>(qs + 2 * HS);
+    float4* red = reinterpret_cast<float4*>(lds + TkLds<SH>::ATT_RED);
+    float* att = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_S);
+    const int sub = lane % LPT, tl = lane / LPT;
+    const float4 qv = reinterpret_cast<const float4*>(qs)[sub];
+    const float scale = sqrtf((float)HS);
+    const float4* kg = reinterpret_cast<const float4*>(a.kc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
+    const float4* vg = reinterpret_cast<const float4*>(a.vc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
+    constexpr int kv4 = SH::KV / 4;
+    const int tb = wid * TPW + tl;
+    const int npast = pos - 1;  // rows 0..pos-2 live in the cache; row pos-1 is this token's (LDS)
+    const int tmax = max(npast - 1, 0);
+
+    for (int base = 0; base < pos; base += TILE) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) kv[u] = kg[(size_t)min(base + u * TPB + tb, tmax) * kv4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = base + u * TPB + tb;
+            const float4 kk = (t == npast) ? kcur[sub] : kv[u];
+            float d = dot4(qv, kk, 0.f);
+#pragma unroll
+            for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (sub == 0 && t < pos) att[t] = d / scale;                           // :582
+        }
+    }
+    if (dbg) dbg[0] = wall_clock64();
+    tk_barrier();
+    if (dbg) dbg[1] = wall_clock64();
+    // every wave folds max and sum over ALL scores itself: no cross-wave reduction, no extra barriers
+    float m = -INFINITY;
+    for (int t = lane; t < pos; t += WAVE) m = fmaxf(m, att[t]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int t = lane; t < pos; t += WAVE) s += expf(att[t] - m);
+    s = wave_sum(s);
+
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < pos; base += TILE) {
+        if (base > 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) vv[u] = vg[(size_t)min(base + u * TPB + tb, tmax) * kv4];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = base + u * TPB + tb;
+            const float4 v4 = (t == npast) ? vcur[sub] : vv[u];
+            const float p = (t < pos) ? expf(att[t] - m) / s : 0.f;                // xi/sum(xi)  :476
+            acc.x = fmaf(p, v4.x, acc.x);
+            acc.y = fmaf(p, v4.y, acc.y);
+            acc.z = fmaf(p, v4.z, acc.z);
+            acc.w = fmaf(p, v4.w, acc.w);
+        }
+    }
+#pragma unroll
+    for (int o = LPT; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64);
+        acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64);
+        acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (tl == 0) red[wid * LPT + sub] = acc;
+    if (dbg) dbg[2] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// SERVICE wave of a CU: everything that depends on other CUs.  Per phase: gather the input vector
+// (granule sweep), rmsnorm, barrier A, barrier B, epilogue + publish.
+// ------------------------------------------------------------------------------------------------
+template <class SH>
+__device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c, int lane, int tid) {
+    typedef TkLds<SH> LD;
+    float* xs = reinterpret_cast<float*>(lds + LD::XS);
+    float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
+    const float* part = reinterpret_cast<const float*>(lds + LD::PART);
+    const int L = a.L;
+    const int tok = a.tokpos[0], pos = a.tokpos[1];
+    const unsigned ebase = (unsigned)a.tokpos[2] * (unsigned)(5 * L + 2);
+    constexpr int HPC = TK_NCU / SH::NH;
+    const bool att_cu = (c % HPC) == 0;
+    const int my_head = c / HPC;
+    bool ok = true;
+    // RoPE angles depend on pos only: cos/sin once per token, not once per layer        :544-548
+    float* rope_cs = reinterpret_cast<float*>(lds + LD::ROPE);
+    if (lane < SH::HS / 2) {
+        const float rval = (float)pos * a.rope[lane];
+        rope_cs[lane] = cosf(rval);
+        rope_cs[SH::HS / 2 + lane] = sinf(rval);
+    }
+    unsigned long long* tr = a.trace ? a.trace + (size_t)c * TK_TRACE_N : nullptr;
+#define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
+
+    for (int l = 0; l < L; ++l) {
+        const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
+        TK_STAMP(0);
+        // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
+        TkNorm<SH::E> nrm;
+        nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
+        if (l == 0) {
+#pragma unroll 8
+            for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
+        } else {
+            ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+        }
+        TK_STAMP(1);
+        const float xn_att = nrm.apply(xraw, xs, lane);
+        tk_barrier();
+        TK_STAMP(2);
+        tk_barrier();
+        TK_STAMP(3);
+        if (lane < SH::R_Q) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int p = 0; p < SH::TPR_E; ++p) {
+                v0 += part[lane * SH::TPR_E + p];
+                v1 += part[(lane ^ 1) * SH::TPR_E + p];
+            }
+            v0 = v0 / xn_att;
+            v1 = v1 / xn_att;
+            const int r = c * SH::R_Q + lane;
+            float outv = v0;
+            if (r < SH::E + SH::KV) {
+                // pairs (i,i+1); 1-based odd i -> head_dim = mod(i,hs) = 2j+1 (table index j)   :543-559
+                const int i0 = ((r < SH::E) ? r : r - SH::E) & ~1;
+                const int jf = (i0 % SH::HS) >> 1;
+                const float fcr = rope_cs[jf], fci = rope_cs[SH::HS / 2 + jf];
+                // even lane: own = q0, partner = q1; odd lane: own = q1, partner = q0
+                outv = (lane & 1) ? (v1 * fci + v0 * fcr) : (v0 * fcr - v1 * fci);
+                if (r >= SH::E) a.kc[((size_t)l * a.S + (pos - 1)) * SH::KV + (r - SH::E)] = outv;          // :564
+            } else {
+                a.vc[((size_t)l * a.S + (pos - 1)) * SH::KV + (r - SH::E - SH::KV)] = outv;                 // :565
+            }
+            tk_publish(a.g_qkv + r, e_q, outv);
+        }
+        TK_STAMP(4);
+        // ---- P1: attention, one CU per head                                     llama2.f90:572-598
+        if (att_cu) {
+            float* qs = reinterpret_cast<float*>(lds + LD::ATT_Q);
+            const int g = my_head / SH::KVMUL;
+            for (unsigned spin = 0;; ++spin) {
+                const unsigned long long xq = __hip_atomic_load(a.g_qkv + my_head * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long xk = __hip_atomic_load(a.g_qkv + SH::E + g * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long xv = __hip_atomic_load(a.g_qkv + SH::E + SH::KV + g * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool good = (unsigned)(xq >> 32) == e_q && (unsigned)(xk >> 32) == e_q && (unsigned)(xv >> 32) == e_q;
+                qs[lane] = __uint_as_float((unsigned)xq);
+                qs[SH::HS + lane] = __uint_as_float((unsigned)xk);
+                qs[2 * SH::HS + lane] = __uint_as_float((unsigned)xv);
+                if (__all(good) || a.nosync) break;
+                if ((spin & 63) == 63) {
+                    if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+                    if (spin > TK_SPIN_LIMIT) {
+                        if (lane == 0) __hip_atomic_store(a.err, 0x200u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = false; break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            TK_STAMP(5);
+            tk_barrier();
+            {
+                TkAtt<SH> pa;
+                pa.prefetch(a, l, my_head, pos, tid);
+                tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 12 : nullptr);
+            }
+            tk_barrier();
+            TK_STAMP(6);
+            const float4* red = reinterpret_cast<const float4*>(lds + LD::ATT_RED);
+            constexpr int LPT = SH::HS / 4;
+            const int d4 = lane >> 2, comp = lane & 3;   // output dim = lane
+            float o = 0.f;
+#pragma unroll
+            for (int w = 0; w < TK_WAVES; ++w) {
+                const float4 r = red[w * LPT + d4];
+                o += (comp == 0) ? r.x : (comp == 1) ? r.y : (comp == 2) ? r.z : r.w;
+            }
+            tk_publish(a.g_xb + my_head * SH::HS + lane, e_att, o);
+        }
+        // ---- P2: x += wo . xb                                                    llama2.f90:603-605
+        ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        TK_STAMP(7);
+        tk_barrier();
+        tk_barrier();
+        TK_STAMP(8);
+        if (lane < SH::R_O) {
+            float v = 0.f;
+#pragma unroll
+            for (int p = 0; p < SH::TPR_E; ++p) v += part[lane * SH::TPR_E + p];
+            const int r = c * SH::R_O + lane;
+            tk_publish(a.g_xa + r, e_o, xraw[r] + v);
+        }
+        // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
+        nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
+        ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+        TK_STAMP(9);
+        const float xn_ffn = nrm.apply(xraw, xs, lane);
+        tk_barrier();
+        TK_STAMP(10);
+        tk_barrier();
+        TK_STAMP(11);
+        if (lane < SH::R_A / 2) {
+            float gsum = 0.f, usum = 0.f;
+#pragma unroll
+            for (int p = 0; p < SH::TPR_E; ++p) {
+                gsum += part[(2 * lane) * SH::TPR_E + p];
+                usum += part[(2 * lane + 1) * SH::TPR_E + p];
+            }
+            gsum = gsum / xn_ffn;
+            usum = usum / xn_ffn;
+            const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
+            tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
+        }
+        // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
+        ok = tk_gather<SH::H>(a.g_hb, e_a, xs, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        TK_STAMP(12);
+        tk_barrier();
+        TK_STAMP(13);
+        tk_barrier();
+        TK_STAMP(14);
+        if (lane < SH::R_D) {
+            float v = 0.f;
+#pragma unroll
+            for (int p = 0; p < SH::TPR_H; ++p) v += part[lane * SH::TPR_H + p];
+            const int r = c * SH::R_D + lane;
+            tk_publish(a.g_x + r, e_d, xraw[r] + v);
+        }
+        TK_STAMP(15);
+    }
+#undef TK_STAMP
+    // ---- final rmsnorm + classifier                                             llama2.f90:627-636
+    TkNorm<SH::E> nrmf;
+    nrmf.prefetch(a.rms_final, lane);
+    ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : nullptr) && ok;
+    const float xn_fin = nrmf.apply(xraw, xs, lane);
+    tk_barrier();
+    tk_barrier();
+    for (int j = lane; j < SH::R_C; j += WAVE) {
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < SH::TPR_E; ++p) v += part[j * SH::TPR_E + p];
+        a.logits[c * SH::R_C + j] = v / xn_fin;
+    }
+    if (!ok && lane == 0) atomicOr(a.err, 0x1000u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// STREAMING wave: a static list of 8 KB row tiles, always TK_NB requested ahead (register ring),
+// consumed between the phase's two barriers.  Nothing here depends on another CU.
+// ------------------------------------------------------------------------------------------------
+struct TkRing {
+    float4 b[TK_NB][TK_TCOLS];
+    TkTile t[TK_NB];
+};
+
+// slots K .. K+N-1 (compile-time) of layer l: consume ring entry K % NB, refill it with slot K + NB
+template <class SH, int K, int N, bool CLS>
+__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
+                                       float* part, int lane) {
+    if constexpr (N > 0) {
+        constexpr int R = K % TK_NB;
+        tk_consume(r.b[R], r.t[R], xs4, part, lane);
+        if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
+        else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
+        tk_issue(r.b[R], r.t[R], a.zeros, lane);
+        tk_run<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, xs4, part, lane);
+    }
+}
+// consume only / refill only: a phase's LAST min(NB, slots) slots are dotted first, the partial sums
+// handed to the service wave (barrier B), and only THEN refilled.  Issuing a refill can block for
+// microseconds when the CU's memory pipeline is full of earlier prefetches; that wait must not sit
+// between the dot products and the publish of the phase's result.
+template <class SH, int K, int N>
+__device__ __forceinline__ void tk_eat(const TkRing& r, const float4* xs4, float* part, int lane) {
+    if constexpr (N > 0) {
+        tk_consume(r.b[K % TK_NB], r.t[K % TK_NB], xs4, part, lane);
+        tk_eat<SH, K + 1, N - 1>(r, xs4, part, lane);
+    }
+}
+template <class SH, int K, int N, bool CLS>
+__device__ __forceinline__ void tk_refill(TkRing& r, const TokenArgs& a, int l, int c, int sw, int lane) {
+    if constexpr (N > 0) {
+        constexpr int R = K % TK_NB;
+        if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
+        else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
+        tk_issue(r.b[R], r.t[R], a.zeros, lane);
+        tk_refill<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, lane);
+    }
+}
+// one phase of S slots starting at slot K0: [barrier A] early slots (consume+refill), late slots
+// (consume), [barrier B], late refills
+template <class SH, int K0, int S, bool CLS>
+__device__ __forceinline__ void tk_phase(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
+                                         float* part, int lane) {
+    constexpr int LATE = S < TK_NB ? S : TK_NB, EARLY = S - LATE;
+    tk_barrier();
+    tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, xs4, part, lane);
+    tk_eat<SH, K0 + EARLY, LATE>(r, xs4, part, lane);
+    tk_barrier();
+    tk_refill<SH, K0 + EARLY, LATE, CLS>(r, a, l, c, sw, lane);
+}
+
+template <class SH, int K>
+__device__ __forceinline__ void tk_prime(TkRing& r, const TokenArgs& a, int c, int sw, int lane) {
+    if constexpr (K < TK_NB) {
+        r.t[K] = tk_at<SH, K>(a, 0, c, sw);
+        tk_issue(r.b[K], r.t[K], a.zeros, lane);
+        tk_prime<SH, K + 1>(r, a, c, sw, lane);
+    }
+}
+
+template <class SH>
+__device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, int sw, int lane, int tid) {
+    typedef TkLds<SH> LD;
+    typedef TkSched<SH> SC;
+    const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
+    float* part = reinterpret_cast<float*>(lds + LD::PART);
+    const int L = a.L;
+    const int pos = a.tokpos[1];
+    constexpr int HPC = TK_NCU / SH::NH;
+    const bool att_cu = (c % HPC) == 0;
+    const int my_head = c / HPC;
+
+    TkRing r;
+    tk_prime<SH, 0>(r, a, c, sw, lane);
+
+    for (int l = 0; l < L; ++l) {
+        {   // QKV phase; on the attention CUs the refills wait until attention has issued ITS loads,
+            // which would otherwise queue behind 100+ KB of prefetch in this CU's memory pipeline
+            constexpr int LATE = SH::SL_Q < TK_NB ? SH::SL_Q : TK_NB, EARLY = SH::SL_Q - LATE;
+            tk_barrier();
+            tk_run<SH, SC::KQ, EARLY, false>(r, a, l, c, sw, xs4, part, lane);
+            tk_eat<SH, SC::KQ + EARLY, LATE>(r, xs4, part, lane);
+            tk_barrier();
+            if (att_cu) {
+                tk_barrier();
+                {
+                    TkAtt<SH> pa;
+                    pa.prefetch(a, l, my_head, pos, tid);
+                    tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
+                }
+                tk_barrier();
+            }
+            tk_refill<SH, SC::KQ + EARLY, LATE, false>(r, a, l, c, sw, lane);
+        }
+        tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
+    }
+    // classifier: the ring index is 0 again (SLP is a multiple of TK_NB); refills run off the stream's end
+    tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
+}
+
+template <class SH>
+__global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = blockIdx.x;
+    // every wave reads its OWN zero block: one shared block would make 1800 waves hammer one HBM channel
+    a.zeros += (size_t)(c * TK_WAVES + wid) * WAVE;
+    if (wid == TK_NS) tk_service<SH>(a, lds, c, lane, tid);
+    else tk_stream<SH>(a, lds, c, wid, lane, tid);
+}
+
+typedef TkShape<2048, 5632, 32, 4, 32000> TkTinyLlama;
+
+}  // namespace llmk

@@ -18,7 +18,7 @@ TENSOR_IDS = {
     "token_embedding_table": 0, "rms_att_weight": 1, "rms_ffn_weight": 2, "wqkv": 3, "wo": 4, "w13": 5, "w2": 6,
     "rms_final_weight": 7, "wcls": 8,
 }
-FLAG_NO_GRAPH, FLAG_TIMINGS = 1, 2
+FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 # every symbol include/llmk.h declares
 SYMBOLS = ["llmk_create", "llmk_upload", "llmk_upload_rows", "llmk_set_rope_freqs", "llmk_forward",
            "llmk_forward_greedy", "llmk_reset", "llmk_timings", "llmk_time_kernel", "llmk_peek", "llmk_destroy",
