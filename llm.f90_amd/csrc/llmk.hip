@@ -68,6 +68,7 @@ struct llmk_ctx {
     int n_cu = 256;
     // persistent whole-token kernel (token_kernel.h)
     bool use_tk = false;
+    int tk_shape = 0;      // 1 TinyLlama-1.1B, 2 the small parity shape
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
@@ -192,8 +193,8 @@ hipError_t launch_embed(llmk_ctx* c) {
         if (e_ != hipSuccess) return e_; \
     } while (0)
 
-hipError_t launch_token_kernel(llmk_ctx* c) {
-    typedef TkTinyLlama TK;
+template <class TK>
+hipError_t launch_token_kernel_t(llmk_ctx* c) {
     TokenArgs a;
     a.emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
     a.rms_att = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;
@@ -222,6 +223,31 @@ hipError_t launch_token_kernel(llmk_ctx* c) {
     a.nosync = getenv("LLMK_TK_NOSYNC") ? 1 : 0;
     hipLaunchKernelGGL((token_kernel<TK>), dim3(TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
     return hipGetLastError();
+}
+hipError_t launch_token_kernel(llmk_ctx* c) {
+    return c->tk_shape == 1 ? launch_token_kernel_t<TkTinyLlama>(c) : launch_token_kernel_t<TkSmall>(c);
+}
+
+// Allocate the exchange state of the persistent kernel if cfg matches the instantiated shape TK.
+template <class TK>
+int tk_setup(llmk_ctx* c, int id) {
+    const llmk_config& g = c->cfg;
+    if (c->use_tk || g.emb_dim != TK::E || g.hidden_dim != TK::H || g.n_heads != TK::NH || g.n_kv_heads != TK::NKV ||
+        g.vocab_size != TK::V)
+        return LLMK_OK;
+    const size_t lds = (size_t)TkLds<TK>::ATT_S + (size_t)c->S * sizeof(float);
+    c->tk_lds = lds < 96 * 1024 ? 96 * 1024 : lds;   // > 80 KB: never two workgroups on one CU
+    if (c->tk_lds > 160 * 1024) return LLMK_OK;      // context too long for the in-LDS score row: multi-kernel path
+    const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H;
+    HIPCHK(hipMalloc(&c->d_gran, ngran * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
+    if (getenv("LLMK_TK_TRACE")) HIPCHK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));
+    HIPCHK(hipMemset(c->d_gran, 0, ngran * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_zeros, 0, (size_t)TK_NCU * TK_WAVES * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)token_kernel<TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
+    c->use_tk = true;
+    c->tk_shape = id;
+    return LLMK_OK;
 }
 
 __global__ void bump_serial_kernel(int* tokpos) { tokpos[2] += 1; }
@@ -421,22 +447,10 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));
     // The whole-token persistent kernel serves the shapes it is instantiated for, on a full 256-CU part
-    typedef TkTinyLlama TK;
-    c->use_tk = !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && cfg->weight_type == LLMK_TYPE_F32 &&
-                c->n_cu == TK_NCU && E == TK::E && H == TK::H && nh == TK::NH && nkv == TK::NKV && V == TK::V;
-    if (c->use_tk) {
-        const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H;
-        CK(hipMalloc(&c->d_gran, ngran * sizeof(unsigned long long)));
-        CK(hipMalloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
-        if (getenv("LLMK_TK_TRACE")) CK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));
-        if (rc == LLMK_OK) {
-            CK(hipMemset(c->d_gran, 0, ngran * sizeof(unsigned long long)));
-            CK(hipMemset(c->d_zeros, 0, (size_t)TK_NCU * TK_WAVES * 1024));
-        }
-        c->tk_lds = (size_t)TkLds<TK>::ATT_S + (size_t)S * sizeof(float);
-        if (c->tk_lds < 96 * 1024) c->tk_lds = 96 * 1024;   // > 80 KB: never two workgroups on one CU
-        if (c->tk_lds > 160 * 1024) c->use_tk = false;
-        else CK(hipFuncSetAttribute((const void*)token_kernel<TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
+    if (rc == LLMK_OK && !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && cfg->weight_type == LLMK_TYPE_F32 &&
+        c->n_cu == TK_NCU) {
+        rc = tk_setup<TkTinyLlama>(c, 1);
+        if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
     }
     if (rc == LLMK_OK) {
         CK(hipMemset(c->d_logits, 0, ((size_t)V + 4) * sizeof(float)));

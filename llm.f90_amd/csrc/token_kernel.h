@@ -97,7 +97,7 @@ struct TkLds {
     static constexpr int PART = XRAW + SH::E * 4;
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
     static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
-    static constexpr int ATT_R4 = ATT_RED + TK_WAVES * SH::HS * 4;         // [16] floats
+    static constexpr int ATT_R4 = ATT_RED + TK_WAVES * (256 / SH::HS) * SH::HS * 4;   // [waves][TPW][HS/4] float4
     static constexpr int ROPE = ATT_R4 + 64;                               // cos[HS/2] | sin[HS/2] of pos*freq
     static constexpr int ATT_S = ROPE + SH::HS * 4;                        // scores [S]
 };
@@ -328,10 +328,20 @@ struct TkAtt {
     }
 };
 
+// sum over the 16 lanes of a DPP row (= the HS/4 lanes that share a timestep); valid in lane 15 of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1, 0xf, true>(0.f, v);
+    v += dpp_mov<0x4E, 0xf, true>(0.f, v);
+    v += dpp_mov<0x114, 0xf, true>(0.f, v);
+    v += dpp_mov<0x118, 0xf, true>(0.f, v);
+    return v;
+}
+
 template <class SH>
 __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int l, int h, int pos, int tid, TkAtt<SH>& pa,
                                              unsigned long long* dbg = nullptr) {
     constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = TkAtt<SH>::U, TILE = TPB * U;
+    static_assert(LPT == 16, "one timestep per DPP row");
     float4 (&kv)[U] = pa.kv;
     float4 (&vv)[U] = pa.vv;
     const int lane = tid & 63, wid = tid >> 6;
@@ -339,7 +349,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     const float* qs = reinterpret_cast<const float*>(lds + TkLds<SH>::ATT_Q);
     const float4* kcur = reinterpret_cast<const float4*>(qs + HS);
     const float4* vcur = reinterpret_cast<const float4*>(qs + 2 * HS);
-    float4* red = reinterpret_cast<float4*>(lds + TkLds<SH>::ATT_RED);
+    float4* red = reinterpret_cast<float4*>(lds + TkLds<SH>::ATT_RED);   // [waves][TPW][LPT] float4
     float* att = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_S);
     const int sub = lane % LPT, tl = lane / LPT;
     const float4 qv = reinterpret_cast<const float4*>(qs)[sub];
@@ -358,12 +368,12 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = base + u * TPB + tb;
-            const float4 kk = (t == npast) ? kcur[sub] : kv[u];
-            float d = dot4(qv, kk, 0.f);
-#pragma unroll
-            for (int o = LPT / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            if (sub == 0 && t < pos) att[t] = d / scale;                           // :582
+            if (base + u * TPB < pos) {   // block-uniform: short contexts skip the empty batches
+                const int t = base + u * TPB + tb;
+                const float4 kk = (t == npast) ? kcur[sub] : kv[u];
+                const float d = row16_sum(dot4(qv, kk, 0.f));
+                if (sub == LPT - 1 && t < pos) att[t] = d / scale;                 // :582
+            }
         }
     }
     if (dbg) dbg[0] = wall_clock64();
@@ -385,23 +395,18 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = base + u * TPB + tb;
-            const float4 v4 = (t == npast) ? vcur[sub] : vv[u];
-            const float p = (t < pos) ? expf(att[t] - m) / s : 0.f;                // xi/sum(xi)  :476
-            acc.x = fmaf(p, v4.x, acc.x);
-            acc.y = fmaf(p, v4.y, acc.y);
-            acc.z = fmaf(p, v4.z, acc.z);
-            acc.w = fmaf(p, v4.w, acc.w);
+            if (base + u * TPB < pos) {
+                const int t = base + u * TPB + tb;
+                const float4 v4 = (t == npast) ? vcur[sub] : vv[u];
+                const float p = (t < pos) ? expf(att[t] - m) / s : 0.f;            // xi/sum(xi)  :476
+                acc.x = fmaf(p, v4.x, acc.x);
+                acc.y = fmaf(p, v4.y, acc.y);
+                acc.z = fmaf(p, v4.z, acc.z);
+                acc.w = fmaf(p, v4.w, acc.w);
+            }
         }
     }
-#pragma unroll
-    for (int o = LPT; o < 64; o <<= 1) {
-        acc.x += __shfl_xor(acc.x, o, 64);
-        acc.y += __shfl_xor(acc.y, o, 64);
-        acc.z += __shfl_xor(acc.z, o, 64);
-        acc.w += __shfl_xor(acc.w, o, 64);
-    }
-    if (tl == 0) red[wid * LPT + sub] = acc;
+    red[(wid * TPW + tl) * LPT + sub] = acc;   // the service wave folds the waves*TPW partials per dim
     if (dbg) dbg[2] = wall_clock64();
 }
 
@@ -479,6 +484,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (att_cu) {
             float* qs = reinterpret_cast<float*>(lds + LD::ATT_Q);
             const int g = my_head / SH::KVMUL;
+            TkAtt<SH> pa;
+            pa.prefetch(a, l, my_head, pos, tid);   // K/V rows cross the memory system while q is awaited
             for (unsigned spin = 0;; ++spin) {
                 const unsigned long long xq = __hip_atomic_load(a.g_qkv + my_head * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long xk = __hip_atomic_load(a.g_qkv + SH::E + g * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -499,11 +506,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
             TK_STAMP(5);
             tk_barrier();
-            {
-                TkAtt<SH> pa;
-                pa.prefetch(a, l, my_head, pos, tid);
-                tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 12 : nullptr);
-            }
+            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 12 : nullptr);
             tk_barrier();
             TK_STAMP(6);
             const float4* red = reinterpret_cast<const float4*>(lds + LD::ATT_RED);
@@ -511,7 +514,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int d4 = lane >> 2, comp = lane & 3;   // output dim = lane
             float o = 0.f;
 #pragma unroll
-            for (int w = 0; w < TK_WAVES; ++w) {
+            for (int w = 0; w < TK_WAVES * (64 / LPT); ++w) {
                 const float4 r = red[w * LPT + d4];
                 o += (comp == 0) ? r.x : (comp == 1) ? r.y : (comp == 2) ? r.z : r.w;
             }
@@ -673,12 +676,10 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             tk_eat<SH, SC::KQ + EARLY, LATE>(r, xs4, part, lane);
             tk_barrier();
             if (att_cu) {
+                TkAtt<SH> pa;
+                pa.prefetch(a, l, my_head, pos, tid);   // before the wait for q: K/V latency overlaps it
                 tk_barrier();
-                {
-                    TkAtt<SH> pa;
-                    pa.prefetch(a, l, my_head, pos, tid);
-                    tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
-                }
+                tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
                 tk_barrier();
             }
             tk_refill<SH, SC::KQ + EARLY, LATE, false>(r, a, l, c, sw, lane);
@@ -703,6 +704,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }
 
-typedef TkShape<2048, 5632, 32, 4, 32000> TkTinyLlama;
+typedef TkShape<2048, 5632, 32, 4, 32000> TkTinyLlama;   // /root/reference/llama2.f90:102-108
+typedef TkShape<256, 768, 4, 2, 1024> TkSmall;           // tests/golden/tk-small*.npz: pinned to the real reference
 
 }  // namespace llmk

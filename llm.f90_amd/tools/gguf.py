@@ -70,6 +70,8 @@ SHAPES: Dict[str, LlamaShape] = {
     "tiny-hs64": LlamaShape(256, 704, 2, 4, 2, 1000, 96),    # hs 64 like TinyLlama, kv_mul 2
     "tiny-hs128": LlamaShape(512, 1376, 2, 4, 4, 640, 40),   # hs 128 like Llama-2-7B
     "tiny-70bish": LlamaShape(1024, 3584, 3, 8, 1, 800, 64),  # E:nh:nkv = 70B ratios / 8, hs 128
+    # smallest shape the persistent whole-token kernel is instantiated for (rows divide over 256 CUs)
+    "tk-small": LlamaShape(256, 768, 2, 4, 2, 1024, 64),
 }
 
 

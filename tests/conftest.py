@@ -10,7 +10,8 @@ if ROOT not in sys.path:
 import llm_f90_amd  # noqa: E402,F401  (alias for the llm.f90_amd/ directory)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = ["tiny-gqa", "tiny-gqa-prompt", "tiny-mha", "tiny-hs64", "tiny-hs128", "tiny-70bish"]
+GOLDEN_CASES = ["tiny-gqa", "tiny-gqa-prompt", "tiny-mha", "tiny-hs64", "tiny-hs128", "tiny-70bish", "tk-small",
+                "tk-small-prompt"]
 
 # Parity bar (BASELINE.json north_star): logits within 1e-4 relative of the reference CPU path,
 # bit-exact argmax at temperature 0.  "Relative" is measured against the logit scale

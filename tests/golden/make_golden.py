@@ -32,6 +32,8 @@ CASES = [
     ("tiny-hs64", 24, ""),
     ("tiny-hs128", 12, ""),
     ("tiny-70bish", 12, ""),
+    ("tk-small", 32, ""),
+    ("tk-small", 24, "GPU token"),
 ]
 
 

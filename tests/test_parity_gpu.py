@@ -12,8 +12,11 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("tag", GOLDEN_CASES)
-@pytest.mark.parametrize("flags", [0, llmk.FLAG_NO_GRAPH], ids=["graph", "eager"])
+@pytest.mark.parametrize("flags", [0, llmk.FLAG_NO_GRAPH, llmk.FLAG_MULTI_KERNEL], ids=["graph", "eager", "multikernel"])
 def test_f32_matches_reference_golden(tag, flags, gguf):
+    """Every golden case through the default path (the persistent whole-token kernel for the shapes it is
+    instantiated for -- tk-small here --, the 5-launches-per-layer path otherwise) and with the
+    token kernel disabled."""
     g = load_golden(tag)
     fw = gguf.synth_fused(gguf.SHAPES[str(g["shape"])], int(g["seed"]))
     m = llmk.Llmk(fw, flags=flags)
@@ -98,3 +101,64 @@ def test_timings_mode_sections(gguf):
     t = m.timings()
     assert t[0] > 0 and t[2] > 0 and t[3] > 0 and t[4] > 0 and t[1] == 0   # RoPE is fused into section 1
     m.close()
+
+
+def test_token_kernel_is_the_default_for_its_shapes(gguf):
+    """llmk_time_kernel(6) only answers when the ctx runs the persistent whole-token kernel."""
+    fw = gguf.synth_fused(gguf.SHAPES["tk-small"], 3)
+    m = llmk.Llmk(fw)
+    m.forward(2, 1)
+    ms, b = m.time_kernel(6, 3)
+    assert ms > 0 and b > 0
+    m.close()
+    m = llmk.Llmk(fw, flags=llmk.FLAG_MULTI_KERNEL)
+    with pytest.raises(llmk.LlmkError):
+        m.time_kernel(6, 3)
+    m.close()
+    m = llmk.Llmk(gguf.synth_fused(gguf.SHAPES["tiny-hs64"], 3))
+    with pytest.raises(llmk.LlmkError):
+        m.time_kernel(6, 3)
+    m.close()
+
+
+def test_token_kernel_full_context_reset_and_determinism(gguf):
+    s = gguf.SHAPES["tk-small"]
+    fw = gguf.synth_fused(s, 77)
+    m = llmk.Llmk(fw)
+    t1, l1 = m.generate(s.seq_len)                 # fills the KV cache to pos == S
+    ot, ol = Oracle(fw, "omp").generate(s.seq_len)
+    assert rel_err(l1, ol).max() <= REL_TOL
+    assert np.array_equal(t1, ot)
+    t2, l2 = m.generate(s.seq_len)
+    assert np.array_equal(l1, l2)                  # bit-identical replay: fixed reduction order, no atomics in the data path
+    t3, _ = m.generate(s.seq_len, want_logits=False, greedy_on_device=True)
+    assert np.array_equal(t3, ot)
+    with pytest.raises(llmk.LlmkError):
+        m.forward(1, s.seq_len + 1)
+    m.close()
+
+
+def test_tinyllama_size_token_kernel_vs_multikernel_vs_oracle(gguf):
+    """BASELINE.json's full size (TinyLlama-1.1B f32, 4.4 GB of synthetic weights).  The oracle checks the
+    first positions (seconds of CPU); the two independent GPU paths must agree to rounding over 300
+    positions, which crosses the 256-timestep tile of the in-kernel attention."""
+    s = gguf.SHAPES["tinyllama"]
+    fw = gguf.synth_fused(s, 20260928)
+    n = 300
+    ref = llmk.Llmk(fw, flags=llmk.FLAG_MULTI_KERNEL)
+    rt, rl = ref.generate(n)
+    ref.close()
+    m = llmk.Llmk(fw)
+    assert m.time_kernel(6, 1)[0] > 0              # the persistent kernel is what runs
+    tt, tl = m.generate(n)
+    m.close()
+    err = rel_err(tl, rl)
+    assert err.max() <= 2e-5, err.max()            # same arithmetic, different summation order
+    margin = np.sort(rl, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(rl).max()
+    assert np.array_equal(tt[safe], rt[safe])
+    k = 4
+    ot, ol = Oracle(fw, "omp").generate(k)
+    assert rel_err(tl[:k], ol).max() <= REL_TOL
+    assert rel_err(rl[:k], ol).max() <= REL_TOL
+    assert np.array_equal(tt[:k], ot)
