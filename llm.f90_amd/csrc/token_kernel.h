@@ -31,7 +31,7 @@ namespace llmk {
 
 constexpr int TK_NCU = 256;               // one workgroup per CU
 constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
-constexpr int TK_NB = 4;                  // register tiles a streaming wave keeps requested ahead (4 x 8 KB)
+constexpr int TK_NB = 5;                  // register tiles a streaming wave keeps requested ahead (4 x 8 KB)
 constexpr int TK_NS = TK_WAVES - 1;
 constexpr int TK_THREADS = TK_WAVES * WAVE;
 constexpr int TK_TCOLS = 8;               // 16-byte vector columns per tile (8 x 64 lanes x 4 floats = 2048)
@@ -224,15 +224,23 @@ __device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t,
         b[j] = ldg_nt(pj + lane);
     }
 }
-__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, float* part,
-                                           int lane) {
-    float acc = 0.f;
+// per-lane partial dot of one tile: four independent FMA chains (x,y,z,w) instead of one 32-deep chain
+__device__ __forceinline__ float tk_dot_tile(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, int lane) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int xj = (j < t.ncol) ? t.xoff + j * WAVE : 0;      // zero weights: any finite x will do
-        acc = dot4(b[j], xs[xj + lane], acc);
+        const float4 x = xs[xj + lane];
+        acc.x = fmaf(b[j].x, x.x, acc.x);
+        acc.y = fmaf(b[j].y, x.y, acc.y);
+        acc.z = fmaf(b[j].z, x.z, acc.z);
+        acc.w = fmaf(b[j].w, x.w, acc.w);
     }
-    acc = wave_sum(acc);
+    return (acc.x + acc.y) + (acc.z + acc.w);
+}
+__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, float* part,
+                                           int lane) {
+    const float acc = wave_sum(tk_dot_tile(b, t, xs, lane));
     if (lane == 0) part[t.pidx] = acc;
 }
 
@@ -613,11 +621,20 @@ __device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int
 // handed to the service wave (barrier B), and only THEN refilled.  Issuing a refill can block for
 // microseconds when the CU's memory pipeline is full of earlier prefetches; that wait must not sit
 // between the dot products and the publish of the phase's result.
+// N tiles at once: all per-lane dots first, then the N wave reductions (independent DPP chains the
+// scheduler can interleave), then ONE lane-0 block of LDS writes
 template <class SH, int K, int N>
 __device__ __forceinline__ void tk_eat(const TkRing& r, const float4* xs4, float* part, int lane) {
     if constexpr (N > 0) {
-        tk_consume(r.b[K % TK_NB], r.t[K % TK_NB], xs4, part, lane);
-        tk_eat<SH, K + 1, N - 1>(r, xs4, part, lane);
+        float v[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = tk_dot_tile(r.b[(K + i) % TK_NB], r.t[(K + i) % TK_NB], xs4, lane);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) part[r.t[(K + i) % TK_NB].pidx] = v[i];
+        }
     }
 }
 template <class SH, int K, int N, bool CLS>
