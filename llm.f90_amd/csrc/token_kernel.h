@@ -127,9 +127,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tk_rsrc(const void* p, int byt
 // Returns false on timeout / sticky error.
 template <int NL>
 __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* dst,
-                                               unsigned* err, int lane, unsigned long long* dbg = nullptr) {
+                                               unsigned* err, int lane, bool nowait, unsigned long long* dbg) {
     for (unsigned spin = 0;; ++spin) {
-        const unsigned long long tp0 = dbg > reinterpret_cast<unsigned long long*>(1) ? wall_clock64() : 0;
+        const unsigned long long tp0 = dbg ? wall_clock64() : 0;
         tk_v4u r[NL];
         // NO predicate on the loads: a per-load condition makes hipcc branch around each one and wait
         // vmcnt(0) per element (NL dependent round trips instead of one)
@@ -143,8 +143,8 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
             const int i = 2 * (first_pair + lane + k * WAVE);
             *reinterpret_cast<float2*>(dst + i) = make_float2(__uint_as_float(r[k].x), __uint_as_float(r[k].z));
         }
-        if (__all(ok) || (dbg == reinterpret_cast<unsigned long long*>(1))) {
-            if (dbg > reinterpret_cast<unsigned long long*>(1) && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
+        if (__all(ok) || nowait) {
+            if (dbg && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
             return true;
         }
         if ((spin & 63) == 63) {
@@ -159,17 +159,16 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
 }
 template <int N>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
-                                          int lane, unsigned long long* dbg = nullptr) {
+                                          int lane, bool nowait = false, unsigned long long* dbg = nullptr) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     if constexpr (NL <= 24) {
-        return tk_gather_part<NL>(rs, 0, epoch, dst, err, lane, dbg);
+        return tk_gather_part<NL>(rs, 0, epoch, dst, err, lane, nowait, dbg);
     } else {      // long vectors in two register-sized halves
         constexpr int H0 = NL / 2, H1 = NL - H0;
-        const bool a = tk_gather_part<H0>(rs, 0, epoch, dst, err, lane, dbg);
-        const bool b = tk_gather_part<H1>(rs, H0 * WAVE, epoch, dst, err, lane,
-                                            dbg > reinterpret_cast<unsigned long long*>(1) ? dbg + 2 : dbg);
+        const bool a = tk_gather_part<H0>(rs, 0, epoch, dst, err, lane, nowait, dbg);
+        const bool b = tk_gather_part<H1>(rs, H0 * WAVE, epoch, dst, err, lane, nowait, dbg ? dbg + 2 : nullptr);
         return a && b;
     }
 }
@@ -455,7 +454,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 #pragma unroll 8
             for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
         } else {
-            ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+            ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
         }
         TK_STAMP(1);
         const float xn_att = nrm.apply(xraw, xs, lane);
@@ -517,19 +516,23 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 12 : nullptr);
             tk_barrier();
             TK_STAMP(6);
-            const float4* red = reinterpret_cast<const float4*>(lds + LD::ATT_RED);
-            constexpr int LPT = SH::HS / 4;
-            const int d4 = lane >> 2, comp = lane & 3;   // output dim = lane
-            float o = 0.f;
+            // fold the waves*TPW partial output vectors: lane = output dim, one conflict-free ds_read_b32 per partial
+            const float* redf = reinterpret_cast<const float*>(lds + LD::ATT_RED);
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
-            for (int w = 0; w < TK_WAVES * (64 / LPT); ++w) {
-                const float4 r = red[w * LPT + d4];
-                o += (comp == 0) ? r.x : (comp == 1) ? r.y : (comp == 2) ? r.z : r.w;
+            for (int w = 0; w < TK_WAVES * (256 / SH::HS); w += 4) {
+                o0 += redf[(w + 0) * SH::HS + lane];
+                o1 += redf[(w + 1) * SH::HS + lane];
+                o2 += redf[(w + 2) * SH::HS + lane];
+                o3 += redf[(w + 3) * SH::HS + lane];
             }
+            const float o = (o0 + o1) + (o2 + o3);
+            if (tr && lane == 0 && l < 22) tr[(32 + l) * 16 + 10] = wall_clock64();
             tk_publish(a.g_xb + my_head * SH::HS + lane, e_att, o);
+            if (tr && lane == 0 && l < 22) tr[(32 + l) * 16 + 11] = wall_clock64();
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         TK_STAMP(7);
         tk_barrier();
         tk_barrier();
@@ -543,7 +546,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
-        ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+        ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
         TK_STAMP(9);
         const float xn_ffn = nrm.apply(xraw, xs, lane);
         tk_barrier();
@@ -563,7 +566,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        ok = tk_gather<SH::H>(a.g_hb, e_a, xs, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        ok = tk_gather<SH::H>(a.g_hb, e_a, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -582,7 +585,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     TkNorm<SH::E> nrmf;
     nrmf.prefetch(a.rms_final, lane);
-    ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, a.nosync ? reinterpret_cast<unsigned long long*>(1) : nullptr) && ok;
+    ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, a.nosync != 0) && ok;
     const float xn_fin = nrmf.apply(xraw, xs, lane);
     tk_barrier();
     tk_barrier();

@@ -65,3 +65,8 @@ if os.environ.get("LLMK_TK_TRACE"):
     t5 = raw[ai][:, 1:22, 5] / 100.0; t6 = raw[ai][:, 1:22, 6] / 100.0
     print("attention (service wave view): enter->scores done %.2f | barrier wait %.2f | softmax+PV %.2f | tail barrier %.2f" % (
         (d[:, :, 0] - t5).mean(), (d[:, :, 1] - d[:, :, 0]).mean(), (d[:, :, 2] - d[:, :, 1]).mean(), (t6 - d[:, :, 2]).mean()))
+    pb = raw[ai][:, 32+1:32+22, 10:12] / 100.0
+    t6 = raw[ai][:, 1:22, 6] / 100.0
+    t7all = raw[:, 1:22, 7] / 100.0
+    print("xb publish: attDone->before publish %.2f us, publish call %.2f us; consumers done after last publish-return: mean %.2f" % (
+        (pb[:, :, 0] - t6).mean(), (pb[:, :, 1] - pb[:, :, 0]).mean(), (t7all - pb[:, :, 1].max(axis=0)[None, :]).mean()))
