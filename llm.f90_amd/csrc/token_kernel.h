@@ -390,9 +390,11 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     float m = -INFINITY;
     for (int t = lane; t < pos; t += WAVE) m = fmaxf(m, att[t]);
     m = wave_max(m);
+    if (dbg) dbg[3] = wall_clock64();
     float s = 0.f;
     for (int t = lane; t < pos; t += WAVE) s += expf(att[t] - m);
     s = wave_sum(s);
+    if (dbg) dbg[4] = wall_clock64();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < pos; base += TILE) {
@@ -447,6 +449,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
         TK_STAMP(0);
+
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
         TkNorm<SH::E> nrm;
         nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
@@ -513,7 +516,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
             TK_STAMP(5);
             tk_barrier();
-            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 12 : nullptr);
+            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 10 : nullptr);
             tk_barrier();
             TK_STAMP(6);
             // fold the waves*TPW partial output vectors: lane = output dim, one conflict-free ds_read_b32 per partial
@@ -527,9 +530,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 o3 += redf[(w + 3) * SH::HS + lane];
             }
             const float o = (o0 + o1) + (o2 + o3);
-            if (tr && lane == 0 && l < 22) tr[(32 + l) * 16 + 10] = wall_clock64();
             tk_publish(a.g_xb + my_head * SH::HS + lane, e_att, o);
-            if (tr && lane == 0 && l < 22) tr[(32 + l) * 16 + 11] = wall_clock64();
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
         ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;

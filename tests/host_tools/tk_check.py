@@ -61,12 +61,8 @@ if os.environ.get("LLMK_TK_TRACE"):
     for j, nm in enumerate(["x", "xb", "xa", "hb(1st half)", "hb(2nd half)"]):
         print(f"gather {nm}: passes mean {g[:, 1:, 2*j].mean():.1f} max {g[:, 1:, 2*j].max():.0f}; last pass us mean {g[:, 1:, 2*j+1].mean()/100:.2f} max {g[:, 1:, 2*j+1].max()/100:.2f}")
     ai = np.where(att)[0]
-    d = raw[ai][:, 32+1:32+22, 12:15] / 100.0
+    d = raw[ai][:, 32+1:32+22, 10:15] / 100.0     # scores done, after barrier, end, after max, after sum
     t5 = raw[ai][:, 1:22, 5] / 100.0; t6 = raw[ai][:, 1:22, 6] / 100.0
-    print("attention (service wave view): enter->scores done %.2f | barrier wait %.2f | softmax+PV %.2f | tail barrier %.2f" % (
-        (d[:, :, 0] - t5).mean(), (d[:, :, 1] - d[:, :, 0]).mean(), (d[:, :, 2] - d[:, :, 1]).mean(), (t6 - d[:, :, 2]).mean()))
-    pb = raw[ai][:, 32+1:32+22, 10:12] / 100.0
-    t6 = raw[ai][:, 1:22, 6] / 100.0
-    t7all = raw[:, 1:22, 7] / 100.0
-    print("xb publish: attDone->before publish %.2f us, publish call %.2f us; consumers done after last publish-return: mean %.2f" % (
-        (pb[:, :, 0] - t6).mean(), (pb[:, :, 1] - pb[:, :, 0]).mean(), (t7all - pb[:, :, 1].max(axis=0)[None, :]).mean()))
+    print("attention (service wave): enter->scores %.2f | barrier %.2f | max %.2f | exp+sum %.2f | PV+write %.2f | tail barrier %.2f" % (
+        (d[:, :, 0] - t5).mean(), (d[:, :, 1] - d[:, :, 0]).mean(), (d[:, :, 3] - d[:, :, 1]).mean(),
+        (d[:, :, 4] - d[:, :, 3]).mean(), (d[:, :, 2] - d[:, :, 4]).mean(), (t6 - d[:, :, 2]).mean()))
