@@ -6,7 +6,7 @@
 ! llama2.f90:102-108).  There is no CPU forward pass in this program.
 !
 !   ./llm -m model.gguf [-p prompt] [-n tokens] [-t temperature] [-s tokenizer.bin] [-v]
-!         [-d device] [--device-argmax]
+!         [--ak] [-d device] [--device-argmax]
 module arg_parse
   implicit none
 
@@ -70,6 +70,7 @@ program llm
   use weight_module
   use arg_parse
   use read_ggml, only: load_ggml
+  use ak_loader, only: load_ak
   use llmk_binding
   implicit none
 
@@ -91,11 +92,15 @@ program llm
 
   call parse_args(opts)
   if (opts%ak) then
-     print *, "--ak (llama2.c flat format) is not supported on the GPU path yet; use a GGUF file"
-     stop 1
+     ! llama2.c flat format: no tokenizer inside, `-s tokenizer.bin` is required (llama2.f90:160-356)
+     call load_ak(opts%model_file, weights, conf, opts%verbose)
+     if (opts%tokenizer == "") then
+        print *, "--ak needs a tokenizer file: -s tokenizer.bin"
+        stop 1
+     end if
+  else
+     call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose)
   end if
-
-  call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose)
   if (opts%verbose) print *, "Loaded weights"
   if (opts%tokenizer /= "") call read_tokenizer_bin(opts%tokenizer)
   max_len = maxval(vocab_len)

@@ -370,6 +370,32 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
             f.write(b"\0" * ((-nbytes) % alignment))
 
 
+def write_ak(path: str, fw: "FusedWeights") -> None:
+    """llama2.c-style flat checkpoint ("ak" format) in the order the reference's `--ak` reader
+    consumes it (/root/reference/llama2.f90:160-292): 7 int32 header, token_embedding_table,
+    rms_att_weight, wq, wk, wv (layer-major each), wo, rms_ffn_weight, w1, w2, w3, rms_final_weight,
+    wcls.  f32 only."""
+    assert fw.ggml_type == GGML_F32
+    s = fw.shape
+    E, H, KV = s.emb_dim, s.hidden_dim, s.kv_dim
+    with open(path, "wb") as f:
+        f.write(struct.pack("<7i", s.emb_dim, s.hidden_dim, s.n_layers, s.n_heads, s.n_kv_heads, s.vocab_size, s.seq_len))
+        for a in (fw.token_embedding_table, fw.rms_att_weight, fw.wqkv[:, 0:E], fw.wqkv[:, E:E + KV],
+                  fw.wqkv[:, E + KV:E + 2 * KV], fw.wo, fw.rms_ffn_weight, fw.w13[:, 0:H], fw.w2, fw.w13[:, H:2 * H],
+                  fw.rms_final_weight, fw.wcls):
+            f.write(np.ascontiguousarray(a, dtype="<f4").tobytes())
+
+
+def write_tokenizer_bin(path: str, vocab: List[bytes], scores=None) -> None:
+    """llama2.c tokenizer.bin as the reference reads it (llama2.f90:321-356): int32 max_len, then per
+    token f32 score, int32 length, bytes."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", max(len(t) for t in vocab)))
+        for i, t in enumerate(vocab):
+            f.write(struct.pack("<fi", float(-i if scores is None else scores[i]), len(t)))
+            f.write(t)
+
+
 def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = GGML_F32,
                      alignment: int = 32, version: int = 3) -> None:
     """Synthetic Llama GGUF: tensor bytes are a pure function of (shape, seed, type)."""

@@ -34,6 +34,7 @@ CASES = [
     ("tiny-70bish", 12, ""),
     ("tk-small", 32, ""),
     ("tk-small", 24, "GPU token"),
+    ("tiny-gqa", 16, "ak"),          # same weights through the `--ak` flat format + `-s tokenizer.bin`
 ]
 
 
@@ -49,10 +50,20 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         for name, n, prompt in CASES:
             s = gguf.SHAPES[name]
-            path = os.path.join(td, name + ".gguf")
-            gguf.write_synth_gguf(path, s, SEED)
+            ak = prompt == "ak"
+            if ak:
+                prompt = ""
+                path = os.path.join(td, name + ".ak")
+                gguf.write_ak(path, gguf.synth_fused(s, SEED))
+                tokp = os.path.join(td, name + ".tokenizer.bin")
+                gguf.write_tokenizer_bin(tokp, gguf.vocab_strings(s.vocab_size))
+            else:
+                path = os.path.join(td, name + ".gguf")
+                gguf.write_synth_gguf(path, s, SEED)
             exe = os.path.join(ROOT, "oracle", "_ref", "llm_ref_" + name)
             cmd = [exe, "-m", path, "-n", str(n), "-t", "0"] + (["-p", prompt] if prompt else [])
+            if ak:
+                cmd += ["--ak", "-s", tokp]
             r = subprocess.run(cmd, cwd=td, capture_output=True, check=True)
             logits = np.fromfile(os.path.join(td, "logits.bin"), dtype="<f4").reshape(n, s.vocab_size)
             pids = prompt_ids(prompt)
@@ -60,11 +71,14 @@ def main():
             vocab = gguf.vocab_strings(s.vocab_size)
             text = b"".join(vocab[t - 1] for t in toks)
             lines = r.stdout.split(b"\n")
-            assert lines[0].strip().startswith(b"data offset"), lines[0]
-            assert lines[1].rstrip(b" ") == text, (lines[1], text)   # reference printed the same tokens
+            if ak:
+                assert lines[0].rstrip(b" ") == text, (lines[0], text)
+            else:
+                assert lines[0].strip().startswith(b"data offset"), lines[0]
+                assert lines[1].rstrip(b" ") == text, (lines[1], text)   # reference printed the same tokens
             srt = np.sort(logits, axis=1)
-            tag = name + ("-prompt" if prompt else "")
-            np.savez_compressed(os.path.join(outdir, tag + ".npz"), shape=name, seed=SEED, n=n, prompt=prompt,
+            tag = name + ("-ak" if ak else "-prompt" if prompt else "")
+            np.savez_compressed(os.path.join(outdir, tag + ".npz"), shape=name, seed=SEED, n=n, prompt=prompt, ak=ak,
                                 prompt_ids=np.asarray(pids, np.int32), logits=logits,
                                 tokens=np.asarray(toks, np.int32), stdout=np.frombuffer(r.stdout, np.uint8),
                                 top1_margin=(srt[:, -1] - srt[:, -2]))

@@ -144,3 +144,15 @@ def test_llm_binary_has_no_cpu_fallback(tools, gguf):
     g = load_golden("tiny-gqa")
     assert r.stdout.split(b"\n")[0] == bytes(g["stdout"]).split(b"\n")[0]     # same " data offset" line as the reference
     assert r.returncode != 0 and b"no usable HIP device" in r.stdout
+
+
+def test_ak_requires_tokenizer_and_rejects_garbage(tools, gguf):
+    s = gguf.SHAPES["tiny-gqa"]
+    ak = str(tools["dir"] / "m.ak")
+    gguf.write_ak(ak, gguf.synth_fused(s, 5))
+    r = subprocess.run([tools["llm"], "--ak", "-m", ak, "-n", "4"], capture_output=True)
+    assert r.returncode != 0 and b"--ak needs a tokenizer file" in r.stdout
+    bad = str(tools["dir"] / "bad.ak")
+    open(bad, "wb").write(struct.pack("<7i", 0, 0, 0, 0, 0, 0, 0))
+    r = subprocess.run([tools["llm"], "--ak", "-m", bad, "-s", ak], capture_output=True)
+    assert r.returncode != 0 and b"not an ak checkpoint" in r.stdout

@@ -66,3 +66,18 @@ def test_cli_runs_f16_and_q4_files(wtype, gguf, tmp_path):
     vocab = gguf.vocab_strings(s.vocab_size)
     assert out[1].rstrip(b" ") == b"".join(vocab[t - 1] for t in toks).rstrip(b" ")
     m.close()
+
+
+def test_cli_ak_format_matches_reference_transcript(gguf, tmp_path):
+    """`--ak` (llama2.c flat checkpoint) + `-s tokenizer.bin`: same tokens as the real reference printed
+    for the same weights through its own --ak reader (tests/golden/tiny-gqa-ak.npz)."""
+    g = load_golden("tiny-gqa-ak")
+    s = gguf.SHAPES["tiny-gqa"]
+    ak = str(tmp_path / "m.ak")
+    tok = str(tmp_path / "tokenizer.bin")
+    gguf.write_ak(ak, gguf.synth_fused(s, int(g["seed"])))
+    gguf.write_tokenizer_bin(tok, gguf.vocab_strings(s.vocab_size))
+    out = _run(["--ak", "-m", ak, "-s", tok, "-n", str(int(g["n"])), "-t", "0"], str(tmp_path)).split(b"\n")
+    ref = bytes(g["stdout"]).split(b"\n")
+    k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
+    assert out[:k] == ref[:k]
