@@ -118,6 +118,8 @@ def main():
 
     rep = Replicas()
     rank, world, local = rep.rank, rep.world, rep.local
+    if os.environ.get("LLMK_SHARE_GPU"):      # test aid: several replicas on one GPU (use with --multi-kernel)
+        local = 0
 
     shape = gguf.SHAPES[a.shape]
     wtype = {"f32": 0, "f16": 1, "q4_0": 2}[a.type]
