@@ -103,6 +103,67 @@ def cpu_baseline(fw, shape_name: str, wtype: int, n_ref: int = 128):
                       f"host has {os.cpu_count()} logical cores"}
 
 
+class _ShapeOnly:
+    """what llmk.Llmk needs to create a ctx without weights (they are streamed in layer by layer)"""
+    def __init__(self, shape, wtype):
+        self.shape, self.ggml_type = shape, wtype
+
+
+def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep):
+    """Create the ctx first, then upload layer by layer (llmk_upload_rows hands over FULL layers; a
+    tensor-parallel ctx keeps only its shard).  q4_0 weights of the big shapes are generated directly in
+    block format.  With tp_size > 1 rank 0's RCCL unique id is broadcast over torch.distributed."""
+    import ctypes as C
+    s = shape
+    E, H, L, KV, V = s.emb_dim, s.hidden_dim, s.n_layers, s.kv_dim, s.vocab_size
+    cfg = llmk.Config(E, H, L, s.n_heads, s.n_kv_heads, V, s.seq_len, wtype, device, flags)
+    m = llmk.Llmk.__new__(llmk.Llmk)
+    m.shape, m.V, m.tp_rank, m.tp_size = s, V, tp_rank, tp_size
+    m._h = C.c_void_p()
+    llmk._ck(llmk.lib().llmk_create_tp(C.byref(cfg), tp_rank, tp_size, C.byref(m._h)))
+    m._logits = np.empty(V, np.float32)
+    if tp_size > 1 or rep is not None:
+        uid = llmk.Llmk.tp_unique_id() if tp_rank == 0 else bytes(128)
+        if rep is not None and rep.dist is not None:
+            import torch
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=rep.device)
+            rep.dist.broadcast(t, src=0)
+            uid = bytes(t.cpu().tolist())
+        m.tp_init_comm(uid)
+
+    def up(tid, layer, arr, typ):
+        arr = np.ascontiguousarray(arr)
+        llmk._ck(llmk.lib().llmk_upload_rows(m._h, tid, layer, 0, arr.shape[0] if arr.ndim > 1 else 1, arr.ctypes.data,
+                                             arr.nbytes, typ))
+    T = llmk.TENSOR_IDS
+    names = gguf.tensor_names(s)
+    idx = {n: i for i, (n, _, _) in enumerate(names)}
+    if fw is not None:
+        up(T["token_embedding_table"], 0, fw.token_embedding_table, 0)
+        up(T["rms_final_weight"], 0, fw.rms_final_weight, 0)
+        up(T["wcls"], 0, fw.wcls, wtype)
+        for l in range(L):
+            up(T["rms_att_weight"], l, fw.rms_att_weight[l], 0)
+            up(T["rms_ffn_weight"], l, fw.rms_ffn_weight[l], 0)
+            for k in ("wqkv", "wo", "w13", "w2"):
+                up(T[k], l, getattr(fw, k)[l], wtype)
+        return m
+    q4 = lambda name, rows, K: gguf.synth_q4_rows(SEED, idx[name], rows, K)
+    up(T["token_embedding_table"], 0, gguf.synth_tensor(s, SEED, idx["token_embd.weight"], (V, E), "emb"), 0)
+    up(T["rms_final_weight"], 0, gguf.synth_tensor(s, SEED, idx["output_norm.weight"], (E,), "norm"), 0)
+    up(T["wcls"], 0, q4("output.weight", V, E), 2)
+    for l in range(L):
+        pre = f"blk.{l}."
+        up(T["rms_att_weight"], l, gguf.synth_tensor(s, SEED, idx[pre + "attn_norm.weight"], (E,), "norm"), 0)
+        up(T["rms_ffn_weight"], l, gguf.synth_tensor(s, SEED, idx[pre + "ffn_norm.weight"], (E,), "norm"), 0)
+        up(T["wqkv"], l, np.concatenate([q4(pre + "attn_q.weight", E, E), q4(pre + "attn_k.weight", KV, E),
+                                         q4(pre + "attn_v.weight", KV, E)]), 2)
+        up(T["wo"], l, q4(pre + "attn_output.weight", E, E), 2)
+        up(T["w13"], l, np.concatenate([q4(pre + "ffn_gate.weight", H, E), q4(pre + "ffn_up.weight", H, E)]), 2)
+        up(T["w2"], l, q4(pre + "ffn_down.weight", E, H), 2)
+    return m
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,8 +174,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling aid)")
     ap.add_argument("--multi-kernel", action="store_true", help="5 launches per layer instead of the persistent token kernel")
+    ap.add_argument("--tp", action="store_true",
+                    help="tensor-parallel: ONE model sharded over the N ranks (RCCL all-reduce), the 70B configuration; "
+                         "default for N>1 is N independent replicas")
     ap.add_argument("--greedy-on-device", action="store_true", help="time llmk_forward_greedy instead")
     a = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout.  RCCL (torch's, and ours in --tp mode) prints a version banner
+    # through C stdio to fd 1 whenever a communicator is created, so everything this process or its
+    # libraries print is sent to stderr and the result line alone goes to the real stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rep = Replicas()
     rank, world, local = rep.rank, rep.world, rep.local
@@ -128,9 +199,16 @@ def main():
         raise SystemExit(f"warmup+steps must be <= seq_len {shape.seq_len}")
 
     t0 = time.perf_counter()
-    fw = gguf.synth_fused(shape, SEED, wtype)
+    flags = (llmk.FLAG_NO_GRAPH if a.no_graph else 0) | (llmk.FLAG_MULTI_KERNEL if a.multi_kernel else 0)
+    big = shape.matmul_params() > 3e9            # 7B / 70B: never materialise f32 weights on the host
+    if big and wtype != 2:
+        raise SystemExit("the 7B/70B shapes are benchmarked as q4_0 (BASELINE.json configs[3], configs[4])")
+    fw = None if big else gguf.synth_fused(shape, SEED, wtype)
     t_gen = time.perf_counter() - t0
-    m = llmk.Llmk(fw, device=local, flags=(llmk.FLAG_NO_GRAPH if a.no_graph else 0) | (llmk.FLAG_MULTI_KERNEL if a.multi_kernel else 0))
+    if a.tp or big:
+        m = build_streamed(shape, wtype, fw, local, flags, rank if a.tp else 0, world if a.tp else 1, rep if a.tp else None)
+    else:
+        m = llmk.Llmk(fw, device=local, flags=flags)
     t_up = time.perf_counter() - t0 - t_gen
 
     barrier = rep.barrier
@@ -162,18 +240,18 @@ def main():
     if not np.all(np.isfinite(lg)):
         raise SystemExit("non-finite logits")
 
-    tok_s = world * K / elapsed
+    tok_s = (1 if a.tp else world) * K / elapsed   # --tp: ONE model over all ranks; else N replicas
     mean_pos = W + (K + 1) / 2.0
     bpt = bytes_per_token(shape, wtype, mean_pos)
 
     out = {
         "metric": "tokens/sec TinyLlama-1.1B decode" if a.shape == "tinyllama" else f"tokens/sec {a.shape} decode",
         "value": tok_s, "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "strong" if a.tp else "weak", "vs_baseline": None,
         "dtype": a.type, "data": "synthetic",
         "config": {"workload": f"{a.shape} {a.type} decode, greedy, positions {W + 1}..{W + K} (./llm -n {W + K} -t 0)",
                    "consumer": "device argmax (llmk_forward_greedy)" if step else "logits to host + host argmax (llmk_forward)",
-                   "parallelism": "replicas" if world > 1 else "single GPU", "seed": SEED,
+                   "parallelism": (f"tp{world} (row-parallel GEMVs, RCCL all-reduce)" if a.tp else "replicas" if world > 1 else "single GPU"), "seed": SEED,
                    "path": "multi-kernel (5 launches/layer)" if a.multi_kernel else "default (persistent token kernel where instantiated)"},
     }
     if rank == 0:
@@ -201,13 +279,13 @@ def main():
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": pmc_traffic("gemv_kernel<0, 3, true"), "bytes_per_launch": b,
                                "us_per_launch": ms * 1000, "kernels": per_k}
-        tok_gbs = bpt * (tok_s / world) / 1e9
+        tok_gbs = bpt * (tok_s / (1 if a.tp else world)) / 1e9 / (world if a.tp else 1)   # per-GPU HBM rate
         out["token_roofline"] = {"bytes_per_token": bpt, "achieved": tok_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": tok_gbs / HBM_PEAK_GBS, "roofline_tok_s": HBM_PEAK_GBS * 1e9 / bpt}
         out["setup_s"] = {"weights_gen": round(t_gen, 1), "upload": round(t_up, 1)}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fw, a.shape, wtype)
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(fw, a.shape, wtype) if fw is not None else None
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     rep.close()
 

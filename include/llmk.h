@@ -67,6 +67,7 @@ extern "C" {
 #define LLMK_E_NODEVICE 6  /* no usable HIP device (there is no CPU fallback)                       */
 #define LLMK_E_NOMEM 7
 #define LLMK_E_TIMEOUT 8   /* an in-kernel exchange timed out (GPU shared with other work?)        */
+#define LLMK_E_COMM 9      /* tensor-parallel ctx used before llmk_tp_init_comm, or an RCCL error       */
 #define LLMK_E_HIP 1000    /* 1000 + hipError_t                                                     */
 
 /* Run-time replacement of the reference's compile-time dims (llama2.f90:102-108) and of
@@ -89,6 +90,31 @@ typedef struct llmk_ctx llmk_ctx;
 /* Allocates device weights + RunState (key_cache, value_cache zeroed as at llama2.f90:316-318).
  * Replaces: the allocations at llama2.f90:311-319 and read_ggml.f90:265-410. */
 int llmk_create(const llmk_config *cfg, llmk_ctx **out);
+
+/* Tensor-parallel shard `tp_rank` of `tp_size` of the same model (for the 70B configuration,
+ * where one GPU's HBM bandwidth is the limit).  Megatron split: wqkv, w13 and wcls by output rows (each rank
+ * owns nkv/P kv heads and their query heads, H/P hidden rows, V/P vocabulary rows), wo and w2 by the
+ * contraction dimension; per layer two all-reduces of an E-vector, one all-gather of the logits per token.
+ * llmk_upload / llmk_upload_rows are handed the FULL tensors (whole layers) and keep only this rank's
+ * shard.  Requires n_kv_heads, hidden_dim, vocab_size divisible by tp_size.  One process per GPU:
+ * rank 0 calls llmk_tp_unique_id, ships the 128 bytes to the other ranks (any side channel), every rank
+ * calls llmk_tp_init_comm; after that llmk_forward / llmk_forward_greedy run the collectives over RCCL. */
+int llmk_create_tp(const llmk_config *cfg, int tp_rank, int tp_size, llmk_ctx **out);
+int llmk_tp_unique_id(char id_out[128]);
+int llmk_tp_init_comm(llmk_ctx *ctx, const char id[128]);
+
+/* Single-process stepping of a tensor-parallel ctx, for verification on one GPU (no communicator): the
+ * caller plays the collective.  llmk_tp_begin sets token/pos; llmk_tp_segment runs
+ *   seg 0 (layer l):  [l>0: x += exchanged]  rmsnorm+qkv, attention, wo   -> partial E-vector
+ *   seg 1 (layer l):  x += exchanged          rmsnorm+w1|w3, w2            -> partial E-vector
+ *   seg 2:            x += exchanged          final rmsnorm + classifier   -> this rank's V/P logits
+ * llmk_tp_read_partial / llmk_tp_write_partial move the E-vector (the caller sums the ranks' partials in
+ * rank order and writes the sum back to every rank); llmk_tp_read_logits returns the rank's logits slice. */
+int llmk_tp_begin(llmk_ctx *ctx, int token, int pos);
+int llmk_tp_segment(llmk_ctx *ctx, int seg, int layer);
+int llmk_tp_read_partial(llmk_ctx *ctx, float *out);
+int llmk_tp_write_partial(llmk_ctx *ctx, const float *in);
+int llmk_tp_read_logits(llmk_ctx *ctx, float *out_slice);
 
 /* Copy one whole TransformerWeights component to the device.  `host` points at the first
  * element of the Fortran array (c_loc(w%wqkv) ...); nbytes must equal the full array size for

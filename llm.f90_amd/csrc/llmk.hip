@@ -15,6 +15,8 @@
 #include "kernels.h"
 #include "token_kernel.h"
 
+#include <rccl/rccl.h>
+
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +24,8 @@
 #include <new>
 
 using namespace llmk;
+
+extern "C" int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** out);
 
 #define HIPCHK(expr)                                          \
     do {                                                      \
@@ -53,6 +57,13 @@ struct DevTensor {
 struct llmk_ctx {
     llmk_config cfg;
     int E, H, L, nh, nkv, V, S, hs, KV, kv_mul;
+    // tensor-parallel shard of this ctx (tp_size == 1: the whole model). Local dims: q columns, kv dim,
+    // hidden rows, vocab rows and heads owned by this rank (Megatron split).
+    int tp_rank = 0, tp_size = 1;
+    int Eq, KVl, Hl, Vl, nhl;
+    ncclComm_t comm = nullptr;
+    float* d_part = nullptr;       // [E] partial sums of the row-parallel GEMVs (wo, w2) before the all-reduce
+    TensorDesc gdesc[LLMK_N_TENSORS];  // the full (unsharded) tensors, what llmk_upload is handed
     TensorDesc desc[LLMK_N_TENSORS];
     DevTensor t[LLMK_N_TENSORS];
     float *d_kc = nullptr, *d_vc = nullptr;  // [L][S][KV]  (RunState, weight_module.f90:33-40)
@@ -120,12 +131,12 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int /*n_cu*/
 }
 
 hipError_t launch_attn(llmk_ctx* c, int l) {
-    const float* kc = c->d_kc + (size_t)l * c->S * c->KV;
-    const float* vc = c->d_vc + (size_t)l * c->S * c->KV;
+    const float* kc = c->d_kc + (size_t)l * c->S * c->KVl;
+    const float* vc = c->d_vc + (size_t)l * c->S * c->KVl;
     const size_t smem = (516 + (size_t)c->S) * sizeof(float);
 #define ATT(HS_)                                                                                                 \
-    hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nh), dim3(256), smem, c->stream, c->d_q, kc, vc, c->d_xb,      \
-                       c->d_tokpos, c->KV, c->kv_mul)
+    hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nhl), dim3(256), smem, c->stream, c->d_q, kc, vc, c->d_xb,     \
+                       c->d_tokpos, c->KVl, c->kv_mul)
     switch (c->hs) {
         case 16: ATT(16); break;
         case 32: ATT(32); break;
@@ -152,20 +163,26 @@ GemvArgs base_args(llmk_ctx* c, int tid, int l, const float* x, const float* nor
     a.K = d.K;
     a.rope_freqs = c->d_rope;
     a.tokpos = c->d_tokpos;
-    a.E = c->E;
-    a.KV = c->KV;
+    a.E = c->Eq;
+    a.KV = c->KVl;
     a.hs = c->hs;
-    a.H = c->H;
+    a.H = c->Hl;
     return a;
 }
 
 hipError_t launch_qkv(llmk_ctx* c, int l) {
     GemvArgs a = base_args(c, LLMK_WQKV, l, c->d_x, (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * c->E, c->d_q);
-    a.kc = c->d_kc + (size_t)l * c->S * c->KV;
-    a.vc = c->d_vc + (size_t)l * c->S * c->KV;
+    a.kc = c->d_kc + (size_t)l * c->S * c->KVl;
+    a.vc = c->d_vc + (size_t)l * c->S * c->KVl;
     return launch_gemv_t<EPI_ROPE_KV, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
 }
+// Row-parallel GEMVs (wo, w2): with tp_size > 1 each rank contracts over ITS slice of the input and
+// writes a PARTIAL x-increment to d_part; the all-reduce + `x += part` follow (tp_reduce_add).
 hipError_t launch_wo(llmk_ctx* c, int l) {
+    if (c->tp_size > 1 || c->comm) {
+        GemvArgs a = base_args(c, LLMK_WO, l, c->d_xb, nullptr, c->d_part);
+        return launch_gemv_t<EPI_STORE, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
+    }
     GemvArgs a = base_args(c, LLMK_WO, l, c->d_xb, nullptr, c->d_x);
     return launch_gemv_t<EPI_RESID, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
 }
@@ -174,11 +191,17 @@ hipError_t launch_w13(llmk_ctx* c, int l) {
     return launch_gemv_t<EPI_SWIGLU, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
 }
 hipError_t launch_w2(llmk_ctx* c, int l) {
+    if (c->tp_size > 1 || c->comm) {
+        GemvArgs a = base_args(c, LLMK_W2, l, c->d_hb, nullptr, c->d_part);
+        return launch_gemv_t<EPI_STORE, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
+    }
     GemvArgs a = base_args(c, LLMK_W2, l, c->d_hb, nullptr, c->d_x);
     return launch_gemv_t<EPI_RESID, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
 }
 hipError_t launch_cls(llmk_ctx* c) {
-    GemvArgs a = base_args(c, LLMK_WCLS, 0, c->d_x, (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data, c->d_logits);
+    // vocab-parallel: this rank's V/P rows land in its slice of the full logits vector
+    GemvArgs a = base_args(c, LLMK_WCLS, 0, c->d_x, (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data,
+                           c->d_logits + (size_t)c->tp_rank * c->Vl);
     return launch_gemv_t<EPI_STORE, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
 }
 hipError_t launch_embed(llmk_ctx* c) {
@@ -264,6 +287,39 @@ hipError_t enqueue_tail(llmk_ctx* c, bool greedy) {
     return hipSuccess;
 }
 
+__global__ void add_kernel(float* __restrict__ x, const float* __restrict__ part, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += part[i];
+}
+hipError_t launch_add_partial(llmk_ctx* c) {   // x += all-reduced partial (the residual of wo / w2)
+    hipLaunchKernelGGL(add_kernel, dim3((c->E + 255) / 256), dim3(256), 0, c->stream, c->d_x, c->d_part, c->E);
+    return hipGetLastError();
+}
+
+// Tensor-parallel token pass over RCCL: two all-reduces of E floats per layer (ring order is fixed by the
+// communicator, so every rank sees bit-identical sums), one all-gather of the logits.
+int enqueue_token_tp(llmk_ctx* c) {
+    if (!c->comm) return LLMK_E_COMM;
+#define NC(expr) do { if ((expr) != ncclSuccess) return LLMK_E_COMM; } while (0)
+    HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_embed(c));
+    for (int l = 0; l < c->L; ++l) {
+        HIPCHK(launch_qkv(c, l));
+        HIPCHK(launch_attn(c, l));
+        HIPCHK(launch_wo(c, l));
+        NC(ncclAllReduce(c->d_part, c->d_part, c->E, ncclFloat, ncclSum, c->comm, c->stream));
+        HIPCHK(launch_add_partial(c));
+        HIPCHK(launch_w13(c, l));
+        HIPCHK(launch_w2(c, l));
+        NC(ncclAllReduce(c->d_part, c->d_part, c->E, ncclFloat, ncclSum, c->comm, c->stream));
+        HIPCHK(launch_add_partial(c));
+    }
+    HIPCHK(launch_cls(c));
+    NC(ncclAllGather(c->d_logits + (size_t)c->tp_rank * c->Vl, c->d_logits, c->Vl, ncclFloat, c->comm, c->stream));
+#undef NC
+    return LLMK_OK;
+}
+
 // Enqueue one token pass on c->stream.  timed: bracket the reference's five sections with events.
 hipError_t enqueue_token(llmk_ctx* c, bool greedy, bool timed) {
     HIPRET(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -332,7 +388,11 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
     c->h_tokpos[1] = pos;
     c->h_tokpos[2] += 1;  // token serial: makes every exchange epoch of this pass unique
     const bool timed = (c->cfg.flags & LLMK_FLAG_TIMINGS) != 0;
-    if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
+    if (c->tp_size > 1 || c->comm) {   // tensor-parallel: eager launches with RCCL collectives in between
+        rc = enqueue_token_tp(c);
+        if (rc) return rc;
+        HIPCHK(enqueue_tail(c, greedy));
+    } else if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
         HIPCHK(enqueue_token(c, greedy, timed));
     } else {
         hipGraphExec_t* g = greedy ? &c->graph_greedy : &c->graph_logits;
@@ -367,14 +427,18 @@ const char* llmk_strerror(int code) {
         case LLMK_E_NODEVICE: return "llmk: no usable HIP device (there is no CPU fallback)";
         case LLMK_E_NOMEM: return "llmk: out of memory";
         case LLMK_E_TIMEOUT: return "llmk: device-side exchange timed out (persistent kernel not fully resident?)";
+        case LLMK_E_COMM: return "llmk: tensor-parallel communicator missing or RCCL error";
     }
     if (code >= LLMK_E_HIP) return hipGetErrorString((hipError_t)(code - LLMK_E_HIP));
     return "llmk: unknown error";
 }
 
-int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
+int llmk_create(const llmk_config* cfg, llmk_ctx** out) { return llmk_create_tp(cfg, 0, 1, out); }
+
+int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** out) {
     if (!cfg || !out) return LLMK_E_ARG;
     *out = nullptr;
+    if (tp_size < 1 || tp_rank < 0 || tp_rank >= tp_size) return LLMK_E_ARG;
     const int E = cfg->emb_dim, H = cfg->hidden_dim, L = cfg->n_layers, nh = cfg->n_heads, nkv = cfg->n_kv_heads;
     const int V = cfg->vocab_size, S = cfg->seq_len;
     if (E <= 0 || H <= 0 || L <= 0 || nh <= 0 || nkv <= 0 || V <= 0 || S <= 0) return LLMK_E_SHAPE;
@@ -382,6 +446,10 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
     const int hs = E / nh;
     if (hs != 16 && hs != 32 && hs != 64 && hs != 128) return LLMK_E_SHAPE;
     if (E % 32 || H % 32 || (V & 1)) return LLMK_E_SHAPE;  // 16-byte vectors, q4_0 blocks, row pairs
+    // tensor parallelism splits by kv head (each rank: nkv/P kv heads + their nh/P query heads), hidden
+    // rows and vocab rows; every local extent must keep the alignment rules above
+    const int kalign = cfg->weight_type == LLMK_TYPE_Q4_0 ? 32 : cfg->weight_type == LLMK_TYPE_F16 ? 8 : 4;
+    if (nkv % tp_size || H % tp_size || V % tp_size || (H / tp_size) % kalign || ((V / tp_size) & 1)) return LLMK_E_SHAPE;
     if (cfg->weight_type != LLMK_TYPE_F32 && cfg->weight_type != LLMK_TYPE_F16 && cfg->weight_type != LLMK_TYPE_Q4_0)
         return LLMK_E_TYPE;
     int ndev = 0;
@@ -394,20 +462,29 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
     c->cfg = *cfg;
     c->E = E; c->H = H; c->L = L; c->nh = nh; c->nkv = nkv; c->V = V; c->S = S;
     c->hs = hs; c->KV = nkv * hs; c->kv_mul = nh / nkv;
+    c->tp_rank = tp_rank; c->tp_size = tp_size;
+    c->nhl = nh / tp_size; c->Eq = c->nhl * hs; c->KVl = (nkv / tp_size) * hs; c->Hl = H / tp_size; c->Vl = V / tp_size;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
         c->n_cu = prop.multiProcessorCount;
 
     const int KV = c->KV;
-    c->desc[LLMK_TOKEN_EMBEDDING_TABLE] = {false, V, E, false};
-    c->desc[LLMK_RMS_ATT_WEIGHT] = {true, 1, E, false};
-    c->desc[LLMK_RMS_FFN_WEIGHT] = {true, 1, E, false};
-    c->desc[LLMK_WQKV] = {true, E + 2 * KV, E, true};
-    c->desc[LLMK_WO] = {true, E, E, true};
-    c->desc[LLMK_W13] = {true, 2 * H, E, true};
-    c->desc[LLMK_W2] = {true, E, H, true};
-    c->desc[LLMK_RMS_FINAL_WEIGHT] = {false, 1, E, false};
-    c->desc[LLMK_WCLS] = {false, V, E, true};
+    c->gdesc[LLMK_TOKEN_EMBEDDING_TABLE] = {false, V, E, false};
+    c->gdesc[LLMK_RMS_ATT_WEIGHT] = {true, 1, E, false};
+    c->gdesc[LLMK_RMS_FFN_WEIGHT] = {true, 1, E, false};
+    c->gdesc[LLMK_WQKV] = {true, E + 2 * KV, E, true};
+    c->gdesc[LLMK_WO] = {true, E, E, true};
+    c->gdesc[LLMK_W13] = {true, 2 * H, E, true};
+    c->gdesc[LLMK_W2] = {true, E, H, true};
+    c->gdesc[LLMK_RMS_FINAL_WEIGHT] = {false, 1, E, false};
+    c->gdesc[LLMK_WCLS] = {false, V, E, true};
+    for (int i = 0; i < LLMK_N_TENSORS; ++i) c->desc[i] = c->gdesc[i];
+    // what THIS rank keeps: column-parallel qkv / w1|w3 / classifier (rows), row-parallel wo / w2 (input slice)
+    c->desc[LLMK_WQKV] = {true, c->Eq + 2 * c->KVl, E, true};
+    c->desc[LLMK_WO] = {true, E, c->Eq, true};
+    c->desc[LLMK_W13] = {true, 2 * c->Hl, E, true};
+    c->desc[LLMK_W2] = {true, E, c->Hl, true};
+    c->desc[LLMK_WCLS] = {false, c->Vl, E, true};
 
     int rc = LLMK_OK;
 #define CK(expr)                                                        \
@@ -430,13 +507,14 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
             CK(hipMalloc(&t.data, rows * t.row_bytes));
         }
     }
-    const size_t kvn = (size_t)L * S * KV;
+    const size_t kvn = (size_t)L * S * c->KVl;
     CK(hipMalloc(&c->d_kc, kvn * sizeof(float)));
     CK(hipMalloc(&c->d_vc, kvn * sizeof(float)));
     CK(hipMalloc(&c->d_x, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_q, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_xb, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_hb, (size_t)H * sizeof(float)));
+    CK(hipMalloc(&c->d_part, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_logits, ((size_t)V + 4) * sizeof(float)));  // [V] = sticky device error word
     CK(hipMalloc(&c->d_rope, (size_t)(hs / 2) * sizeof(float)));
     CK(hipMalloc(&c->d_tokpos, 4 * sizeof(int)));
@@ -448,7 +526,7 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
     for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));
     // The whole-token persistent kernel serves the shapes it is instantiated for, on a full 256-CU part
     if (rc == LLMK_OK && !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && cfg->weight_type == LLMK_TYPE_F32 &&
-        c->n_cu == TK_NCU) {
+        c->n_cu == TK_NCU && tp_size == 1) {
         rc = tk_setup<TkTinyLlama>(c, 1);
         if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
     }
@@ -476,28 +554,24 @@ int llmk_create(const llmk_config* cfg, llmk_ctx** out) {
     return LLMK_OK;
 }
 
-int llmk_upload_rows(llmk_ctx* c, int tid, int layer, int row_offset, int rows, const void* host, size_t nbytes,
-                     int ggml_type) {
-    if (!c || !host || tid < 0 || tid >= LLMK_N_TENSORS) return LLMK_E_ARG;
+// Copy `nrows` rows of a HOST tensor (row pitch `spitch` bytes in `type` encoding; for each row only the
+// bytes [col_off, col_off + col_bytes) -- a contraction slice for the row-parallel wo / w2) into local rows
+// dst_row0.. of layer `layer` of tensor `tid`.  q4_0 is re-packed (nibble plane + scale plane) on the way.
+static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows, const uint8_t* src, size_t spitch,
+                        size_t col_off, size_t col_bytes) {
     const TensorDesc& d = c->desc[tid];
     DevTensor& t = c->t[tid];
-    const int nl = d.layered ? c->L : 1;
-    if (layer < 0 || layer >= nl || row_offset < 0 || rows <= 0 || row_offset + rows > d.rows) return LLMK_E_ARG;
-    if (ggml_type != t.type) return LLMK_E_TYPE;
-    if (nbytes != (size_t)rows * row_bytes_for(ggml_type, d.K)) return LLMK_E_SIZE;
-    HIPCHK(hipSetDevice(c->cfg.device));
-    const size_t first_row = (size_t)layer * d.rows + row_offset;
+    const size_t first_row = (size_t)layer * d.rows + dst_row0;
     if (t.type == LLMK_TYPE_Q4_0) {
-        // stage raw ggml blocks, then split them into the 16-byte-aligned nibble plane + scale plane
-        const size_t blocks_per_row = (size_t)d.K / 32;
-        const size_t chunk_rows_max = ((size_t)256 << 20) / (blocks_per_row * 18) + 1;
+        const size_t blocks_per_row = col_bytes / 18;
+        const size_t chunk_rows_max = ((size_t)256 << 20) / col_bytes + 1;
         uint8_t* tmp = nullptr;
-        const size_t cr0 = (size_t)rows < chunk_rows_max ? (size_t)rows : chunk_rows_max;
-        HIPCHK(hipMalloc(&tmp, cr0 * blocks_per_row * 18));
-        for (size_t r = 0; r < (size_t)rows; r += cr0) {
-            const size_t cr = ((size_t)rows - r) < cr0 ? ((size_t)rows - r) : cr0;
+        const size_t cr0 = (size_t)nrows < chunk_rows_max ? (size_t)nrows : chunk_rows_max;
+        HIPCHK(hipMalloc(&tmp, cr0 * col_bytes));
+        for (size_t r = 0; r < (size_t)nrows; r += cr0) {
+            const size_t cr = ((size_t)nrows - r) < cr0 ? ((size_t)nrows - r) : cr0;
             const size_t nb = cr * blocks_per_row;
-            hipError_t e = hipMemcpy(tmp, (const uint8_t*)host + r * blocks_per_row * 18, nb * 18, hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpy2D(tmp, col_bytes, src + r * spitch + col_off, spitch, col_bytes, cr, hipMemcpyHostToDevice);
             if (e == hipSuccess) {
                 uint4* nib = (uint4*)((char*)t.data + (first_row + r) * t.row_bytes);
                 __half* sc = (__half*)((char*)t.scales + (first_row + r) * t.scale_row_bytes);
@@ -509,24 +583,70 @@ int llmk_upload_rows(llmk_ctx* c, int tid, int layer, int row_offset, int rows, 
         }
         HIPCHK(hipFree(tmp));
     } else {
-        HIPCHK(hipMemcpy((char*)t.data + first_row * t.row_bytes, host, nbytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy2D((char*)t.data + first_row * t.row_bytes, t.row_bytes, src + col_off, spitch, col_bytes, nrows,
+                           hipMemcpyHostToDevice));
     }
-    t.rows_uploaded += (size_t)rows;
-    if (t.rows_uploaded >= (size_t)d.rows * nl) t.uploaded = true;
+    t.rows_uploaded += (size_t)nrows;
+    if (t.rows_uploaded >= (size_t)d.rows * (d.layered ? c->L : 1)) t.uploaded = true;
     return LLMK_OK;
+}
+
+// One FULL layer of a full (unsharded) host tensor -> this rank's shard of it.
+static int upload_layer_sharded(llmk_ctx* c, int tid, int layer, const uint8_t* src, int type) {
+    const TensorDesc& g = c->gdesc[tid];
+    const size_t pitch = row_bytes_for(type, g.K);
+    const int r = c->tp_rank, E = c->E, KV = c->KV, H = c->H;
+    int rc = LLMK_OK;
+    switch (tid) {
+        case LLMK_WQKV:  // rows: this rank's query heads, then its kv heads' K rows, then their V rows
+            rc = upload_block(c, tid, layer, 0, c->Eq, src + (size_t)(r * c->Eq) * pitch, pitch, 0, pitch);
+            if (!rc) rc = upload_block(c, tid, layer, c->Eq, c->KVl, src + (size_t)(E + r * c->KVl) * pitch, pitch, 0, pitch);
+            if (!rc) rc = upload_block(c, tid, layer, c->Eq + c->KVl, c->KVl, src + (size_t)(E + KV + r * c->KVl) * pitch, pitch, 0, pitch);
+            return rc;
+        case LLMK_WO:    // all E rows, the input columns of this rank's heads
+            return upload_block(c, tid, layer, 0, E, src, pitch, row_bytes_for(type, r * c->Eq), row_bytes_for(type, c->Eq));
+        case LLMK_W13:   // gate rows then up rows of this rank's hidden slice
+            rc = upload_block(c, tid, layer, 0, c->Hl, src + (size_t)(r * c->Hl) * pitch, pitch, 0, pitch);
+            if (!rc) rc = upload_block(c, tid, layer, c->Hl, c->Hl, src + (size_t)(H + r * c->Hl) * pitch, pitch, 0, pitch);
+            return rc;
+        case LLMK_W2:    // all E rows, the input columns of this rank's hidden slice
+            return upload_block(c, tid, layer, 0, E, src, pitch, row_bytes_for(type, r * c->Hl), row_bytes_for(type, c->Hl));
+        case LLMK_WCLS:
+            return upload_block(c, tid, layer, 0, c->Vl, src + (size_t)(r * c->Vl) * pitch, pitch, 0, pitch);
+        default:         // replicated: embedding table and norm gains
+            return upload_block(c, tid, layer, 0, g.rows, src, pitch, 0, pitch);
+    }
+}
+
+int llmk_upload_rows(llmk_ctx* c, int tid, int layer, int row_offset, int rows, const void* host, size_t nbytes,
+                     int ggml_type) {
+    if (!c || !host || tid < 0 || tid >= LLMK_N_TENSORS) return LLMK_E_ARG;
+    const TensorDesc& g = c->gdesc[tid];
+    DevTensor& t = c->t[tid];
+    const int nl = g.layered ? c->L : 1;
+    if (layer < 0 || layer >= nl || row_offset < 0 || rows <= 0 || row_offset + rows > g.rows) return LLMK_E_ARG;
+    if (ggml_type != t.type) return LLMK_E_TYPE;
+    if (nbytes != (size_t)rows * row_bytes_for(ggml_type, g.K)) return LLMK_E_SIZE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (c->tp_size > 1) {   // a shard is cut from a whole layer: partial-row uploads are a single-GPU convenience
+        if (row_offset != 0 || rows != g.rows) return LLMK_E_ARG;
+        return upload_layer_sharded(c, tid, layer, (const uint8_t*)host, ggml_type);
+    }
+    const size_t pitch = row_bytes_for(ggml_type, g.K);
+    return upload_block(c, tid, layer, row_offset, rows, (const uint8_t*)host, pitch, 0, pitch);
 }
 
 int llmk_upload(llmk_ctx* c, int tid, const void* host, size_t nbytes, int ggml_type) {
     if (!c || !host || tid < 0 || tid >= LLMK_N_TENSORS) return LLMK_E_ARG;
-    const TensorDesc& d = c->desc[tid];
-    const int nl = d.layered ? c->L : 1;
+    const TensorDesc& g = c->gdesc[tid];
+    const int nl = g.layered ? c->L : 1;
     if (ggml_type != c->t[tid].type) return LLMK_E_TYPE;
-    const size_t per_layer = (size_t)d.rows * row_bytes_for(ggml_type, d.K);
+    const size_t per_layer = (size_t)g.rows * row_bytes_for(ggml_type, g.K);
     if (nbytes != per_layer * nl) return LLMK_E_SIZE;
     c->t[tid].rows_uploaded = 0;
     c->t[tid].uploaded = false;
     for (int l = 0; l < nl; ++l) {
-        int rc = llmk_upload_rows(c, tid, l, 0, d.rows, (const char*)host + (size_t)l * per_layer, per_layer, ggml_type);
+        int rc = llmk_upload_rows(c, tid, l, 0, g.rows, (const char*)host + (size_t)l * per_layer, per_layer, ggml_type);
         if (rc) return rc;
     }
     return LLMK_OK;
@@ -558,7 +678,7 @@ int llmk_forward_greedy(llmk_ctx* c, int token, int pos, int* next_token) {
 int llmk_reset(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
-    const size_t kvn = (size_t)c->L * c->S * c->KV * sizeof(float);
+    const size_t kvn = (size_t)c->L * c->S * c->KVl * sizeof(float);
     HIPCHK(hipMemsetAsync(c->d_kc, 0, kvn, c->stream));
     HIPCHK(hipMemsetAsync(c->d_vc, 0, kvn, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -633,14 +753,14 @@ int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
     int len = 0;
     switch (which) {
         case 0: src = c->d_x; len = c->E; break;
-        case 1: src = c->d_q; len = c->E; break;
-        case 2: src = c->d_xb; len = c->E; break;
-        case 3: src = c->d_hb; len = c->H; break;
+        case 1: src = c->d_q; len = c->Eq; break;
+        case 2: src = c->d_xb; len = c->Eq; break;
+        case 3: src = c->d_hb; len = c->Hl; break;
         case 4:
         case 5:
             if (layer < 0 || layer >= c->L || pos < 1 || pos > c->S) return LLMK_E_ARG;
-            src = (which == 4 ? c->d_kc : c->d_vc) + ((size_t)layer * c->S + (pos - 1)) * c->KV;
-            len = c->KV;
+            src = (which == 4 ? c->d_kc : c->d_vc) + ((size_t)layer * c->S + (pos - 1)) * c->KVl;
+            len = c->KVl;
             break;
         case 6:  // debug: raw trace stamps reinterpret as floats (2 per stamp)
             if (!c->d_trace) return LLMK_E_ARG;
@@ -654,10 +774,84 @@ int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
     return LLMK_OK;
 }
 
+int llmk_tp_unique_id(char id_out[128]) {
+    if (!id_out) return LLMK_E_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return LLMK_E_COMM;
+    memcpy(id_out, &id, sizeof(id));
+    return LLMK_OK;
+}
+
+int llmk_tp_init_comm(llmk_ctx* c, const char id_in[128]) {
+    if (!c || !id_in || c->comm) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof(id));
+    if (ncclCommInitRank(&c->comm, c->tp_size, id, c->tp_rank) != ncclSuccess) { c->comm = nullptr; return LLMK_E_COMM; }
+    return LLMK_OK;
+}
+
+int llmk_tp_begin(llmk_ctx* c, int token, int pos) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (token < 1 || token > c->V || pos < 1 || pos > c->S) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    c->h_tokpos[0] = token - 1;
+    c->h_tokpos[1] = pos;
+    c->h_tokpos[2] += 1;
+    HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_embed(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LLMK_OK;
+}
+
+int llmk_tp_segment(llmk_ctx* c, int seg, int layer) {
+    int rc = check_ready(c);
+    if (rc) return rc;
+    if (seg < 0 || seg > 2 || layer < 0 || layer >= c->L) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (seg == 0) {
+        if (layer > 0) HIPCHK(launch_add_partial(c));
+        HIPCHK(launch_qkv(c, layer));
+        HIPCHK(launch_attn(c, layer));
+        HIPCHK(launch_wo(c, layer));
+    } else if (seg == 1) {
+        HIPCHK(launch_add_partial(c));
+        HIPCHK(launch_w13(c, layer));
+        HIPCHK(launch_w2(c, layer));
+    } else {
+        HIPCHK(launch_add_partial(c));
+        HIPCHK(launch_cls(c));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LLMK_OK;
+}
+
+int llmk_tp_read_partial(llmk_ctx* c, float* out) {
+    if (!c || !out) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpy(out, c->d_part, (size_t)c->E * sizeof(float), hipMemcpyDeviceToHost));
+    return LLMK_OK;
+}
+int llmk_tp_write_partial(llmk_ctx* c, const float* in) {
+    if (!c || !in) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpy(c->d_part, in, (size_t)c->E * sizeof(float), hipMemcpyHostToDevice));
+    return LLMK_OK;
+}
+int llmk_tp_read_logits(llmk_ctx* c, float* out_slice) {
+    if (!c || !out_slice) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipMemcpy(out_slice, c->d_logits + (size_t)c->tp_rank * c->Vl, (size_t)c->Vl * sizeof(float), hipMemcpyDeviceToHost));
+    return LLMK_OK;
+}
+
 int llmk_destroy(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
     if (c->graph_logits) hipGraphExecDestroy(c->graph_logits);
     if (c->graph_greedy) hipGraphExecDestroy(c->graph_greedy);
     for (int i = 0; i < LLMK_N_TENSORS; ++i) {
@@ -665,7 +859,7 @@ int llmk_destroy(llmk_ctx* c) {
         if (c->t[i].scales) hipFree(c->t[i].scales);
     }
     void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,
-                   c->d_gran, c->d_zeros, c->d_trace};
+                   c->d_gran, c->d_zeros, c->d_trace, c->d_part};
     for (void* p : dev)
         if (p) hipFree(p);
     if (c->h_tokpos) hipHostFree(c->h_tokpos);

@@ -20,9 +20,10 @@ TENSOR_IDS = {
 }
 FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 # every symbol include/llmk.h declares
-SYMBOLS = ["llmk_create", "llmk_upload", "llmk_upload_rows", "llmk_set_rope_freqs", "llmk_forward",
-           "llmk_forward_greedy", "llmk_reset", "llmk_timings", "llmk_time_kernel", "llmk_peek", "llmk_destroy",
-           "llmk_strerror", "llmk_version"]
+SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_begin", "llmk_tp_segment",
+           "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
+           "llmk_set_rope_freqs", "llmk_forward", "llmk_forward_greedy", "llmk_reset", "llmk_timings",
+           "llmk_time_kernel", "llmk_peek", "llmk_destroy", "llmk_strerror", "llmk_version"]
 
 
 class LlmkError(RuntimeError):
@@ -53,6 +54,14 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, ci, cf = C.c_void_p, C.c_int, C.POINTER(C.c_float)
         L.llmk_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.llmk_create_tp.argtypes = [C.POINTER(Config), ci, ci, C.POINTER(vp)]
+        L.llmk_tp_unique_id.argtypes = [C.c_char_p]
+        L.llmk_tp_init_comm.argtypes = [vp, C.c_char_p]
+        L.llmk_tp_begin.argtypes = [vp, ci, ci]
+        L.llmk_tp_segment.argtypes = [vp, ci, ci]
+        L.llmk_tp_read_partial.argtypes = [vp, cf]
+        L.llmk_tp_write_partial.argtypes = [vp, cf]
+        L.llmk_tp_read_logits.argtypes = [vp, cf]
         L.llmk_upload.argtypes = [vp, ci, vp, C.c_size_t, ci]
         L.llmk_upload_rows.argtypes = [vp, ci, ci, ci, ci, vp, C.c_size_t, ci]
         L.llmk_set_rope_freqs.argtypes = [vp, cf, ci]
@@ -81,14 +90,16 @@ def _ck(rc):
 class Llmk:
     """One sequence on one GPU. `fw` is tools.gguf.FusedWeights (weight_module layout)."""
 
-    def __init__(self, fw, device: int = 0, flags: int = 0, seq_len: int | None = None):
+    def __init__(self, fw, device: int = 0, flags: int = 0, seq_len: int | None = None, tp_rank: int = 0,
+                 tp_size: int = 1):
         s = fw.shape
         self.shape = s
         self.V = s.vocab_size
+        self.tp_rank, self.tp_size = tp_rank, tp_size
         cfg = Config(s.emb_dim, s.hidden_dim, s.n_layers, s.n_heads, s.n_kv_heads, s.vocab_size,
                      seq_len or s.seq_len, fw.ggml_type, device, flags)
         self._h = C.c_void_p()
-        _ck(lib().llmk_create(C.byref(cfg), C.byref(self._h)))
+        _ck(lib().llmk_create_tp(C.byref(cfg), tp_rank, tp_size, C.byref(self._h)))
         for name, tid in TENSOR_IDS.items():
             a = np.ascontiguousarray(getattr(fw, name))
             is_mat = name in ("wqkv", "wo", "w13", "w2", "wcls")
@@ -136,6 +147,36 @@ class Llmk:
             token = p[pos - 1] if pos <= len(p) else nxt
             toks[pos - 1] = token
         return toks, logits
+
+    # ---- tensor parallel ------------------------------------------------------------------------
+    @staticmethod
+    def tp_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _ck(lib().llmk_tp_unique_id(buf))
+        return buf.raw
+
+    def tp_init_comm(self, uid: bytes):
+        _ck(lib().llmk_tp_init_comm(self._h, C.create_string_buffer(uid, 128)))
+
+    def tp_begin(self, token: int, pos: int):
+        _ck(lib().llmk_tp_begin(self._h, token, pos))
+
+    def tp_segment(self, seg: int, layer: int = 0):
+        _ck(lib().llmk_tp_segment(self._h, seg, layer))
+
+    def tp_read_partial(self) -> np.ndarray:
+        out = np.empty(self.shape.emb_dim, np.float32)
+        _ck(lib().llmk_tp_read_partial(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def tp_write_partial(self, v: np.ndarray):
+        v = np.ascontiguousarray(v, np.float32)
+        _ck(lib().llmk_tp_write_partial(self._h, v.ctypes.data_as(C.POINTER(C.c_float))))
+
+    def tp_read_logits(self) -> np.ndarray:
+        out = np.empty(self.V // self.tp_size, np.float32)
+        _ck(lib().llmk_tp_read_logits(self._h, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def reset(self):
         _ck(lib().llmk_reset(self._h))

@@ -198,6 +198,31 @@ def decode(raw: np.ndarray, ggml_type: int, cols: int) -> np.ndarray:
     raise ValueError(ggml_type)
 
 
+def synth_q4_rows(seed: int, stream: int, rows: int, K: int) -> np.ndarray:
+    """Synthetic q4_0 rows generated DIRECTLY in the block format (for the 7B/70B shapes, where
+    materialising f32 weights first would need hundreds of GB): nibbles from the integer hash, one f16
+    scale per block chosen so the dequantised weights have variance 1/K.  uint8 [rows, K/32*18]."""
+    nb = rows * (K // QK4_0)
+    out = np.empty((nb, Q4_0_BLOCK_BYTES), np.uint8)
+    base = np.uint64((seed * 0x9E3779B1 + stream * 0x85EBCA77) & 0xFFFFFFFF) << np.uint64(32)
+    d = np.float16(np.sqrt(1.0 / K / 21.25))
+    out[:, 0:2] = np.frombuffer(d.tobytes(), np.uint8)
+    chunk = 1 << 20
+    def fill(s0):
+        e0 = min(nb, s0 + chunk)
+        idx = (np.arange(s0 * 2, e0 * 2, dtype=np.uint64) + base)
+        out[s0:e0, 2:] = _splitmix64(idx).view(np.uint8).reshape(e0 - s0, 16)
+    spans = list(range(0, nb, chunk))
+    if len(spans) <= 2:
+        for s0 in spans:
+            fill(s0)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(fill, spans))
+    return out.reshape(rows, K // QK4_0 * Q4_0_BLOCK_BYTES)
+
+
 # ----------------------------------------------------------------------------------------------
 # fused in-memory layout == weight_module.f90:13-26 (Fortran (in,rows,L) == C [L][rows][in])
 # ----------------------------------------------------------------------------------------------
