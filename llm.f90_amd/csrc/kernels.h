@@ -350,6 +350,153 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// q4_0 GEMV (ggml block_q4_0: 32 weights = f16 d + 16 nibble bytes; device layout: nibble plane + scale
+// plane, see llmk_upload).  18 B per 32 weights makes this kernel ALU/LDS-heavy rather than purely
+// HBM-bound, so it is organised around reuse:
+//   * a wave owns NP row pairs (8 rows): the 32 activations of a block are read from LDS ONCE (8
+//     ds_read_b128, transposed staging -> lane-contiguous) and used for all 8 rows;
+//   * nibbles are widened with v_cvt_f32_ubyteN on (q & 0x0F0F0F0F) / ((q >> 4) & 0x0F0F0F0F): no per-weight
+//     shift/mask/subtract; the "-8" of (nibble-8)*d is applied per block through the staged block sums
+//     of x:  sum_i (n_i-8) d x_i = d (sum_i n_i x_i - 8 sum_i x_i);
+//   * x is staged once per 32 rows (4 waves x 8) instead of once per 8.
+// Same pairing rules and epilogues as gemv_kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float q4_dword_dot(unsigned q, const float4& xl, const float4& xh, float acc) {
+    const unsigned lo = q & 0x0F0F0F0Fu, hi = (q >> 4) & 0x0F0F0F0Fu;   // bytes = nibbles of elems 4i.. / 16+4i..
+    acc = fmaf((float)(lo & 0xFF), xl.x, acc);
+    acc = fmaf((float)((lo >> 8) & 0xFF), xl.y, acc);
+    acc = fmaf((float)((lo >> 16) & 0xFF), xl.z, acc);
+    acc = fmaf((float)(lo >> 24), xl.w, acc);
+    acc = fmaf((float)(hi & 0xFF), xh.x, acc);
+    acc = fmaf((float)((hi >> 8) & 0xFF), xh.y, acc);
+    acc = fmaf((float)((hi >> 16) & 0xFF), xh.z, acc);
+    acc = fmaf((float)(hi >> 24), xh.w, acc);
+    return acc;
+}
+
+template <int EPI, bool NORM, int NP>
+__global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* red = reinterpret_cast<float*>(smem_raw);          // [4]
+    float4* xs = reinterpret_cast<float4*>(smem_raw + 16);    // [8][nblk] float4 (transposed x)
+    constexpr int NR = 2 * NP;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int K = a.K, nx4 = K >> 2, nblk = K >> 5;
+    float* xsum = reinterpret_cast<float*>(xs + 8 * nblk);    // [nblk] block sums of the staged x
+    const int npairs = (EPI == EPI_SWIGLU) ? a.H : (a.rows >> 1);
+    const int g0 = (blockIdx.x * GEMV_WAVES + wid) * NP;      // first pair of this wave
+    const uint4* Wn = reinterpret_cast<const uint4*>(a.W);
+    const __half* Sc = reinterpret_cast<const __half*>(a.W_scales);
+
+    int rows[NR];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int g = min(g0 + j, npairs - 1);                // clamped: past-the-end pairs recompute the last one
+        rows[2 * j] = (EPI == EPI_SWIGLU) ? g : 2 * g;
+        rows[2 * j + 1] = (EPI == EPI_SWIGLU) ? g + a.H : 2 * g + 1;
+    }
+    // first block column of all 8 rows is requested before x is staged
+    uint4 wq[NR];
+    __half wd[NR];
+    {
+        const int b = min(lane, nblk - 1);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            wq[i] = ldg_nt(Wn + (size_t)rows[i] * nblk + b);
+            wd[i] = Sc[(size_t)rows[i] * nblk + b];
+        }
+    }
+    // ---- stage x: transposed float4 groups + per-block sums ------------------------------------
+    {
+        const float4* xg = reinterpret_cast<const float4*>(a.x);
+        float ss = 0.f;
+        for (int i = tid; i < nx4; i += GEMV_THREADS) {
+            const float4 v = xg[i];
+            if (NORM) ss = dot4(v, v, ss);
+            xs[(i & 7) * nblk + (i >> 3)] = v;
+        }
+        if (NORM) {
+            ss = wave_sum(ss);
+            if (lane == 0) red[wid] = ss;
+            __syncthreads();
+            ss = red[0] + red[1] + red[2] + red[3];
+            const float xn = sqrtf(ss / (float)K + 1e-5f);
+            const float4* wg = reinterpret_cast<const float4*>(a.norm_w);
+            for (int i = tid; i < nx4; i += GEMV_THREADS) {
+                const int li = (i & 7) * nblk + (i >> 3);
+                float4 v = xs[li];
+                const float4 nw = wg[i];
+                v.x = v.x * nw.x / xn;
+                v.y = v.y * nw.y / xn;
+                v.z = v.z * nw.z / xn;
+                v.w = v.w * nw.w / xn;
+                xs[li] = v;
+            }
+        }
+        __syncthreads();
+        for (int b = tid; b < nblk; b += GEMV_THREADS) {
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 v = xs[m * nblk + b];
+                t += (v.x + v.y) + (v.z + v.w);
+            }
+            xsum[b] = t;
+        }
+        __syncthreads();
+    }
+
+    float acc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[i] = 0.f;
+    for (int b0 = 0; b0 < nblk; b0 += WAVE) {
+        const int bl = b0 + lane;
+        const bool live = bl < nblk;
+        const int b = live ? bl : nblk - 1;
+        // next column's loads go out before this column's math
+        uint4 nq[NR];
+        __half nd[NR];
+        const bool more = b0 + WAVE < nblk;   // wave-uniform
+        if (more) {
+            const int nb = min(bl + WAVE, nblk - 1);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                nq[i] = ldg_nt(Wn + (size_t)rows[i] * nblk + nb);
+                nd[i] = Sc[(size_t)rows[i] * nblk + nb];
+            }
+        }
+        float4 xl[4], xh[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            xl[m] = xs[m * nblk + b];
+            xh[m] = xs[(4 + m) * nblk + b];
+        }
+        const float xs8 = 8.0f * xsum[b];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            float t = 0.f;
+            t = q4_dword_dot(wq[i].x, xl[0], xh[0], t);
+            t = q4_dword_dot(wq[i].y, xl[1], xh[1], t);
+            t = q4_dword_dot(wq[i].z, xl[2], xh[2], t);
+            t = q4_dword_dot(wq[i].w, xl[3], xh[3], t);
+            const float d = live ? __half2float(wd[i]) : 0.f;
+            acc[i] = fmaf(d, t - xs8, acc[i]);
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { wq[i] = nq[i]; wd[i] = nd[i]; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[i] = wave_sum(acc[i]);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            if (g0 + j < npairs) gemv_epilogue2<EPI>(a, g0 + j, rows[2 * j], rows[2 * j + 1], acc[2 * j], acc[2 * j + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Attention for one query head per block (llama2.f90:572-598 + softmax :468-478).
 // GQA: head h reads kv head h/kv_mul (the intended semantics of the slice at :581/:591).
 // Decode attention is a latency problem, not a bandwidth one (pos*512 B per head): every K (and

@@ -111,7 +111,7 @@ hipError_t launch_gemv(hipStream_t st, const GemvArgs& a) {
 //   f16  K=2048: 2 x 4;                                      K=5632: 1 x 11
 //   q4_0 K=4096: 2 x 2
 template <int EPI, bool NORM>
-hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int /*n_cu*/) {
+hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
     constexpr bool single_ok = (EPI == EPI_STORE || EPI == EPI_RESID) && !NORM;
     switch (wt) {
         case LLMK_TYPE_F32: {
@@ -126,7 +126,22 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int /*n_cu*/
                 if (ncol % 11 == 0) return launch_gemv<WT_F16, EPI, NORM, 1, 11>(st, a);
             return launch_gemv<WT_F16, EPI, NORM, 2, 4>(st, a);
         }
-        default: return launch_gemv<WT_Q4_0, EPI, NORM, 2, 2>(st, a);
+        default: {   // q4_0: dedicated kernel, up to 8 rows per wave (kernels.h); fewer when the matrix is
+                     // too small to give every CU at least two workgroups that way
+            const int npairs = (EPI == EPI_SWIGLU) ? a.H : a.rows / 2;
+            const size_t smem = 16 + (size_t)a.K * sizeof(float) + (size_t)(a.K / 32) * sizeof(float);
+            const int want = 2 * n_cu;
+#define Q4_LAUNCH(NP_)                                                                                           \
+            do {                                                                                                 \
+                const int blocks = (npairs + GEMV_WAVES * NP_ - 1) / (GEMV_WAVES * NP_);                         \
+                hipLaunchKernelGGL((gemv_q4_kernel<EPI, NORM, NP_>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a); \
+            } while (0)
+            if (npairs / (GEMV_WAVES * 4) >= want) Q4_LAUNCH(4);
+            else if (npairs / (GEMV_WAVES * 2) >= want) Q4_LAUNCH(2);
+            else Q4_LAUNCH(1);
+#undef Q4_LAUNCH
+            return hipGetLastError();
+        }
     }
 }
 
