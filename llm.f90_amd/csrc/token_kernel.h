@@ -433,7 +433,9 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     const int tok = a.tokpos[0], pos = a.tokpos[1];
     const unsigned ebase = (unsigned)a.tokpos[2] * (unsigned)(5 * L + 2);
     constexpr int HPC = TK_NCU / SH::NH;
-    const bool att_cu = (c % HPC) == 0;
+    // head h runs on CU h*HPC + (its kv group mod HPC): with the dispatcher placing block b on XCD b % 8 the heads
+    // of one kv group share an XCD (one L2 copy of their K/V rows) and different groups use different XCDs
+    const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
     bool ok = true;
     // RoPE angles depend on pos only: cos/sin once per token, not once per layer        :544-548
@@ -682,7 +684,9 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const int L = a.L;
     const int pos = a.tokpos[1];
     constexpr int HPC = TK_NCU / SH::NH;
-    const bool att_cu = (c % HPC) == 0;
+    // head h runs on CU h*HPC + (its kv group mod HPC): with the dispatcher placing block b on XCD b % 8 the heads
+    // of one kv group share an XCD (one L2 copy of their K/V rows) and different groups use different XCDs
+    const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
 
     TkRing r;

@@ -43,7 +43,7 @@ if os.environ.get("LLMK_TK_TRACE"):
             d = us[cu, l]
             print("  L%02d " % l + " ".join(f"{n}={d[i]-d[0]:.1f}" for i, n in enumerate(names)) + f"  | layer start @{d[0]:.1f}us")
     seg = np.diff(us[:, 1:22, :], axis=2)
-    att = (np.arange(256) % 8) == 0
+    att = (np.arange(256) % 8) == ((np.arange(256) // 8 // 8) % 8)
     print("mean segment us (non-attention CUs):", " ".join(f"{names[i+1]}:{seg[~att][:, :, i].mean():.2f}" for i in range(15)))
     print("mean segment us (attention CUs):    ", " ".join(f"{names[i+1]}:{seg[att][:, :, i].mean():.2f}" for i in range(15)))
     print("layer time:", (us[:, 2:22, 0] - us[:, 1:21, 0]).mean())
