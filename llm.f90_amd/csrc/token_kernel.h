@@ -75,8 +75,10 @@ struct TkShape {
     static constexpr int TPR_H = (H / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = H
     static constexpr int NT_Q = R_Q * TPR_E, NT_O = R_O * TPR_E, NT_A = R_A * TPR_E, NT_D = R_D * TPR_H, NT_C = R_C * TPR_E;
     static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
-                         SL_A = (NT_A + TK_NS - 1) / TK_NS, SL_D = (NT_D + TK_NS - 1) / TK_NS,
-                         SL_C = (NT_C + TK_NS - 1) / TK_NS;
+                         SL_A = (NT_A + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
+    // w2 rows are TPR_H tiles wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
+    // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
+    static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D + NW_D - 1) / NW_D;
     static constexpr int SL_LAYER = SL_Q + SL_O + SL_A + SL_D;
     static constexpr int NC_E_LAST = E / 4 / WAVE - (TPR_E - 1) * TK_TCOLS;  // columns in a row's last tile
     static constexpr int NC_H_LAST = H / 4 / WAVE - (TPR_H - 1) * TK_TCOLS;
@@ -87,6 +89,7 @@ struct TkShape {
     static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
     static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
     static_assert(HS == 64, "in-kernel attention is written for head_size 64");
+    static_assert(TPR_H <= TK_NS && TPR_E == 1, "every column part of a w2 row needs a wave; K = E rows are one tile");
 };
 
 // LDS carve (bytes): xs (streaming input, up to H floats) | xraw (E) | partial | attention scratch
@@ -135,7 +138,7 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
         // vmcnt(0) per element (NL dependent round trips instead of one)
 #pragma unroll
         for (int k = 0; k < NL; ++k)
-            r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane + k * WAVE) * 16, 0, 16);
+            r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);   // k in the scalar offset: one VGPR address
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
@@ -157,12 +160,35 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
         __builtin_amdgcn_s_sleep(1);
     }
 }
+// Cheap wait ahead of a sweep that is known to be far off (the attention output): ONE 16-byte load per lane,
+// a sample of N/128-strided granule pairs that touches every producer, instead of re-reading all N granules
+// per pass -- 224 idle CUs sweeping 16 KB each every microsecond is memory traffic the attention CUs and the
+// weight prefetch pay for.
 template <int N>
+__device__ __forceinline__ bool tk_prepoll(__amdgpu_buffer_rsrc_t rs, unsigned epoch, unsigned* err, int lane, bool nowait) {
+    constexpr int STRIDE = N / 128;
+    for (unsigned spin = 0;; ++spin) {
+        const tk_v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * STRIDE * 16, 0, 16);
+        if (__all((r.y == epoch) & (r.w == epoch)) || nowait) return true;
+        if ((spin & 63) == 63) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spin > TK_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(err, 0x300u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+template <int N, bool PREPOLL = false>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
                                           int lane, bool nowait = false, unsigned long long* dbg = nullptr) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
+    if constexpr (PREPOLL) {
+        if (!tk_prepoll<N>(rs, epoch, err, lane, nowait)) return false;
+    }
     if constexpr (NL <= 24) {
         return tk_gather_part<NL>(rs, 0, epoch, dst, err, lane, nowait, dbg);
     } else {      // long vectors in two register-sized halves
@@ -237,9 +263,47 @@ __device__ __forceinline__ float tk_dot_tile(const float4 (&b)[TK_TCOLS], const 
     }
     return (acc.x + acc.y) + (acc.z + acc.w);
 }
-__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, float* part,
-                                           int lane) {
-    const float acc = wave_sum(tk_dot_tile(b, t, xs, lane));
+// Phases whose rows are ONE tile wide (K = E <= 2048) dot every tile against the same x fragment: it is read
+// from LDS once per phase into registers (XR), not once per tile -- 7 waves x 8 KB of ds_read per slot was
+// ~0.2 us of LDS time in the middle of every slot of the critical path.
+struct TkX {
+    float4 v[TK_TCOLS];
+    template <int NC>
+    __device__ __forceinline__ void load(const float4* xs, int lane) {
+#pragma unroll
+        for (int j = 0; j < TK_TCOLS; ++j) v[j] = (j < NC) ? xs[j * WAVE + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // column part `part` of a K-wide vector (K/4/WAVE vector columns in all): columns past the end read as zero
+    template <int K>
+    __device__ __forceinline__ void load_part(const float4* xs, int part, int lane) {
+        const int nc = K / 4 / WAVE - part * TK_TCOLS;
+#pragma unroll
+        for (int j = 0; j < TK_TCOLS; ++j) {
+            const float4 x = xs[(j < nc) ? part * TK_TCOLS * WAVE + j * WAVE + lane : lane];
+            v[j] = (j < nc) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+};
+template <bool XR>
+__device__ __forceinline__ float tk_dot(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, const TkX& x, int lane) {
+    if constexpr (XR) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < TK_TCOLS; ++j) {
+            acc.x = fmaf(b[j].x, x.v[j].x, acc.x);
+            acc.y = fmaf(b[j].y, x.v[j].y, acc.y);
+            acc.z = fmaf(b[j].z, x.v[j].z, acc.z);
+            acc.w = fmaf(b[j].w, x.v[j].w, acc.w);
+        }
+        return (acc.x + acc.y) + (acc.z + acc.w);
+    } else {
+        return tk_dot_tile(b, t, xs, lane);
+    }
+}
+template <bool XR>
+__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, const TkX& x,
+                                           float* part, int lane) {
+    const float acc = wave_sum(tk_dot<XR>(b, t, xs, x, lane));
     if (lane == 0) part[t.pidx] = acc;
 }
 
@@ -304,8 +368,16 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
             return tk_mk<SH::E, SH::TPR_E, SH::NT_A, SH::MAXP>(
                 a.w13, (long long)l * 2 * SH::H + (r & 1) * SH::H + c * (SH::R_A / 2) + (r >> 1), ti, a.zeros);
         } else if constexpr (K < SC::KP) {
-            const int ti = (K - SC::KD) * TK_NS + sw;
-            return tk_mk<SH::H, SH::TPR_H, SH::NT_D, SH::MAXP>(a.w2, (long long)l * SH::E + c * SH::R_D + ti / SH::TPR_H, ti, a.zeros);
+            constexpr int P = SH::TPR_H;
+            const int part = sw % P, nw = (TK_NS - part + P - 1) / P;      // waves that share this column part
+            const int row = (K - SC::KD) * nw + sw / P;
+            const bool live = row < SH::R_D;
+            TkTile t;
+            t.xoff = part * TK_TCOLS * WAVE;
+            t.ncol = live ? min(TK_TCOLS, SH::H / 4 / WAVE - part * TK_TCOLS) : 0;
+            t.p = live ? reinterpret_cast<const float4*>(a.w2 + ((long long)l * SH::E + c * SH::R_D + row) * SH::H) + part * TK_TCOLS * WAVE : a.zeros;
+            t.pidx = live ? row * P + part : SH::MAXP;
+            return t;
         } else {
             return tk_null<SH::MAXP>(a.zeros);
         }
@@ -611,16 +683,16 @@ struct TkRing {
 };
 
 // slots K .. K+N-1 (compile-time) of layer l: consume ring entry K % NB, refill it with slot K + NB
-template <class SH, int K, int N, bool CLS>
-__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
+template <class SH, int K, int N, bool CLS, bool XR>
+__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4, const TkX& x,
                                        float* part, int lane) {
     if constexpr (N > 0) {
         constexpr int R = K % TK_NB;
-        tk_consume(r.b[R], r.t[R], xs4, part, lane);
+        tk_consume<XR>(r.b[R], r.t[R], xs4, x, part, lane);
         if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
         else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
         tk_issue(r.b[R], r.t[R], a.zeros, lane);
-        tk_run<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, xs4, part, lane);
+        tk_run<SH, K + 1, N - 1, CLS, XR>(r, a, l, c, sw, xs4, x, part, lane);
     }
 }
 // consume only / refill only: a phase's LAST min(NB, slots) slots are dotted first, the partial sums
@@ -629,12 +701,12 @@ __device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int
 // between the dot products and the publish of the phase's result.
 // N tiles at once: all per-lane dots first, then the N wave reductions (independent DPP chains the
 // scheduler can interleave), then ONE lane-0 block of LDS writes
-template <class SH, int K, int N>
-__device__ __forceinline__ void tk_eat(const TkRing& r, const float4* xs4, float* part, int lane) {
+template <class SH, int K, int N, bool XR>
+__device__ __forceinline__ void tk_eat(const TkRing& r, const float4* xs4, const TkX& x, float* part, int lane) {
     if constexpr (N > 0) {
         float v[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = tk_dot_tile(r.b[(K + i) % TK_NB], r.t[(K + i) % TK_NB], xs4, lane);
+        for (int i = 0; i < N; ++i) v[i] = tk_dot<XR>(r.b[(K + i) % TK_NB], r.t[(K + i) % TK_NB], xs4, x, lane);
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
         if (lane == 0) {
@@ -655,13 +727,16 @@ __device__ __forceinline__ void tk_refill(TkRing& r, const TokenArgs& a, int l, 
 }
 // one phase of S slots starting at slot K0: [barrier A] early slots (consume+refill), late slots
 // (consume), [barrier B], late refills
-template <class SH, int K0, int S, bool CLS>
+template <class SH, int K0, int S, bool CLS, bool XR, bool WIDE = false>
 __device__ __forceinline__ void tk_phase(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
                                          float* part, int lane) {
     constexpr int LATE = S < TK_NB ? S : TK_NB, EARLY = S - LATE;
     tk_barrier();
-    tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, xs4, part, lane);
-    tk_eat<SH, K0 + EARLY, LATE>(r, xs4, part, lane);
+    TkX x;
+    if constexpr (XR && WIDE) x.template load_part<SH::H>(xs4, sw % SH::TPR_H, lane);
+    else if constexpr (XR) x.template load<SH::E / 4 / WAVE>(xs4, lane);
+    tk_run<SH, K0, EARLY, CLS, XR>(r, a, l, c, sw, xs4, x, part, lane);
+    tk_eat<SH, K0 + EARLY, LATE, XR>(r, xs4, x, part, lane);
     tk_barrier();
     tk_refill<SH, K0 + EARLY, LATE, CLS>(r, a, l, c, sw, lane);
 }
@@ -689,6 +764,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
 
+    constexpr bool XR = SH::TPR_E == 1;   // a row of the K = E matrices is one tile: x fragment lives in registers
     TkRing r;
     tk_prime<SH, 0>(r, a, c, sw, lane);
 
@@ -697,8 +773,10 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             // which would otherwise queue behind 100+ KB of prefetch in this CU's memory pipeline
             constexpr int LATE = SH::SL_Q < TK_NB ? SH::SL_Q : TK_NB, EARLY = SH::SL_Q - LATE;
             tk_barrier();
-            tk_run<SH, SC::KQ, EARLY, false>(r, a, l, c, sw, xs4, part, lane);
-            tk_eat<SH, SC::KQ + EARLY, LATE>(r, xs4, part, lane);
+            TkX x;
+            if constexpr (XR) x.template load<SH::E / 4 / WAVE>(xs4, lane);
+            tk_run<SH, SC::KQ, EARLY, false, XR>(r, a, l, c, sw, xs4, x, part, lane);
+            tk_eat<SH, SC::KQ + EARLY, LATE, XR>(r, xs4, x, part, lane);
             tk_barrier();
             if (att_cu) {
                 TkAtt<SH> pa;
@@ -709,12 +787,12 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             }
             tk_refill<SH, SC::KQ + EARLY, LATE, false>(r, a, l, c, sw, lane);
         }
-        tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
-        tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
-        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
+        tk_phase<SH, SC::KO, SH::SL_O, false, XR>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase<SH, SC::KA, SH::SL_A, false, XR>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true, true>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
     }
     // classifier: the ring index is 0 again (SLP is a multiple of TK_NB); refills run off the stream's end
-    tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
+    tk_phase<SH, 0, SH::SL_C, true, XR>(r, a, L, c, sw, xs4, part, lane);
 }
 
 template <class SH>
