@@ -273,7 +273,7 @@ int tk_setup(llmk_ctx* c, int id) {
     if (c->use_tk || g.emb_dim != TK::E || g.hidden_dim != TK::H || g.n_heads != TK::NH || g.n_kv_heads != TK::NKV ||
         g.vocab_size != TK::V)
         return LLMK_OK;
-    const size_t lds = (size_t)TkLds<TK>::ATT_S + (size_t)c->S * sizeof(float);
+    const size_t lds = (size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float);   // scores + exp(scores)
     c->tk_lds = lds < 96 * 1024 ? 96 * 1024 : lds;   // > 80 KB: never two workgroups on one CU
     if (c->tk_lds > 160 * 1024) return LLMK_OK;      // context too long for the in-LDS score row: multi-kernel path
     const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H;

@@ -102,7 +102,8 @@ struct TkLds {
     static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
     static constexpr int ATT_R4 = ATT_RED + TK_WAVES * (256 / SH::HS) * SH::HS * 4;   // [waves][TPW][HS/4] float4
     static constexpr int ROPE = ATT_R4 + 64;                               // cos[HS/2] | sin[HS/2] of pos*freq
-    static constexpr int ATT_S = ROPE + SH::HS * 4;                        // scores [S]
+    static constexpr int ATT_P = ROPE + SH::HS * 4;                        // [waves][32] softmax weights of the wave's own timesteps
+    static constexpr int ATT_S = ATT_P + TK_WAVES * 32 * 4;                // scores [S], then exp(score - max) [S]
 };
 
 __device__ __forceinline__ void tk_barrier() {
@@ -121,6 +122,12 @@ typedef unsigned tk_v4u __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t tk_rsrc(const void* p, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// K/V cache rows through a buffer descriptor: a 32-bit byte offset per lane instead of a 64-bit address pair
+__device__ __forceinline__ float4 tk_ldkv(__amdgpu_buffer_rsrc_t rs, int voff) {
+    const tk_v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
 
 // Service wave: collect N granules (N % 128 == 0) whose tag == epoch; values -> dst (LDS, N floats).
@@ -390,20 +397,20 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
 // ------------------------------------------------------------------------------------------------
 template <class SH>
 struct TkAtt {
-    static constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = (TK_NB > 4 ? 4 : 8), TILE = TPB * U;
-    float4 kv[U], vv[U];
-    // K and V rows of the first TILE timesteps (written by earlier launches) are requested at the START
-    // of the layer, long before q exists: by attention time they have crossed the loaded memory system
+    static constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = 8, TILE = TPB * U;
+    float4 kv[U];
+    // K rows of the first TILE (= 256) timesteps (written by earlier launches) are requested at the START of the
+    // layer's attention, long before q exists: by the time q arrives they have crossed the loaded memory system.
+    // The V rows of the same timesteps are requested INTO THE SAME REGISTERS as each score is finished, so they
+    // travel while the softmax runs; only contexts longer than TILE pay exposed round trips.
     __device__ __forceinline__ void prefetch(const TokenArgs& a, int l, int h, int pos, int tid) {
         const int lane = tid & 63, wid = tid >> 6;
         const int g = h / SH::KVMUL, sub = lane % LPT, tl = lane / LPT;
-        const float4* kg = reinterpret_cast<const float4*>(a.kc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
-        const float4* vg = reinterpret_cast<const float4*>(a.vc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
+        const __amdgpu_buffer_rsrc_t rk = tk_rsrc(a.kc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
+        const int col = (g * HS + sub * 4) * 4;
         const int tb = wid * TPW + tl, tmax = max(pos - 2, 0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) kv[u] = kg[(size_t)min(u * TPB + tb, tmax) * (SH::KV / 4)];
-#pragma unroll
-        for (int u = 0; u < U; ++u) vv[u] = vg[(size_t)min(u * TPB + tb, tmax) * (SH::KV / 4)];
+        for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rk, min(u * TPB + tb, tmax) * (SH::KV * 4) + col);
     }
 };
 
@@ -422,7 +429,6 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = TkAtt<SH>::U, TILE = TPB * U;
     static_assert(LPT == 16, "one timestep per DPP row");
     float4 (&kv)[U] = pa.kv;
-    float4 (&vv)[U] = pa.vv;
     const int lane = tid & 63, wid = tid >> 6;
     const int g = h / SH::KVMUL;
     const float* qs = reinterpret_cast<const float*>(lds + TkLds<SH>::ATT_Q);
@@ -433,53 +439,74 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     const int sub = lane % LPT, tl = lane / LPT;
     const float4 qv = reinterpret_cast<const float4*>(qs)[sub];
     const float scale = sqrtf((float)HS);
-    const float4* kg = reinterpret_cast<const float4*>(a.kc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
-    const float4* vg = reinterpret_cast<const float4*>(a.vc + (size_t)l * a.S * SH::KV + (size_t)g * HS) + sub;
-    constexpr int kv4 = SH::KV / 4;
+    const __amdgpu_buffer_rsrc_t rk = tk_rsrc(a.kc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
+    const __amdgpu_buffer_rsrc_t rv = tk_rsrc(a.vc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
+    constexpr int rowb = SH::KV * 4;                 // bytes per cached timestep
+    const int col = (g * HS + sub * 4) * 4;
     const int tb = wid * TPW + tl;
     const int npast = pos - 1;  // rows 0..pos-2 live in the cache; row pos-1 is this token's (LDS)
     const int tmax = max(npast - 1, 0);
+    const int last = (pos - 1) / TILE * TILE;   // base of the last batch: ITS V rows replace its K rows in kv[]
 
+    float* ex = att + a.S;                                                      // exp(score - max), written per wave
+    float* pw = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_P) + wid * 32;    // this wave's 32 weights of a batch
     for (int base = 0; base < pos; base += TILE) {
         if (base > 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) kv[u] = kg[(size_t)min(base + u * TPB + tb, tmax) * kv4];
+            for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rk, min(base + u * TPB + tb, tmax) * rowb + col);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (base + u * TPB < pos) {   // block-uniform: short contexts skip the empty batches
                 const int t = base + u * TPB + tb;
-                const float4 kk = (t == npast) ? kcur[sub] : kv[u];
-                const float d = row16_sum(dot4(qv, kk, 0.f));
-                if (sub == LPT - 1 && t < pos) att[t] = d / scale;                 // :582
+                // rows >= pos-1 read a clamped (wrong) row: t = pos-1 is redone from LDS below, later ones are never used
+                const float d = row16_sum(dot4(qv, kv[u], 0.f));
+                if (sub == LPT - 1 && t < npast) att[t] = d / scale;               // :582
+                if (base == last) kv[u] = tk_ldkv(rv, min(t, tmax) * rowb + col);   // V row of the same timestep
             }
         }
+    }
+    {   // this token's own key never went through the cache
+        const float d = row16_sum(dot4(qv, kcur[sub], 0.f));
+        if (wid == 0 && lane == LPT - 1) att[npast] = d / scale;
     }
     if (dbg) dbg[0] = wall_clock64();
     tk_barrier();
     if (dbg) dbg[1] = wall_clock64();
-    // every wave folds max and sum over ALL scores itself: no cross-wave reduction, no extra barriers
+    // every wave folds max and sum over ALL scores itself: no cross-wave reduction, no extra barriers.  exp() is
+    // evaluated once per score here (each wave keeps its own copy of what it wrote: same values, benign overlap)
     float m = -INFINITY;
     for (int t = lane; t < pos; t += WAVE) m = fmaxf(m, att[t]);
     m = wave_max(m);
     if (dbg) dbg[3] = wall_clock64();
     float s = 0.f;
-    for (int t = lane; t < pos; t += WAVE) s += expf(att[t] - m);
+    for (int t = lane; t < pos; t += WAVE) {
+        const float e = expf(att[t] - m);
+        ex[t] = e;
+        s += e;
+    }
     s = wave_sum(s);
     if (dbg) dbg[4] = wall_clock64();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < pos; base += TILE) {
-        if (base > 0) {
+    // the last batch's V rows are already in kv[]: it goes first, the (rare) earlier batches reload after it.
+    // The sum over t is reassociated by batch only; within a lane the order of its timesteps is fixed.
+    for (int it = 0, base = last; it * TILE < pos; ++it, base = (it - 1) * TILE) {
+        if (it > 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) vv[u] = vg[(size_t)min(base + u * TPB + tb, tmax) * kv4];
+            for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rv, min(base + u * TPB + tb, tmax) * rowb + col);
+        }
+        // xi/sum(xi) (:476) once per timestep: lane i < 32 owns timestep (u = i / TPW, tl = i % TPW) of this wave
+        if (lane < 32) {
+            const int t = base + (lane / TPW) * TPB + wid * TPW + (lane % TPW);
+            pw[lane] = (t < pos) ? ex[t] / s : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (base + u * TPB < pos) {
                 const int t = base + u * TPB + tb;
-                const float4 v4 = (t == npast) ? vcur[sub] : vv[u];
-                const float p = (t < pos) ? expf(att[t] - m) / s : 0.f;            // xi/sum(xi)  :476
+                const float4 v4 = (t == npast) ? vcur[sub] : kv[u];
+                const float p = pw[u * TPW + tl];
                 acc.x = fmaf(p, v4.x, acc.x);
                 acc.y = fmaf(p, v4.y, acc.y);
                 acc.z = fmaf(p, v4.z, acc.z);
@@ -803,7 +830,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     const int c = blockIdx.x;
     // every wave reads its OWN zero block: one shared block would make 1800 waves hammer one HBM channel
     a.zeros += (size_t)(c * TK_WAVES + wid) * WAVE;
-    if (wid == TK_NS) tk_service<SH>(a, lds, c, lane, tid);
+    if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH>(a, lds, c, lane, tid); }
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }
 
