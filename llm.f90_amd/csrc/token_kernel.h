@@ -63,6 +63,8 @@ struct TokenArgs {
     unsigned long long* trace;  // optional [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave (debug)
     int L, S;
     int nosync;              // debug: do not wait for exchange tags (wrong results; measures the pure streaming rate)
+    // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
+    int q0, qn, o0, on;
 };
 
 template <int E_, int H_, int NH_, int NKV_, int V_>
@@ -70,7 +72,14 @@ struct TkShape {
     static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_;
     static constexpr int HS = E / NH, KV = NKV * HS, KVMUL = NH / NKV, QKV = E + 2 * KV;
     // rows per CU and tiles per CU for each phase
-    static constexpr int R_Q = QKV / TK_NCU, R_O = E / TK_NCU, R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU, R_C = V / TK_NCU;
+    // The NH attention CUs own NO rows of the QKV and wo matrices (the two phases either side of attention): their q poll,
+    // K/V rows and attention never queue behind their own weight prefetch, and nobody waits for them to catch up on
+    // streaming after attention.  The other NCU_W CUs split those rows as evenly as whole RoPE pairs / rows allow.
+    static constexpr int NCU_W = TK_NCU - NH;
+    static constexpr int QB = (QKV / 2) / NCU_W, QX = (QKV / 2) % NCU_W;      // pairs per CU, CUs with one pair more
+    static constexpr int OB = E / NCU_W, OX = E % NCU_W;
+    static constexpr int R_Q = 2 * (QB + (QX > 0 ? 1 : 0)), R_O = OB + (OX > 0 ? 1 : 0);   // MAX rows per CU
+    static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU, R_C = V / TK_NCU;
     static constexpr int TPR_E = (E / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = E
     static constexpr int TPR_H = (H / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = H
     static constexpr int NT_Q = R_Q * TPR_E, NT_O = R_O * TPR_E, NT_A = R_A * TPR_E, NT_D = R_D * TPR_H, NT_C = R_C * TPR_E;
@@ -83,8 +92,7 @@ struct TkShape {
     static constexpr int NC_E_LAST = E / 4 / WAVE - (TPR_E - 1) * TK_TCOLS;  // columns in a row's last tile
     static constexpr int NC_H_LAST = H / 4 / WAVE - (TPR_H - 1) * TK_TCOLS;
     static constexpr int MAXP = (NT_A > NT_C ? NT_A : NT_C) > NT_D ? (NT_A > NT_C ? NT_A : NT_C) : NT_D;
-    static_assert(QKV % TK_NCU == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % TK_NCU == 0, "rows must split over CUs");
-    static_assert(R_Q % 2 == 0, "RoPE pairs must not straddle CUs");
+    static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % TK_NCU == 0, "rows must split over CUs");
     static_assert(E % 256 == 0 && H % 256 == 0, "rows are whole 1 KB segments");
     static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
     static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
@@ -343,6 +351,18 @@ __device__ __forceinline__ TkTile tk_mk(const float* mat, long long row, int ti,
     return t;
 }
 
+// tile ti of a CU's run-time row range [row0, row0+n) of a K = E matrix (a row is one tile)
+template <class SH>
+__device__ __forceinline__ TkTile tk_row_tile(const float* mat, long long row0, int ti, int n, const float4* zp) {
+    TkTile t;
+    const bool live = ti < n;
+    t.xoff = 0;
+    t.ncol = live ? min(TK_TCOLS, SH::E / 4 / WAVE) : 0;
+    t.p = live ? reinterpret_cast<const float4*>(mat + (row0 + ti) * SH::E) : zp;
+    t.pidx = live ? ti : SH::MAXP;
+    return t;
+}
+
 template <class SH, int K>
 __device__ __forceinline__ TkTile tk_cls_at(const TokenArgs& a, int c, int sw) {
     if constexpr (K < SH::SL_C) {
@@ -364,11 +384,9 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
     } else {
         if (l >= a.L) return tk_cls_at<SH, K>(a, c, sw);
         if constexpr (K < SC::KO) {
-            const int ti = (K - SC::KQ) * TK_NS + sw;
-            return tk_mk<SH::E, SH::TPR_E, SH::NT_Q, SH::MAXP>(a.wqkv, (long long)l * SH::QKV + c * SH::R_Q + ti / SH::TPR_E, ti, a.zeros);
+            return tk_row_tile<SH>(a.wqkv, (long long)l * SH::QKV + a.q0, (K - SC::KQ) * TK_NS + sw, a.qn, a.zeros);
         } else if constexpr (K < SC::KA) {
-            const int ti = (K - SC::KO) * TK_NS + sw;
-            return tk_mk<SH::E, SH::TPR_E, SH::NT_O, SH::MAXP>(a.wo, (long long)l * SH::E + c * SH::R_O + ti / SH::TPR_E, ti, a.zeros);
+            return tk_row_tile<SH>(a.wo, (long long)l * SH::E + a.o0, (K - SC::KO) * TK_NS + sw, a.on, a.zeros);
         } else if constexpr (K < SC::KD) {
             const int ti = (K - SC::KA) * TK_NS + sw;
             const int r = ti / SH::TPR_E;  // 0..R_A-1: (gate0, up0, gate1, up1, ...)
@@ -553,20 +571,23 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
         TkNorm<SH::E> nrm;
-        nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
-        if (l == 0) {
+        if (!att_cu) nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
+        float xn_att = 1.f;
+        if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
+            if (l == 0) {
 #pragma unroll 8
-            for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
-        } else {
-            ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+                for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
+            } else {
+                ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+            }
+            TK_STAMP(1);
+            xn_att = nrm.apply(xraw, xs, lane);
         }
-        TK_STAMP(1);
-        const float xn_att = nrm.apply(xraw, xs, lane);
         tk_barrier();
         TK_STAMP(2);
         tk_barrier();
         TK_STAMP(3);
-        if (lane < SH::R_Q) {
+        if (lane < a.qn) {
             float v0 = 0.f, v1 = 0.f;
 #pragma unroll
             for (int p = 0; p < SH::TPR_E; ++p) {
@@ -575,7 +596,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
             v0 = v0 / xn_att;
             v1 = v1 / xn_att;
-            const int r = c * SH::R_Q + lane;
+            const int r = a.q0 + lane;
             float outv = v0;
             if (r < SH::E + SH::KV) {
                 // pairs (i,i+1); 1-based odd i -> head_dim = mod(i,hs) = 2j+1 (table index j)   :543-559
@@ -634,16 +655,16 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_xb + my_head * SH::HS + lane, e_att, o);
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        if (!att_cu) ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         TK_STAMP(7);
         tk_barrier();
         tk_barrier();
         TK_STAMP(8);
-        if (lane < SH::R_O) {
+        if (lane < a.on) {
             float v = 0.f;
 #pragma unroll
             for (int p = 0; p < SH::TPR_E; ++p) v += part[lane * SH::TPR_E + p];
-            const int r = c * SH::R_O + lane;
+            const int r = a.o0 + lane;
             tk_publish(a.g_xa + r, e_o, xraw[r] + v);
         }
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
@@ -830,6 +851,16 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     const int c = blockIdx.x;
     // every wave reads its OWN zero block: one shared block would make 1800 waves hammer one HBM channel
     a.zeros += (size_t)(c * TK_WAVES + wid) * WAVE;
+    {
+        constexpr int HPC = TK_NCU / SH::NH;
+        const int blk = c / HPC, ap = (blk / SH::KVMUL) % HPC;       // attention CU of this block of HPC CUs (see tk_service)
+        const bool att_cu = (c % HPC) == ap;
+        const int n = c - blk - ((c % HPC) > ap ? 1 : 0);            // rank among the CUs that own QKV / wo rows
+        a.qn = att_cu ? 0 : 2 * (SH::QB + (n < SH::QX ? 1 : 0));
+        a.q0 = 2 * (n * SH::QB + min(n, SH::QX));
+        a.on = att_cu ? 0 : SH::OB + (n < SH::OX ? 1 : 0);
+        a.o0 = n * SH::OB + min(n, SH::OX);
+    }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH>(a, lds, c, lane, tid); }
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }
