@@ -416,19 +416,23 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
 template <class SH>
 struct TkAtt {
     static constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = 8, TILE = TPB * U;
-    float4 kv[U];
-    // K rows of the first TILE (= 256) timesteps (written by earlier launches) are requested at the START of the
-    // layer's attention, long before q exists: by the time q arrives they have crossed the loaded memory system.
-    // The V rows of the same timesteps are requested INTO THE SAME REGISTERS as each score is finished, so they
-    // travel while the softmax runs; only contexts longer than TILE pay exposed round trips.
+    float4 kv[U], vv[U];
+    // K and V rows of the first TILE (= 256) timesteps (written by earlier launches) are requested at the START of
+    // the layer's attention, long before q exists: by the time q arrives they have crossed the loaded memory system.
+    // (The 64 registers are the two ring entries the QKV phase has just consumed and not yet refilled; an attention
+    // CU streams no QKV / wo tiles, so nothing else of its own is queued ahead of the q poll.)
+    // Only contexts longer than TILE pay exposed round trips.
     __device__ __forceinline__ void prefetch(const TokenArgs& a, int l, int h, int pos, int tid) {
         const int lane = tid & 63, wid = tid >> 6;
         const int g = h / SH::KVMUL, sub = lane % LPT, tl = lane / LPT;
         const __amdgpu_buffer_rsrc_t rk = tk_rsrc(a.kc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
+        const __amdgpu_buffer_rsrc_t rv = tk_rsrc(a.vc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
         const int col = (g * HS + sub * 4) * 4;
         const int tb = wid * TPW + tl, tmax = max(pos - 2, 0);
 #pragma unroll
         for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rk, min(u * TPB + tb, tmax) * (SH::KV * 4) + col);
+#pragma unroll
+        for (int u = 0; u < U; ++u) vv[u] = tk_ldkv(rv, min(u * TPB + tb, tmax) * (SH::KV * 4) + col);
     }
 };
 
@@ -447,6 +451,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = TkAtt<SH>::U, TILE = TPB * U;
     static_assert(LPT == 16, "one timestep per DPP row");
     float4 (&kv)[U] = pa.kv;
+    float4 (&vv)[U] = pa.vv;
     const int lane = tid & 63, wid = tid >> 6;
     const int g = h / SH::KVMUL;
     const float* qs = reinterpret_cast<const float*>(lds + TkLds<SH>::ATT_Q);
@@ -464,7 +469,6 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     const int tb = wid * TPW + tl;
     const int npast = pos - 1;  // rows 0..pos-2 live in the cache; row pos-1 is this token's (LDS)
     const int tmax = max(npast - 1, 0);
-    const int last = (pos - 1) / TILE * TILE;   // base of the last batch: ITS V rows replace its K rows in kv[]
 
     float* ex = att + a.S;                                                      // exp(score - max), written per wave
     float* pw = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_P) + wid * 32;    // this wave's 32 weights of a batch
@@ -480,7 +484,6 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
                 // rows >= pos-1 read a clamped (wrong) row: t = pos-1 is redone from LDS below, later ones are never used
                 const float d = row16_sum(dot4(qv, kv[u], 0.f));
                 if (sub == LPT - 1 && t < npast) att[t] = d / scale;               // :582
-                if (base == last) kv[u] = tk_ldkv(rv, min(t, tmax) * rowb + col);   // V row of the same timestep
             }
         }
     }
@@ -507,12 +510,10 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     if (dbg) dbg[4] = wall_clock64();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    // the last batch's V rows are already in kv[]: it goes first, the (rare) earlier batches reload after it.
-    // The sum over t is reassociated by batch only; within a lane the order of its timesteps is fixed.
-    for (int it = 0, base = last; it * TILE < pos; ++it, base = (it - 1) * TILE) {
-        if (it > 0) {
+    for (int base = 0; base < pos; base += TILE) {
+        if (base > 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rv, min(base + u * TPB + tb, tmax) * rowb + col);
+            for (int u = 0; u < U; ++u) vv[u] = tk_ldkv(rv, min(base + u * TPB + tb, tmax) * rowb + col);
         }
         // xi/sum(xi) (:476) once per timestep: lane i < 32 owns timestep (u = i / TPW, tl = i % TPW) of this wave
         if (lane < 32) {
@@ -523,7 +524,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
         for (int u = 0; u < U; ++u) {
             if (base + u * TPB < pos) {
                 const int t = base + u * TPB + tb;
-                const float4 v4 = (t == npast) ? vcur[sub] : kv[u];
+                const float4 v4 = (t == npast) ? vcur[sub] : vv[u];
                 const float p = pw[u * TPW + tl];
                 acc.x = fmaf(p, v4.x, acc.x);
                 acc.y = fmaf(p, v4.y, acc.y);
