@@ -70,7 +70,9 @@ struct llmk_ctx {
     float *d_x = nullptr, *d_q = nullptr, *d_xb = nullptr, *d_hb = nullptr, *d_logits = nullptr, *d_rope = nullptr;
     int *d_tokpos = nullptr, *d_next = nullptr;
     int* h_tokpos = nullptr;  // pinned {token0, pos1}
-    float* h_logits = nullptr;  // pinned [V]
+    float* h_logits = nullptr;  // pinned [V] (+ error word)
+    float* h_logits_dev = nullptr;   // the same buffer as the device sees it (token kernel direct mode)
+    bool tk_direct = true;
     int* h_next = nullptr;      // pinned
     hipStream_t stream = nullptr;
     hipGraphExec_t graph_logits = nullptr, graph_greedy = nullptr;
@@ -231,8 +233,10 @@ hipError_t launch_embed(llmk_ctx* c) {
         if (e_ != hipSuccess) return e_; \
     } while (0)
 
+// direct = true: token/pos/serial travel as kernel arguments and the logits (+ a sticky error word) are written
+// straight into the pinned host buffer, so a token is ONE launch and one stream sync (no copy nodes around it)
 template <class TK>
-hipError_t launch_token_kernel_t(llmk_ctx* c) {
+hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     TokenArgs a;
     a.emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
     a.rms_att = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;
@@ -246,14 +250,18 @@ hipError_t launch_token_kernel_t(llmk_ctx* c) {
     a.kc = c->d_kc;
     a.vc = c->d_vc;
     a.rope = c->d_rope;
-    a.tokpos = c->d_tokpos;
+    a.tokpos = direct ? nullptr : c->d_tokpos;
+    a.tok_imm = c->h_tokpos[0];
+    a.pos_imm = c->h_tokpos[1];
+    a.serial_imm = c->h_tokpos[2];
     a.g_qkv = c->d_gran;
     a.g_xb = a.g_qkv + TK::QKV;
     a.g_xa = a.g_xb + TK::E;
     a.g_hb = a.g_xa + TK::E;
     a.g_x = a.g_hb + TK::H;
-    a.logits = c->d_logits;
+    a.logits = direct ? c->h_logits_dev : c->d_logits;
     a.err = reinterpret_cast<unsigned*>(c->d_logits + c->V);
+    a.herr = direct ? reinterpret_cast<unsigned*>(c->h_logits_dev + c->V) : nullptr;
     a.zeros = c->d_zeros;
     a.trace = c->d_trace;
     a.L = c->L;
@@ -262,8 +270,8 @@ hipError_t launch_token_kernel_t(llmk_ctx* c) {
     hipLaunchKernelGGL((token_kernel<TK>), dim3(TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
     return hipGetLastError();
 }
-hipError_t launch_token_kernel(llmk_ctx* c) {
-    return c->tk_shape == 1 ? launch_token_kernel_t<TkTinyLlama>(c) : launch_token_kernel_t<TkSmall>(c);
+hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false) {
+    return c->tk_shape == 1 ? launch_token_kernel_t<TkTinyLlama>(c, direct) : launch_token_kernel_t<TkSmall>(c, direct);
 }
 
 // Allocate the exchange state of the persistent kernel if cfg matches the instantiated shape TK.
@@ -409,6 +417,9 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
         HIPCHK(enqueue_tail(c, greedy));
     } else if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
         HIPCHK(enqueue_token(c, greedy, timed));
+    } else if (c->use_tk && !greedy && c->tk_direct) {
+        reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
+        HIPCHK(launch_token_kernel(c, true));
     } else {
         hipGraphExec_t* g = greedy ? &c->graph_greedy : &c->graph_logits;
         if (!*g) {
@@ -535,7 +546,9 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     CK(hipMalloc(&c->d_tokpos, 4 * sizeof(int)));
     CK(hipMalloc(&c->d_next, 2 * sizeof(int)));
     CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
-    CK(hipHostMalloc(&c->h_logits, ((size_t)V + 4) * sizeof(float), hipHostMallocDefault));
+    CK(hipHostMalloc(&c->h_logits, ((size_t)V + 4) * sizeof(float), hipHostMallocMapped));
+    CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
+    c->tk_direct = !(getenv("LLMK_TK_DIRECT") && getenv("LLMK_TK_DIRECT")[0] == '0');
     CK(hipHostMalloc(&c->h_next, 2 * sizeof(int), hipHostMallocDefault));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));

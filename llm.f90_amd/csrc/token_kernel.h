@@ -51,7 +51,9 @@ struct TokenArgs {
     float* kc;               // [L][S][KV]
     float* vc;
     const float* rope;       // [hs/2]
-    const int* tokpos;       // {token0, pos1, serial}
+    const int* tokpos;       // {token0, pos1, serial} in device memory (graph replay), or null: the three fields below
+    int tok_imm, pos_imm, serial_imm;
+    unsigned* herr;          // optional sticky error word in HOST memory (direct mode: logits also point at host memory)
     unsigned long long* g_qkv;  // granules [E+2KV]
     unsigned long long* g_xb;   // [E]   attention output
     unsigned long long* g_xa;   // [E]   x after attention residual
@@ -548,8 +550,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
     const float* part = reinterpret_cast<const float*>(lds + LD::PART);
     const int L = a.L;
-    const int tok = a.tokpos[0], pos = a.tokpos[1];
-    const unsigned ebase = (unsigned)a.tokpos[2] * (unsigned)(5 * L + 2);
+    const int tok = a.tokpos ? a.tokpos[0] : a.tok_imm, pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
+    const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
     constexpr int HPC = TK_NCU / SH::NH;
     // head h runs on CU h*HPC + (its kv group mod HPC): with the dispatcher placing block b on XCD b % 8 the heads
     // of one kv group share an XCD (one L2 copy of their K/V rows) and different groups use different XCDs
@@ -719,7 +721,10 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         for (int p = 0; p < SH::TPR_E; ++p) v += part[j * SH::TPR_E + p];
         a.logits[c * SH::R_C + j] = v / xn_fin;
     }
-    if (!ok && lane == 0) atomicOr(a.err, 0x1000u);
+    if (!ok && lane == 0) {
+        atomicOr(a.err, 0x1000u);
+        if (a.herr) __hip_atomic_store(a.herr, 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -806,7 +811,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
     float* part = reinterpret_cast<float*>(lds + LD::PART);
     const int L = a.L;
-    const int pos = a.tokpos[1];
+    const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     constexpr int HPC = TK_NCU / SH::NH;
     // head h runs on CU h*HPC + (its kv group mod HPC): with the dispatcher placing block b on XCD b % 8 the heads
     // of one kv group share an XCD (one L2 copy of their K/V rows) and different groups use different XCDs
