@@ -510,7 +510,8 @@ constexpr int ATT_U = 16;  // timestep batches in flight per thread
 template <int HS>
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                    const float* __restrict__ vc, float* __restrict__ xb,
-                                                   const int* __restrict__ tokpos, int KV, int kv_mul) {
+                                                   const int* __restrict__ tokpos, int KV, int kv_mul,
+                                                   int pos0 = 0, int tstride = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float4* red = reinterpret_cast<float4*>(smem_raw);            // [4 waves][HS/4] float4  (<= 2 KB)
     float* red4 = reinterpret_cast<float*>(smem_raw) + 512;       // [4]
@@ -522,7 +523,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int h = blockIdx.x, g = h / kv_mul;
-    const int pos = tokpos[1];
+    // decode: one query at tokpos[1].  Prefill (pos0 > 0): blockIdx.y-th prompt position of the batch, its own q / xb rows
+    const int pos = pos0 > 0 ? pos0 + (int)blockIdx.y : tokpos[1];
+    q += (size_t)blockIdx.y * tstride;
+    xb += (size_t)blockIdx.y * tstride;
     const int sub = lane % LPT, tl = lane / LPT;
     const float4 qv = reinterpret_cast<const float4*>(q + (size_t)h * HS)[sub];
     const float scale = sqrtf((float)HS);

@@ -14,8 +14,11 @@
 #include "../../include/llmk.h"
 #include "kernels.h"
 #include "token_kernel.h"
+#include "prefill.h"
 
 #include <rccl/rccl.h>
+
+#include <algorithm>
 
 #include <math.h>
 #include <stdio.h>
@@ -86,6 +89,9 @@ struct llmk_ctx {
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
     size_t tk_lds = 0;
+    // batched prefill workspaces (prefill.h), allocated by the first llmk_prefill
+    float *pf_X = nullptr, *pf_Xs = nullptr, *pf_Q = nullptr, *pf_XB = nullptr, *pf_HB = nullptr, *pf_P = nullptr, *pf_xn = nullptr;
+    int* pf_tok = nullptr;
 };
 
 namespace {
@@ -436,6 +442,115 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
     return LLMK_OK;
 }
 
+// ---- batched prefill (prefill.h) ------------------------------------------------------------------------
+// K slices of a GEMM: enough (64-row strip x slice) blocks for >= 2 per CU, slices whole multiples of PF_KSTEP columns
+void pf_split(const llmk_ctx* c, int rows, int K, int* ks_out, int* kslice_out) {
+    const int strips = (rows + 63) / 64;
+    int ks = (2 * c->n_cu + strips - 1) / strips;
+    int kslice = ((K + ks - 1) / ks + PF_KSTEP - 1) / PF_KSTEP * PF_KSTEP;
+    if (kslice < 2 * PF_KSTEP) kslice = 2 * PF_KSTEP;
+    *kslice_out = kslice;
+    *ks_out = (K + kslice - 1) / kslice;
+}
+int pf_setup(llmk_ctx* c) {
+    if (c->pf_X) return LLMK_OK;
+    const size_t T = PF_TMAX;
+    const int rows[4] = {c->E + 2 * c->KV, c->E, 2 * c->H, c->E};
+    size_t pcap = 0;
+    const int Ks[4] = {c->E, c->E, c->E, c->H};
+    for (int i = 0; i < 4; ++i) {
+        int ks, kslice;
+        pf_split(c, rows[i], Ks[i], &ks, &kslice);
+        pcap = std::max(pcap, (size_t)ks * T * rows[i]);
+    }
+    HIPCHK(hipMalloc(&c->pf_X, T * c->E * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_Xs, T * c->E * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_Q, T * c->E * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_XB, T * c->E * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_HB, T * c->H * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_P, pcap * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_xn, T * sizeof(float)));
+    HIPCHK(hipMalloc(&c->pf_tok, T * sizeof(int)));
+    return LLMK_OK;
+}
+// P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; returns KS through *ks_out
+hipError_t pf_gemm(llmk_ctx* c, const float* W, const float* X, int rows, int K, int T, int* ks_out) {
+    PfGemmArgs a;
+    a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
+    int ks, kslice;
+    pf_split(c, rows, K, &ks, &kslice);
+    a.kslice = kslice;
+    *ks_out = ks;
+    const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
+    switch ((T + 15) / 16) {
+        case 1: hipLaunchKernelGGL(pf_gemm_kernel<1>, grid, block, 0, c->stream, a); break;
+        case 2: hipLaunchKernelGGL(pf_gemm_kernel<2>, grid, block, 0, c->stream, a); break;
+        case 3: hipLaunchKernelGGL(pf_gemm_kernel<3>, grid, block, 0, c->stream, a); break;
+        default: hipLaunchKernelGGL(pf_gemm_kernel<4>, grid, block, 0, c->stream, a); break;
+    }
+    return hipGetLastError();
+}
+// one batch of T <= PF_TMAX prompt positions pos0 .. pos0+T-1 (1-based) through all layers; X[T-1] ends up in d_x
+hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
+    const int E = c->E, H = c->H, KV = c->KV, QKV = E + 2 * KV, Tp = (T + 15) / 16 * 16;
+    const float* emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
+    hipLaunchKernelGGL(pf_embed_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, emb, c->pf_tok, c->pf_X, E);
+    HIPRET(hipGetLastError());
+    PfEpiArgs e;
+    memset(&e, 0, sizeof(e));
+    e.P = c->pf_P; e.xn = c->pf_xn; e.rope = c->d_rope; e.Tp = Tp; e.T = T; e.pos0 = pos0;
+    e.E = E; e.KV = KV; e.hs = c->hs; e.H = H;
+    for (int l = 0; l < c->L; ++l) {
+        const float* wqkv = (const float*)c->t[LLMK_WQKV].data + (size_t)l * QKV * E;
+        const float* wo = (const float*)c->t[LLMK_WO].data + (size_t)l * E * E;
+        const float* w13 = (const float*)c->t[LLMK_W13].data + (size_t)l * 2 * H * E;
+        const float* w2 = (const float*)c->t[LLMK_W2].data + (size_t)l * E * H;
+        float* kc = c->d_kc + (size_t)l * c->S * KV;
+        float* vc = c->d_vc + (size_t)l * c->S * KV;
+        // rmsnorm + QKV + RoPE + KV write                                                 llama2.f90:527-565
+        hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
+                           (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E);
+        HIPRET(hipGetLastError());
+        HIPRET(pf_gemm(c, wqkv, c->pf_Xs, QKV, E, T, &e.KS));
+        e.rows = QKV; e.out = c->pf_Q; e.kc = kc; e.vc = vc;
+        hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, c->stream, e);
+        HIPRET(hipGetLastError());
+        // causal attention: position pos0+t sees cache rows 0 .. pos0+t-1                 :572-598
+        const size_t smem = (516 + (size_t)c->S) * sizeof(float);
+#define ATT(HS_)                                                                                                   \
+    hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nh, T), dim3(256), smem, c->stream, c->pf_Q, kc, vc, c->pf_XB, \
+                       c->d_tokpos, KV, c->kv_mul, pos0, E)
+        switch (c->hs) {
+            case 16: ATT(16); break;
+            case 32: ATT(32); break;
+            case 64: ATT(64); break;
+            case 128: ATT(128); break;
+            default: return hipErrorInvalidValue;
+        }
+#undef ATT
+        HIPRET(hipGetLastError());
+        // x += wo . xb                                                                    :603-605
+        HIPRET(pf_gemm(c, wo, c->pf_XB, E, E, T, &e.KS));
+        e.rows = E; e.out = c->pf_X;
+        hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
+        HIPRET(hipGetLastError());
+        // rmsnorm + w1|w3 + SwiGLU                                                        :608-616
+        hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
+                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E);
+        HIPRET(hipGetLastError());
+        HIPRET(pf_gemm(c, w13, c->pf_Xs, 2 * H, E, T, &e.KS));
+        e.rows = 2 * H; e.out = c->pf_HB;
+        hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, c->stream, e);
+        HIPRET(hipGetLastError());
+        // x += w2 . hb                                                                    :618-620
+        HIPRET(pf_gemm(c, w2, c->pf_HB, E, H, T, &e.KS));
+        e.rows = E; e.out = c->pf_X;
+        hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
+        HIPRET(hipGetLastError());
+    }
+    return hipMemcpyAsync(c->d_x, c->pf_X + (size_t)(T - 1) * E, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -695,6 +810,44 @@ int llmk_forward(llmk_ctx* c, int token, int pos, float* logits_out) {
     return LLMK_OK;
 }
 
+// The prompt loop of llama2.f90:376-402 as ONE call: tokens[0..n) (1-based ids) sit at positions pos0 .. pos0+n-1,
+// the KV cache rows of those positions are written, and logits_out receives the logits of the LAST position --
+// exactly what n llmk_forward calls leave behind.  f32 single-GPU contexts run the batched MFMA path (prefill.h);
+// every other configuration falls back to the token-by-token pass.
+int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_out) {
+    if (!c || !tokens || !logits_out || n < 1 || pos0 < 1 || pos0 + n - 1 > c->S) return LLMK_E_ARG;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i)
+        if (tokens[i] < 1 || tokens[i] > c->V) return LLMK_E_ARG;
+    const bool batched = c->cfg.weight_type == LLMK_TYPE_F32 && c->tp_size == 1 && !c->comm && c->E % PF_KSTEP == 0 &&
+                         c->H % PF_KSTEP == 0 && c->KV % 16 == 0 && !(getenv("LLMK_PREFILL") && getenv("LLMK_PREFILL")[0] == '0');
+    if (!batched) {
+        for (int i = 0; i < n; ++i) {
+            rc = run_token(c, tokens[i], pos0 + i, false);
+            if (rc) return rc;
+        }
+        memcpy(logits_out, c->h_logits, (size_t)c->V * sizeof(float));
+        return LLMK_OK;
+    }
+    HIPCHK(hipSetDevice(c->cfg.device));
+    rc = pf_setup(c);
+    if (rc) return rc;
+    int tok0[PF_TMAX];
+    for (int i = 0; i < n; i += PF_TMAX) {
+        const int T = n - i < PF_TMAX ? n - i : PF_TMAX;
+        for (int j = 0; j < T; ++j) tok0[j] = tokens[i + j] - 1;
+        HIPCHK(hipMemcpyAsync(c->pf_tok, tok0, T * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));   // tok0 is reused by the next batch
+        HIPCHK(pf_batch(c, T, pos0 + i));
+    }
+    HIPCHK(launch_cls(c));                          // final rmsnorm + classifier of the last position   :627-636
+    HIPCHK(hipMemcpyAsync(c->h_logits, c->d_logits, (size_t)c->V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(logits_out, c->h_logits, (size_t)c->V * sizeof(float));
+    return LLMK_OK;
+}
+
 int llmk_forward_greedy(llmk_ctx* c, int token, int pos, int* next_token) {
     if (!c || !next_token) return LLMK_E_ARG;
     int rc = run_token(c, token, pos, true);
@@ -887,7 +1040,8 @@ int llmk_destroy(llmk_ctx* c) {
         if (c->t[i].scales) hipFree(c->t[i].scales);
     }
     void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,
-                   c->d_gran, c->d_zeros, c->d_trace, c->d_part};
+                   c->d_gran, c->d_zeros, c->d_trace, c->d_part, c->pf_X, c->pf_Xs, c->pf_Q, c->pf_XB, c->pf_HB, c->pf_P,
+                   c->pf_xn, c->pf_tok};
     for (void* p : dev)
         if (p) hipFree(p);
     if (c->h_tokpos) hipHostFree(c->h_tokpos);

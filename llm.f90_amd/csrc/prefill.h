@@ -1,0 +1,206 @@
+// Batched prompt prefill for gfx950: T prompt positions go through each
+// layer TOGETHER, so a layer's weights cross HBM once per batch instead of once per token
+// (/root/reference/llama2.f90:376-402 feeds the prompt one token at a time through `transformer`, :480-640,
+// and discards the logits of every position but the last).  Same arithmetic per position as the
+// decode path (rmsnorm :450-457, RoPE :543-559 with the 1-based pos, GQA attention :572-598, SwiGLU
+// :615-616); only the order of the dot-product partial sums differs.
+//
+// The weight GEMMs are the one place on this path where the matrix cores are the right tool: Y[T][rows] =
+// X[T][K] . W[rows][K]^T has 2*T flop per weight word.  v_mfma_f32_16x16x4_f32 keeps full f32 operands
+// (parity bar: 1e-4 relative on logits), 256 flop/clk/CU.
+//
+// pf_gemm: grid (ceil(rows/64), KS), 4 waves per block; wave w owns weight rows row0+16w .. +15 for the block's K
+// slice, all four share the slice's activations through LDS (64 tokens x 64 columns per step, double-buffered), so
+// a block reads as many activation bytes from L2 as weight bytes from HBM (one strip per block would read 4x).
+// Lane l holds W[row + l%16][k + 4*(l/16) .. +3] (16 bytes; the 4 lanes of a row cover one 64-byte line) and, per
+// 16-token group, X[t0 + l%16][same columns]: MFMA step j multiplies component j of both -- k is a summation
+// index, so any lane->k assignment is valid as long as A and B agree.  Weight loads run one 64-column step ahead
+// of the MFMAs.  Each block writes ONE partial tile P[ks][t][row]; the epilogue kernel adds the KS partials in
+// order (deterministic) and applies the fused tail (RoPE + KV write / residual / SwiGLU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace llmk {
+
+constexpr int PF_TMAX = 64;          // prompt positions per pass (4 MFMA token groups)
+constexpr int PF_WAVES = 4;
+
+typedef float pf_v4f __attribute__((ext_vector_type(4)));
+
+struct PfGemmArgs {
+    const float* W;      // [rows][K]
+    const float* X;      // [T][K]   (activations, L2-resident)
+    float* P;            // [KS][Tp][rows] partial sums, Tp = 16*NG
+    int rows, K, T;
+    int kslice;          // columns per K slice (multiple of PF_KSTEP)
+};
+
+constexpr int PF_KSTEP = 64;                 // columns per pipeline step (4 MFMA chunks of 16)
+constexpr int PF_LDW = PF_KSTEP + 4;         // LDS row pitch in floats (+16 bytes: the 16 tokens of a read spread over banks)
+
+template <int NG>
+__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) {
+    constexpr int TP = NG * 16;
+    __shared__ __attribute__((aligned(16))) float xs[2][TP][PF_LDW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int row0 = blockIdx.x * 64 + wid * 16, ks = blockIdx.y;
+    const int kb = ks * a.kslice, ke = min(a.K, kb + a.kslice);
+    const int nsteps = (ke - kb) / PF_KSTEP;
+    const int li = lane & 15, lk = (lane >> 4) * 4;
+    const bool active = row0 < a.rows;                               // ragged last block: idle waves still take the barriers
+    const float* wp = a.W + (size_t)min(row0 + li, a.rows - 1) * a.K + kb + lk;
+    // activation staging: thread -> (token, 16-byte column group) of the TP x 64 tile, TP*16/256 vectors per thread
+    constexpr int XV = TP * (PF_KSTEP / 4) / (PF_WAVES * WAVE);
+    const float* xg[XV];
+    int xo[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int idx = tid + i * PF_WAVES * WAVE, t = idx / (PF_KSTEP / 4), c4 = idx % (PF_KSTEP / 4);
+        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + kb + c4 * 4;   // pad tokens re-read the last row
+        xo[i] = t * PF_LDW + c4 * 4;
+    }
+
+    pf_v4f acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+
+    // Weights run TWO steps ahead of the MFMAs (a step is ~0.85 us of matrix-core time, loaded-HBM latency ~2 us): three
+    // register stages, and the loop body is written out three times with the stages rotated BY NAME -- rotating them by
+    // copying (wc = wn) makes the copy wait for the load it was supposed to hide.  The asm barriers pin the loads above
+    // the MFMA block (hipcc otherwise sinks the activation loads below it and waits for them at once).
+    float4 w0[4], w1[4], w2[4], xr[XV];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w0[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * 16));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w1[j] = ldg_nt(reinterpret_cast<const float4*>(wp + min(1, nsteps - 1) * PF_KSTEP + j * 16));
+#pragma unroll
+    for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[0][0][0] + xo[i]) = xr[i];
+    __syncthreads();
+
+    auto step = [&](int s, const float4 (&wc)[4], float4 (&wf)[4]) {
+        const int kn = min(s + 1, nsteps - 1) * PF_KSTEP;             // clamped: the loads stay unconditional
+        const int kf = min(s + 2, nsteps - 1) * PF_KSTEP;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = ldg_nt(reinterpret_cast<const float4*>(wp + kf + j * 16));
+#pragma unroll
+        for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + kn);
+        asm volatile("" ::: "memory");
+        const float* xb = &xs[s & 1][0][0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 x[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * 16 + lk);
+            // component-major: the NG accumulators are independent chains the matrix core can interleave
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].x, x[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].y, x[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].z, x[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].w, x[g].w, acc[g], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+        // the other buffer was last read in step s-1, which every wave left through the barrier below
+#pragma unroll
+        for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[(s + 1) & 1][0][0] + xo[i]) = xr[i];
+        __syncthreads();
+    };
+    for (int s = 0; s < nsteps; s += 3) {
+        step(s, w0, w2);
+        if (s + 1 >= nsteps) break;
+        step(s + 1, w1, w0);
+        if (s + 2 >= nsteps) break;
+        step(s + 2, w2, w1);
+    }
+    if (active) {
+        // D layout of 16x16x4: lane l, register v  <->  weight row 4*(l/16)+v, token l%16
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float* dst = a.P + ((size_t)ks * TP + g * 16 + li) * a.rows + row0 + (lane >> 4) * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
+        }
+    }
+}
+
+// x[t] = token_embedding_table(:, token_t)                                              llama2.f90:520
+__global__ void pf_embed_kernel(const float* __restrict__ table, const int* __restrict__ tokens0, float* __restrict__ X, int E) {
+    const int t = blockIdx.y;
+    const float* src = table + (size_t)tokens0[t] * E;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) X[(size_t)t * E + i] = src[i];
+}
+
+// xs[t] = x[t]*w ; xn[t] = sqrt(dot(x,x)/E + 1e-5): the division is applied to the finished row sums    :450-457
+__global__ __launch_bounds__(256) void pf_norm_kernel(const float* __restrict__ X, const float* __restrict__ w,
+                                                      float* __restrict__ Xs, float* __restrict__ xn, int E) {
+    __shared__ float red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const float* x = X + (size_t)t * E;
+    float ss = 0.f;
+    for (int i = tid; i < E; i += 256) {
+        const float v = x[i];
+        ss = fmaf(v, v, ss);
+        Xs[(size_t)t * E + i] = v * w[i];
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) xn[t] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)E + 1e-5f);
+}
+
+struct PfEpiArgs {
+    const float* P;      // [KS][Tp][rows]
+    const float* xn;     // [T] (QKV, SWIGLU) or null
+    float* out;          // QKV: Q [T][E];  RESID: X [T][rows] (+=);  SWIGLU: HB [T][H]
+    float* kc;           // QKV: this layer's caches [S][KV]
+    float* vc;
+    const float* rope;   // [hs/2]
+    int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0
+    int E, KV, hs, H;
+};
+
+__device__ __forceinline__ float pf_sum(const PfEpiArgs& a, int t, int r) {
+    float s = 0.f;
+    for (int ks = 0; ks < a.KS; ++ks) s += a.P[((size_t)ks * a.Tp + t) * a.rows + r];
+    return s;
+}
+
+// one thread per (token, RoPE pair / V pair)                                          llama2.f90:543-565
+__global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (p >= a.rows / 2) return;
+    const int r0 = 2 * p, pos = a.pos0 + t;
+    const float a0 = pf_sum(a, t, r0) / a.xn[t], a1 = pf_sum(a, t, r0 + 1) / a.xn[t];
+    if (r0 < a.E + a.KV) {
+        const int i0 = (r0 < a.E) ? r0 : r0 - a.E;
+        const float rval = (float)pos * a.rope[(i0 % a.hs) >> 1];
+        const float fcr = cosf(rval), fci = sinf(rval);
+        float* dst = (r0 < a.E) ? a.out + (size_t)t * a.E + i0 : a.kc + (size_t)(pos - 1) * a.KV + i0;
+        dst[0] = a0 * fcr - a1 * fci;
+        dst[1] = a0 * fci + a1 * fcr;
+    } else {
+        float* dst = a.vc + (size_t)(pos - 1) * a.KV + (r0 - a.E - a.KV);
+        dst[0] = a0;
+        dst[1] = a1;
+    }
+}
+// x[t][r] += sum                                                                        :603-605, :618-620
+__global__ void pf_epi_resid_kernel(PfEpiArgs a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (r < a.rows) a.out[(size_t)t * a.rows + r] += pf_sum(a, t, r);
+}
+// hb = silu(gate) * up                                                                  :613-616
+__global__ void pf_epi_swiglu_kernel(PfEpiArgs a) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (g >= a.H) return;
+    const float gate = pf_sum(a, t, g) / a.xn[t], up = pf_sum(a, t, g + a.H) / a.xn[t];
+    const float hb = gate * (1.0f / (1.0f + expf(-gate)));
+    a.out[(size_t)t * a.H + g] = hb * up;
+}
+
+}  // namespace llmk

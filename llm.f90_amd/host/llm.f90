@@ -19,6 +19,7 @@ module arg_parse
      integer :: n
      integer :: device            ! extension: HIP device ordinal
      logical :: device_argmax     ! extension: greedy pick on the GPU (SURVEY.md 8f rank 1)
+     logical :: prefill           ! extension: the prompt goes through the model as ONE batched pass (llmk_prefill)
   end type args
 
 contains
@@ -37,6 +38,7 @@ contains
     a%n = 256
     a%device = 0
     a%device_argmax = .false.
+    a%prefill = .false.
 
     nargs = command_argument_count()
     i = 1
@@ -54,6 +56,7 @@ contains
        case ("-v", "--verbose");     a%verbose = .true.;       i = i + 1
        case ("--ak");                a%ak = .true.;            i = i + 1
        case ("--device-argmax");     a%device_argmax = .true.; i = i + 1
+       case ("--prefill");           a%prefill = .true.;       i = i + 1
        case default
           print *, "Unrecognized option:", trim(opt)
           stop
@@ -85,6 +88,8 @@ program llm
   character(:), dimension(:), allocatable :: vocab
   integer(4), allocatable :: vocab_len(:)
   integer, allocatable :: prompt_tokens(:)
+  integer(c_int), allocatable :: batch(:)
+  integer :: pos0, k
   integer :: seq_len, pos, token, next_tok, l, hs, j, max_len
   integer(c_int) :: flags, rc
   real(kind=wp) :: t_start, t_end
@@ -138,7 +143,29 @@ program llm
   ! ---- generation loop (llama2.f90:376-402) -------------------------------------------------------
   t_start = 0
   token = 2                                          ! BOS: 1-based index of <s>
-  do pos = 1, seq_len
+  pos0 = 1
+  if (opts%prefill .and. size(prompt_tokens) > 0 .and. size(prompt_tokens) < seq_len) then
+     ! positions 1 .. k+1 of the loop below (BOS, then the k prompt tokens) in one call: same cache, same logits
+     ! at position k+1, same text on stdout
+     k = size(prompt_tokens)
+     allocate(batch(k + 1))
+     batch(1) = 2
+     batch(2:) = int(prompt_tokens, c_int)
+     call llmk_check(llmk_prefill(ctx, batch, int(k + 1, c_int), 1_c_int, logits), "llmk_prefill")
+     do pos = 1, k
+        write (*, fmt="(A)", advance="no") vocab(prompt_tokens(pos))(1:vocab_len(prompt_tokens(pos)))
+     end do
+     t_start = time_ms()
+     if (opts%temperature == 0) then
+        token = maxloc(logits, dim=1)
+     else
+        probs = softmax_t(logits / opts%temperature)
+        token = sample(probs)
+     end if
+     write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
+     pos0 = k + 2
+  end if
+  do pos = pos0, seq_len
      if (opts%device_argmax .and. opts%temperature == 0 .and. pos > size(prompt_tokens)) then
         call llmk_check(llmk_forward_greedy(ctx, int(token, c_int), int(pos, c_int), rc), "llmk_forward_greedy")
         next_tok = rc

@@ -51,6 +51,13 @@ module llmk_binding
        integer(c_int), value :: token, pos
        real(c_float), intent(out) :: logits(*)
      end function
+     integer(c_int) function llmk_prefill(ctx, tokens, n, pos0, logits) bind(C, name="llmk_prefill")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(in) :: tokens(*)
+       integer(c_int), value :: n, pos0
+       real(c_float), intent(out) :: logits(*)
+     end function
      integer(c_int) function llmk_forward_greedy(ctx, token, pos, next_token) bind(C, name="llmk_forward_greedy")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

@@ -22,7 +22,7 @@ FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 # every symbol include/llmk.h declares
 SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
-           "llmk_set_rope_freqs", "llmk_forward", "llmk_forward_greedy", "llmk_reset", "llmk_timings",
+           "llmk_set_rope_freqs", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_reset", "llmk_timings",
            "llmk_time_kernel", "llmk_peek", "llmk_destroy", "llmk_strerror", "llmk_version"]
 
 
@@ -66,6 +66,7 @@ def lib():
         L.llmk_upload_rows.argtypes = [vp, ci, ci, ci, ci, vp, C.c_size_t, ci]
         L.llmk_set_rope_freqs.argtypes = [vp, cf, ci]
         L.llmk_forward.argtypes = [vp, ci, ci, cf]
+        L.llmk_prefill.argtypes = [vp, C.POINTER(ci), ci, ci, cf]
         L.llmk_forward_greedy.argtypes = [vp, ci, ci, C.POINTER(ci)]
         L.llmk_reset.argtypes = [vp]
         L.llmk_timings.argtypes = [vp, cf]
@@ -123,6 +124,13 @@ class Llmk:
     def forward_raw(self, token: int, pos: int) -> int:
         """Hot loop for bench.py: no copy of the result, returns the status code."""
         return lib().llmk_forward(self._h, token, pos, self._logits.ctypes.data_as(C.POINTER(C.c_float)))
+
+    def prefill(self, tokens, pos0: int = 1) -> np.ndarray:
+        """tokens (1-based ids) at positions pos0.. in one call; logits of the last position (llama2.f90:376-402)."""
+        t = np.ascontiguousarray(tokens, np.int32)
+        _ck(lib().llmk_prefill(self._h, t.ctypes.data_as(C.POINTER(C.c_int)), len(t), pos0,
+                               self._logits.ctypes.data_as(C.POINTER(C.c_float))))
+        return self._logits.copy()
 
     def forward_greedy(self, token: int, pos: int) -> int:
         nxt = C.c_int(0)

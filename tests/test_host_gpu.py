@@ -81,3 +81,16 @@ def test_cli_ak_format_matches_reference_transcript(gguf, tmp_path):
     ref = bytes(g["stdout"]).split(b"\n")
     k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
     assert out[:k] == ref[:k]
+
+
+@pytest.mark.parametrize("tag", ["tiny-gqa-prompt", "tk-small-prompt"])
+def test_cli_prefill_flag_prints_the_reference_transcript(tag, gguf, tmp_path):
+    """`--prefill`: the prompt goes through llmk_prefill in one batched pass; stdout up to the timing report must
+    still be what the real reference printed feeding the prompt token by token."""
+    g = load_golden(tag)
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+    out = _run(["-m", path, "-n", str(int(g["n"])), "-t", "0", "-p", str(g["prompt"]), "--prefill"], str(tmp_path)).split(b"\n")
+    ref = bytes(g["stdout"]).split(b"\n")
+    k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
+    assert out[:k] == ref[:k]

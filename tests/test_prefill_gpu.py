@@ -1,0 +1,119 @@
+"""Batched prompt prefill (llmk_prefill): one call must leave behind what the reference's
+token-by-token prompt loop (llama2.f90:376-402) leaves -- the KV cache rows of the prompt positions and the logits
+of the last one -- within the 1e-4 relative parity bar, and generation must continue with identical token ids."""
+import numpy as np
+import pytest
+
+from conftest import REL_TOL, load_golden, rel_err
+from llm_f90_amd import llmk
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def continue_greedy(m, first_logits, pos_next, n):
+    """greedy loop from the logits of the last prefilled position: returns tokens and logits of the next n positions"""
+    toks, lgs = [], []
+    tok = int(np.argmax(first_logits)) + 1
+    for pos in range(pos_next, pos_next + n):
+        toks.append(tok)
+        lg = m.forward(tok, pos)
+        lgs.append(lg)
+        tok = int(np.argmax(lg)) + 1
+    return np.asarray(toks, np.int32), np.asarray(lgs)
+
+
+@pytest.mark.parametrize("tag", ["tiny-gqa-prompt", "tk-small-prompt"])
+def test_prefill_matches_reference_golden(tag, gguf):
+    """The REAL reference's run on a prompt: prefill [BOS, prompt...] in one call, then decode the rest."""
+    g = load_golden(tag)
+    fw = gguf.synth_fused(gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+    pids = g["prompt_ids"].tolist()
+    k, n = len(pids), int(g["n"])
+    m = llmk.Llmk(fw)
+    lg = m.prefill([2] + pids, 1)                       # positions 1..k+1
+    assert rel_err(lg[None], g["logits"][k][None]).max() <= REL_TOL
+    toks, lgs = continue_greedy(m, lg, k + 2, n - k - 1)
+    assert np.array_equal(toks, g["tokens"][k:n - 1])   # tokens[k] is the first sampled one
+    assert rel_err(lgs, g["logits"][k + 1:n]).max() <= REL_TOL
+    m.close()
+
+
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 1), ("tiny-gqa", 17), ("tiny-mha", 33), ("tiny-hs64", 40), ("tiny-hs128", 20),
+                                     ("tiny-70bish", 24)])
+def test_prefill_matches_oracle(shape, n, gguf):
+    """seeded pseudo-prompts of ragged lengths (1, 17, 33 ... not multiples of the 16-token MFMA group)"""
+    s = gguf.SHAPES[shape]
+    fw = gguf.synth_fused(s, 777)
+    rng = np.random.default_rng(5)
+    prompt = [2] + (rng.integers(3, s.vocab_size, n - 1) + 1).tolist()
+    o = Oracle(fw, "omp")
+    ol = None
+    for pos, tok in enumerate(prompt, 1):
+        ol = o.forward(tok, pos)
+    m = llmk.Llmk(fw)
+    lg = m.prefill(prompt, 1)
+    assert rel_err(lg[None], ol[None]).max() <= REL_TOL
+    m.close()
+
+
+def test_prefill_in_two_calls_and_after_decode(gguf):
+    """prefill may start at any position: decode 5 tokens, prefill 20 more, compare with the all-sequential run"""
+    s = gguf.SHAPES["tiny-gqa"]
+    fw = gguf.synth_fused(s, 31)
+    rng = np.random.default_rng(9)
+    seq = [2] + (rng.integers(3, s.vocab_size, 29) + 1).tolist()
+    a = llmk.Llmk(fw)
+    for pos, tok in enumerate(seq, 1):
+        ref = a.forward(tok, pos)
+    b = llmk.Llmk(fw)
+    for pos in range(1, 6):
+        b.forward(seq[pos - 1], pos)
+    b.prefill(seq[5:18], 6)
+    lg = b.prefill(seq[18:], 19)
+    assert rel_err(lg[None], ref[None]).max() <= REL_TOL
+    a.close(); b.close()
+
+
+def test_prefill_tinyllama_long_prompt_vs_sequential(gguf):
+    """BASELINE.json's shape, a 150-token prompt (three batches: 64 + 64 + 22), then 8 decoded tokens on the token kernel"""
+    s = gguf.SHAPES["tinyllama"]
+    fw = gguf.synth_fused(s, 20260928)
+    rng = np.random.default_rng(1)
+    prompt = [2] + (rng.integers(3, s.vocab_size, 149) + 1).tolist()
+    a = llmk.Llmk(fw)
+    for pos, tok in enumerate(prompt, 1):
+        ref = a.forward(tok, pos)
+    rt, rl = continue_greedy(a, ref, len(prompt) + 1, 8)
+    b = llmk.Llmk(fw)
+    lg = b.prefill(prompt, 1)
+    assert rel_err(lg[None], ref[None]).max() <= REL_TOL
+    t, l = continue_greedy(b, lg, len(prompt) + 1, 8)
+    assert np.array_equal(t, rt)
+    assert rel_err(l, rl).max() <= REL_TOL
+    a.close(); b.close()
+
+
+def test_prefill_argument_errors(gguf):
+    s = gguf.SHAPES["tiny-gqa"]
+    m = llmk.Llmk(gguf.synth_fused(s, 1))
+    with pytest.raises(llmk.LlmkError):
+        m.prefill([2, 0, 5], 1)                          # token id out of range
+    with pytest.raises(llmk.LlmkError):
+        m.prefill([2] * 4, s.seq_len - 2)                # runs past the context
+    with pytest.raises(llmk.LlmkError):
+        m.prefill([], 1)
+    m.close()
+
+
+@pytest.mark.parametrize("wtype", [1, 2], ids=["f16", "q4_0"])
+def test_prefill_other_weight_types_fall_back(wtype, gguf):
+    """f16 / q4_0 contexts take the token-by-token pass inside llmk_prefill: same answer as llmk_forward"""
+    fw = gguf.synth_fused(gguf.SHAPES["tiny-gqa"], 4242, wtype)
+    prompt = [2, 40, 41, 42, 43]
+    a = llmk.Llmk(fw)
+    for pos, tok in enumerate(prompt, 1):
+        ref = a.forward(tok, pos)
+    b = llmk.Llmk(fw)
+    assert np.array_equal(b.prefill(prompt, 1), ref)
+    a.close(); b.close()
