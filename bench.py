@@ -164,6 +164,46 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep):
     return m
 
 
+def prefill_line(a):
+    """`--prefill N`: prompt tokens/s of llmk_prefill (batched MFMA GEMMs) next to the token-by-token loop it replaces.
+    Roofline of its dominant kernel, the w1|w3 GEMM at 64 positions: f32 matrix-core peak (157.3 TFLOP/s,
+    MI355X_MICROARCH.md) -- at 64 positions per pass the GEMM is MFMA-bound (2*64 flop per 4-byte weight = 32 flop/B)."""
+    shape = gguf.SHAPES[a.shape]
+    n = a.prefill
+    if a.type != "f32" or n < 1 or n + 1 > shape.seq_len:
+        raise SystemExit("--prefill N: f32 weights, N < seq_len")
+    m = llmk.Llmk(gguf.synth_fused(shape, SEED, 0))
+    rng = np.random.default_rng(SEED)
+    prompt = [2] + (rng.integers(3, shape.vocab_size, n - 1) + 1).tolist()
+    for _ in range(max(1, a.warmup // 4)):
+        m.reset(); m.prefill(prompt, 1)
+    reps = max(3, min(20, 2000 // n))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lg = m.prefill(prompt, 1)
+    dt = (time.perf_counter() - t0) / reps
+    m.reset()
+    t0 = time.perf_counter()
+    nseq = min(n, 64)
+    for pos in range(1, nseq + 1):
+        m.forward(prompt[pos - 1], pos)
+    dt_seq = (time.perf_counter() - t0) / nseq
+    ms, wbytes = m.time_kernel(7, 66)
+    flop = 2.0 * 64 * wbytes / 4.0
+    out = {"metric": f"prompt tokens/sec {a.shape} prefill", "value": n / dt, "unit": "tokens/s", "n_gpus": 1,
+           "steps": reps, "warmup": max(1, a.warmup // 4), "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{a.shape} f32 prefill of a {n}-token prompt (llmk_prefill, 64 positions per pass)",
+                      "token_by_token_tok_s": 1.0 / dt_seq, "speedup": (n / dt) * dt_seq, "seed": SEED},
+           "roofline": {"bound": "mfma", "kernel": "pf_gemm_kernel<4> (w1|w3, 64 positions, v_mfma_f32_16x16x4_f32)",
+                        "achieved": flop / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                        "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "us_per_launch": ms * 1000.0,
+                        "flop_per_launch": flop, "weight_bytes_per_launch": wbytes,
+                        "hbm_GBps": wbytes / (ms * 1e-3) / 1e9}}
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,7 +218,11 @@ def main():
                     help="tensor-parallel: ONE model sharded over the N ranks (RCCL all-reduce), the 70B configuration; "
                          "default for N>1 is N independent replicas")
     ap.add_argument("--greedy-on-device", action="store_true", help="time llmk_forward_greedy instead")
+    ap.add_argument("--prefill", type=int, default=0, metavar="N",
+                    help="auxiliary line (not the headline metric): time llmk_prefill on an N-token prompt (SURVEY.md 8f rank 1)")
     a = ap.parse_args()
+    if a.prefill:
+        return prefill_line(a)
 
     # The contract is ONE JSON line on stdout.  RCCL (torch's, and ours in --tp mode) prints a version banner
     # through C stdio to fd 1 whenever a communicator is created, so everything this process or its

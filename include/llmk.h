@@ -164,7 +164,8 @@ int llmk_timings(llmk_ctx *ctx, float ms[5]);
  * ctx's stream with HIP events around them and returns the average milliseconds per launch and
  * the algorithmic bytes one launch moves.  kernel: 0 qkv, 1 attention, 2 wo, 3 w13, 4 w2,
  * 5 classifier (successive launches walk the layers), 6 the persistent whole-token kernel
- * (LLMK_E_ARG when the ctx runs the multi-kernel path). */
+ * (LLMK_E_ARG when the ctx runs the multi-kernel path), 7 the w1|w3 GEMM of llmk_prefill at 64 positions
+ * (bytes = the layer's w1|w3 weights; flop = 2 * 64 * bytes / 4). */
 int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double *bytes_per_launch);
 
 /* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),

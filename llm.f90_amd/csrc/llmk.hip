@@ -876,9 +876,15 @@ int llmk_timings(llmk_ctx* c, float ms[5]) {
 int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* bytes_per_launch) {
     int rc = check_ready(c);
     if (rc) return rc;
-    if (kernel < 0 || kernel > 6 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
+    if (kernel < 0 || kernel > 7 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
     if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (kernel == 7) {   // the prefill w1|w3 GEMM at PF_TMAX positions (whatever the workspaces hold: timing only)
+        if (c->cfg.weight_type != LLMK_TYPE_F32 || c->tp_size != 1 || c->E % PF_KSTEP || c->H % PF_KSTEP) return LLMK_E_ARG;
+        rc = pf_setup(c);
+        if (rc) return rc;
+        HIPCHK(hipMemsetAsync(c->pf_Xs, 0, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
+    }
     // Successive launches walk the layers so the weight stream never re-hits the 256 MiB Infinity
     // Cache (the classifier has one matrix: its figure is cache-assisted beyond the first launch).
     // NOTE: this overwrites x / caches at h_tokpos' position; call llmk_reset afterwards.
@@ -889,6 +895,10 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
         if (kernel == 6) {  // whole-token kernel: fresh exchange epochs for every launch
             hipLaunchKernelGGL(bump_serial_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tokpos);
             return launch_token_kernel(c);
+        }
+        if (kernel == 7) {
+            int ks;
+            return pf_gemm(c, (const float*)c->t[LLMK_W13].data + (size_t)l * 2 * c->H * c->E, c->pf_Xs, 2 * c->H, c->E, PF_TMAX, &ks);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);
@@ -908,7 +918,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
     *avg_ms = ms / (float)iters;
     if (bytes_per_launch) {
-        const int tids[7] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS, -1};
+        const int tids[8] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS, -1, LLMK_W13};
         double b = 0;
         if (kernel == 6) {
             double w = 0;

@@ -14,8 +14,7 @@
 // a block reads as many activation bytes from L2 as weight bytes from HBM (one strip per block would read 4x).
 // Lane l holds W[row + l%16][k + 4*(l/16) .. +3] (16 bytes; the 4 lanes of a row cover one 64-byte line) and, per
 // 16-token group, X[t0 + l%16][same columns]: MFMA step j multiplies component j of both -- k is a summation
-// index, so any lane->k assignment is valid as long as A and B agree.  Weight loads run one 64-column step ahead
-// of the MFMAs.  Each block writes ONE partial tile P[ks][t][row]; the epilogue kernel adds the KS partials in
+// index, so any lane->k assignment is valid as long as A and B agree.  Loads run one 64-column step ahead of the MFMAs.  Each block writes ONE partial tile P[ks][t][row]; the epilogue kernel adds the KS partials in
 // order (deterministic) and applies the fused tail (RoPE + KV write / residual / SwiGLU).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -66,57 +65,48 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
 
-    // Weights run TWO steps ahead of the MFMAs (a step is ~0.85 us of matrix-core time, loaded-HBM latency ~2 us): three
-    // register stages, and the loop body is written out three times with the stages rotated BY NAME -- rotating them by
-    // copying (wc = wn) makes the copy wait for the load it was supposed to hide.  The asm barriers pin the loads above
-    // the MFMA block (hipcc otherwise sinks the activation loads below it and waits for them at once).
-    float4 w0[4], w1[4], w2[4], xr[XV];
+    // Weights and activations of step s+1 are requested before the MFMAs of step s (one register stage ahead).
+    // Measured alternatives on MI355X (w1|w3 GEMM, 64 positions): this form 47 us; two stages ahead with the
+    // stages rotated by name (loop written out three times) 77 us -- 150 registers, 3 waves/SIMD instead of 4.
+    float4 wc[4], wn[4], xr[XV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w0[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * 16));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w1[j] = ldg_nt(reinterpret_cast<const float4*>(wp + min(1, nsteps - 1) * PF_KSTEP + j * 16));
+    for (int j = 0; j < 4; ++j) wc[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * 16));
 #pragma unroll
     for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
 #pragma unroll
     for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[0][0][0] + xo[i]) = xr[i];
     __syncthreads();
 
-    auto step = [&](int s, const float4 (&wc)[4], float4 (&wf)[4]) {
+    for (int s = 0; s < nsteps; ++s) {
         const int kn = min(s + 1, nsteps - 1) * PF_KSTEP;             // clamped: the loads stay unconditional
-        const int kf = min(s + 2, nsteps - 1) * PF_KSTEP;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = ldg_nt(reinterpret_cast<const float4*>(wp + kf + j * 16));
+        for (int j = 0; j < 4; ++j) wn[j] = ldg_nt(reinterpret_cast<const float4*>(wp + kn + j * 16));
 #pragma unroll
         for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + kn);
-        asm volatile("" ::: "memory");
         const float* xb = &xs[s & 1][0][0];
+        if (active) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 x[NG];
+            for (int j = 0; j < 4; ++j) {
+                float4 x[NG];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * 16 + lk);
-            // component-major: the NG accumulators are independent chains the matrix core can interleave
+                for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * 16 + lk);
+                // component-major: the NG accumulators are independent chains the matrix core can interleave
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].x, x[g].x, acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].x, x[g].x, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].y, x[g].y, acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].y, x[g].y, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].z, x[g].z, acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].z, x[g].z, acc[g], 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].w, x[g].w, acc[g], 0, 0, 0);
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].w, x[g].w, acc[g], 0, 0, 0);
+            }
         }
-        asm volatile("" ::: "memory");
         // the other buffer was last read in step s-1, which every wave left through the barrier below
 #pragma unroll
         for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[(s + 1) & 1][0][0] + xo[i]) = xr[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wc[j] = wn[j];
         __syncthreads();
-    };
-    for (int s = 0; s < nsteps; s += 3) {
-        step(s, w0, w2);
-        if (s + 1 >= nsteps) break;
-        step(s + 1, w1, w0);
-        if (s + 2 >= nsteps) break;
-        step(s + 2, w2, w1);
     }
     if (active) {
         // D layout of 16x16x4: lane l, register v  <->  weight row 4*(l/16)+v, token l%16
