@@ -1,16 +1,16 @@
 // Persistent whole-token kernel for gfx950: the complete `transformer` pass
-// (/root/reference/llama2.f90:480-640) in ONE launch, one 16-wave workgroup per CU.
+// (/root/reference/llama2.f90:480-640) in ONE launch, one 8-wave workgroup per CU.
 //
 // Why: with one kernel per GEMV the token is bounded by ~1.55 us of boundary + ramp per launch
 // (5 launches per layer) -- the weight stream stops at every dependency.  Weights
-// do not depend on activations, so here the stream never stops: each of the 15 STREAMING waves of
-// a CU walks a static list of 8 KB row tiles (its share of qkv, wo, w1|w3, w2 of every layer, then
-// the classifier) and always has two tiles requested ahead in registers (non-temporal 16-byte
-// loads), across phase boundaries.  The one SERVICE wave per CU never touches the weight stream
-// (so its polls are not queued behind 16 KB of outstanding loads -- vmcnt retires in order): it
+// do not depend on activations, so here the stream never stops: each of the 7 STREAMING waves of a CU
+// walks a static list of 8 KB row tiles (its share of qkv, wo, w1|w3, w2 of every layer, then the
+// classifier) and always has TK_NB tiles requested ahead in registers (non-temporal 16-byte loads),
+// across phase and layer boundaries.  The one SERVICE wave per CU never touches the weight stream
+// (so its polls are not queued behind 40 KB of outstanding loads -- vmcnt retires in order): it
 // gathers the phase's input vector from the exchange buffers into LDS, applies rmsnorm, and after
 // the streaming waves have dotted their tiles against it, runs the epilogue (RoPE / SwiGLU /
-// residual) and publishes the CU's 8-44 outputs.
+// residual) and publishes the CU's outputs.
 //
 // Exchange = 8-byte {value, epoch-tag} granules written with ONE agent-scope (sc1, write-through)
 // store and swept with agent-scope loads until every tag matches: no flags, no fences, placement
@@ -18,9 +18,12 @@
 // (token serial, phase), so buffers are never reset.  Every spin is bounded; a timeout raises a
 // sticky error word and lets the kernel drain.
 //
-// Work split per phase, CU c of NCU: rows [c*R/NCU, (c+1)*R/NCU) of the phase's matrix; tile t of
-// that range goes to streaming wave t % 15.  A tile is one row x up to 2048 columns; its wave-
-// reduced partial dot goes to LDS and the service wave folds the parts of a row.
+// Work split per phase: CU c owns a contiguous row range of the phase's matrix (w1|w3, w2 and the
+// classifier: R/256 rows each; QKV and wo: split over the 224 CUs that do NOT run attention, see
+// TkShape); tile t of that range goes to streaming wave t % 7.  A tile is one row x up to 2048
+// columns; its wave-reduced partial dot goes to LDS and the service wave folds the parts of a row.
+// The x fragment a wave dots its tiles against is the same for every tile of a phase and lives in
+// registers (TkX).  DESIGN.md section 3b has the measurements behind each of these choices.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,7 +34,7 @@ namespace llmk {
 
 constexpr int TK_NCU = 256;               // one workgroup per CU
 constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
-constexpr int TK_NB = 5;                  // register tiles a streaming wave keeps requested ahead (4 x 8 KB)
+constexpr int TK_NB = 5;                  // register tiles a streaming wave keeps requested ahead (5 x 8 KB)
 constexpr int TK_NS = TK_WAVES - 1;
 constexpr int TK_THREADS = TK_WAVES * WAVE;
 constexpr int TK_TCOLS = 8;               // 16-byte vector columns per tile (8 x 64 lanes x 4 floats = 2048)
@@ -91,8 +94,6 @@ struct TkShape {
     // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
     static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D + NW_D - 1) / NW_D;
     static constexpr int SL_LAYER = SL_Q + SL_O + SL_A + SL_D;
-    static constexpr int NC_E_LAST = E / 4 / WAVE - (TPR_E - 1) * TK_TCOLS;  // columns in a row's last tile
-    static constexpr int NC_H_LAST = H / 4 / WAVE - (TPR_H - 1) * TK_TCOLS;
     static constexpr int MAXP = (NT_A > NT_C ? NT_A : NT_C) > NT_D ? (NT_A > NT_C ? NT_A : NT_C) : NT_D;
     static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % TK_NCU == 0, "rows must split over CUs");
     static_assert(E % 256 == 0 && H % 256 == 0, "rows are whole 1 KB segments");
@@ -177,35 +178,12 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
         __builtin_amdgcn_s_sleep(1);
     }
 }
-// Cheap wait ahead of a sweep that is known to be far off (the attention output): ONE 16-byte load per lane,
-// a sample of N/128-strided granule pairs that touches every producer, instead of re-reading all N granules
-// per pass -- 224 idle CUs sweeping 16 KB each every microsecond is memory traffic the attention CUs and the
-// weight prefetch pay for.
 template <int N>
-__device__ __forceinline__ bool tk_prepoll(__amdgpu_buffer_rsrc_t rs, unsigned epoch, unsigned* err, int lane, bool nowait) {
-    constexpr int STRIDE = N / 128;
-    for (unsigned spin = 0;; ++spin) {
-        const tk_v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * STRIDE * 16, 0, 16);
-        if (__all((r.y == epoch) & (r.w == epoch)) || nowait) return true;
-        if ((spin & 63) == 63) {
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (spin > TK_SPIN_LIMIT) {
-                if (lane == 0) __hip_atomic_store(err, 0x300u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-template <int N, bool PREPOLL = false>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
                                           int lane, bool nowait = false, unsigned long long* dbg = nullptr) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
-    if constexpr (PREPOLL) {
-        if (!tk_prepoll<N>(rs, epoch, err, lane, nowait)) return false;
-    }
     if constexpr (NL <= 24) {
         return tk_gather_part<NL>(rs, 0, epoch, dst, err, lane, nowait, dbg);
     } else {      // long vectors in two register-sized halves
@@ -254,7 +232,6 @@ struct TkNorm {
 // vmcnt(24) and leaves the three younger tiles in flight; a skipped load would force vmcnt(0).
 struct TkTile {
     const float4* p;  // row base + first column of the tile (the zero block when the slot is empty)
-    int xoff;         // float4 offset of the tile's first column in xs
     int ncol;         // real vector columns (0..8); columns >= ncol read zeros
     int pidx;         // partial index (tile index within the CU's phase; MAXP = junk slot)
 };
@@ -266,22 +243,8 @@ __device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t,
         b[j] = ldg_nt(pj + lane);
     }
 }
-// per-lane partial dot of one tile: four independent FMA chains (x,y,z,w) instead of one 32-deep chain
-__device__ __forceinline__ float tk_dot_tile(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, int lane) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < TK_TCOLS; ++j) {
-        const int xj = (j < t.ncol) ? t.xoff + j * WAVE : 0;      // zero weights: any finite x will do
-        const float4 x = xs[xj + lane];
-        acc.x = fmaf(b[j].x, x.x, acc.x);
-        acc.y = fmaf(b[j].y, x.y, acc.y);
-        acc.z = fmaf(b[j].z, x.z, acc.z);
-        acc.w = fmaf(b[j].w, x.w, acc.w);
-    }
-    return (acc.x + acc.y) + (acc.z + acc.w);
-}
 // Phases whose rows are ONE tile wide (K = E <= 2048) dot every tile against the same x fragment: it is read
-// from LDS once per phase into registers (XR), not once per tile -- 7 waves x 8 KB of ds_read per slot was
+// from LDS once per phase into registers, not once per tile -- 7 waves x 8 KB of ds_read per slot was
 // ~0.2 us of LDS time in the middle of every slot of the critical path.
 struct TkX {
     float4 v[TK_TCOLS];
@@ -301,26 +264,20 @@ struct TkX {
         }
     }
 };
-template <bool XR>
-__device__ __forceinline__ float tk_dot(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, const TkX& x, int lane) {
-    if constexpr (XR) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+// per-lane partial dot of one tile: four independent FMA chains (x,y,z,w) instead of one 32-deep chain
+__device__ __forceinline__ float tk_dot(const float4 (&b)[TK_TCOLS], const TkX& x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < TK_TCOLS; ++j) {
-            acc.x = fmaf(b[j].x, x.v[j].x, acc.x);
-            acc.y = fmaf(b[j].y, x.v[j].y, acc.y);
-            acc.z = fmaf(b[j].z, x.v[j].z, acc.z);
-            acc.w = fmaf(b[j].w, x.v[j].w, acc.w);
-        }
-        return (acc.x + acc.y) + (acc.z + acc.w);
-    } else {
-        return tk_dot_tile(b, t, xs, lane);
+    for (int j = 0; j < TK_TCOLS; ++j) {
+        acc.x = fmaf(b[j].x, x.v[j].x, acc.x);
+        acc.y = fmaf(b[j].y, x.v[j].y, acc.y);
+        acc.z = fmaf(b[j].z, x.v[j].z, acc.z);
+        acc.w = fmaf(b[j].w, x.v[j].w, acc.w);
     }
+    return (acc.x + acc.y) + (acc.z + acc.w);
 }
-template <bool XR>
-__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const float4* xs, const TkX& x,
-                                           float* part, int lane) {
-    const float acc = wave_sum(tk_dot<XR>(b, t, xs, x, lane));
+__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const TkX& x, float* part, int lane) {
+    const float acc = wave_sum(tk_dot(b, x));
     if (lane == 0) part[t.pidx] = acc;
 }
 
@@ -337,7 +294,7 @@ struct TkSched {
 template <int JUNK>
 __device__ __forceinline__ TkTile tk_null(const float4* zp) {
     TkTile t;
-    t.p = zp; t.xoff = 0; t.ncol = 0; t.pidx = JUNK;
+    t.p = zp; t.ncol = 0; t.pidx = JUNK;
     return t;
 }
 
@@ -346,7 +303,6 @@ __device__ __forceinline__ TkTile tk_mk(const float* mat, long long row, int ti,
     TkTile t;
     const bool live = ti < NT;
     const int part = (TPR == 1) ? 0 : ti % TPR;
-    t.xoff = live ? part * TK_TCOLS * WAVE : 0;
     t.ncol = live ? min(TK_TCOLS, K_ / 4 / WAVE - part * TK_TCOLS) : 0;
     t.p = live ? reinterpret_cast<const float4*>(mat + row * K_) + part * TK_TCOLS * WAVE : zp;
     t.pidx = live ? ti : JUNK;
@@ -358,7 +314,6 @@ template <class SH>
 __device__ __forceinline__ TkTile tk_row_tile(const float* mat, long long row0, int ti, int n, const float4* zp) {
     TkTile t;
     const bool live = ti < n;
-    t.xoff = 0;
     t.ncol = live ? min(TK_TCOLS, SH::E / 4 / WAVE) : 0;
     t.p = live ? reinterpret_cast<const float4*>(mat + (row0 + ti) * SH::E) : zp;
     t.pidx = live ? ti : SH::MAXP;
@@ -400,7 +355,6 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
             const int row = (K - SC::KD) * nw + sw / P;
             const bool live = row < SH::R_D;
             TkTile t;
-            t.xoff = part * TK_TCOLS * WAVE;
             t.ncol = live ? min(TK_TCOLS, SH::H / 4 / WAVE - part * TK_TCOLS) : 0;
             t.p = live ? reinterpret_cast<const float4*>(a.w2 + ((long long)l * SH::E + c * SH::R_D + row) * SH::H) + part * TK_TCOLS * WAVE : a.zeros;
             t.pidx = live ? row * P + part : SH::MAXP;
@@ -737,16 +691,15 @@ struct TkRing {
 };
 
 // slots K .. K+N-1 (compile-time) of layer l: consume ring entry K % NB, refill it with slot K + NB
-template <class SH, int K, int N, bool CLS, bool XR>
-__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4, const TkX& x,
-                                       float* part, int lane) {
+template <class SH, int K, int N, bool CLS>
+__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const TkX& x, float* part, int lane) {
     if constexpr (N > 0) {
         constexpr int R = K % TK_NB;
-        tk_consume<XR>(r.b[R], r.t[R], xs4, x, part, lane);
+        tk_consume(r.b[R], r.t[R], x, part, lane);
         if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
         else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
         tk_issue(r.b[R], r.t[R], a.zeros, lane);
-        tk_run<SH, K + 1, N - 1, CLS, XR>(r, a, l, c, sw, xs4, x, part, lane);
+        tk_run<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, x, part, lane);
     }
 }
 // consume only / refill only: a phase's LAST min(NB, slots) slots are dotted first, the partial sums
@@ -755,12 +708,12 @@ __device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int
 // between the dot products and the publish of the phase's result.
 // N tiles at once: all per-lane dots first, then the N wave reductions (independent DPP chains the
 // scheduler can interleave), then ONE lane-0 block of LDS writes
-template <class SH, int K, int N, bool XR>
-__device__ __forceinline__ void tk_eat(const TkRing& r, const float4* xs4, const TkX& x, float* part, int lane) {
+template <class SH, int K, int N>
+__device__ __forceinline__ void tk_eat(const TkRing& r, const TkX& x, float* part, int lane) {
     if constexpr (N > 0) {
         float v[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = tk_dot<XR>(r.b[(K + i) % TK_NB], r.t[(K + i) % TK_NB], xs4, x, lane);
+        for (int i = 0; i < N; ++i) v[i] = tk_dot(r.b[(K + i) % TK_NB], x);
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
         if (lane == 0) {
@@ -781,16 +734,16 @@ __device__ __forceinline__ void tk_refill(TkRing& r, const TokenArgs& a, int l, 
 }
 // one phase of S slots starting at slot K0: [barrier A] early slots (consume+refill), late slots
 // (consume), [barrier B], late refills
-template <class SH, int K0, int S, bool CLS, bool XR, bool WIDE = false>
+template <class SH, int K0, int S, bool CLS, bool WIDE = false>
 __device__ __forceinline__ void tk_phase(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
                                          float* part, int lane) {
     constexpr int LATE = S < TK_NB ? S : TK_NB, EARLY = S - LATE;
     tk_barrier();
     TkX x;
-    if constexpr (XR && WIDE) x.template load_part<SH::H>(xs4, sw % SH::TPR_H, lane);
-    else if constexpr (XR) x.template load<SH::E / 4 / WAVE>(xs4, lane);
-    tk_run<SH, K0, EARLY, CLS, XR>(r, a, l, c, sw, xs4, x, part, lane);
-    tk_eat<SH, K0 + EARLY, LATE, XR>(r, xs4, x, part, lane);
+    if constexpr (WIDE) x.template load_part<SH::H>(xs4, sw % SH::TPR_H, lane);
+    else x.template load<SH::E / 4 / WAVE>(xs4, lane);
+    tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
+    tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
     tk_barrier();
     tk_refill<SH, K0 + EARLY, LATE, CLS>(r, a, l, c, sw, lane);
 }
@@ -818,7 +771,6 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
 
-    constexpr bool XR = SH::TPR_E == 1;   // a row of the K = E matrices is one tile: x fragment lives in registers
     TkRing r;
     tk_prime<SH, 0>(r, a, c, sw, lane);
 
@@ -828,9 +780,9 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             constexpr int LATE = SH::SL_Q < TK_NB ? SH::SL_Q : TK_NB, EARLY = SH::SL_Q - LATE;
             tk_barrier();
             TkX x;
-            if constexpr (XR) x.template load<SH::E / 4 / WAVE>(xs4, lane);
-            tk_run<SH, SC::KQ, EARLY, false, XR>(r, a, l, c, sw, xs4, x, part, lane);
-            tk_eat<SH, SC::KQ + EARLY, LATE, XR>(r, xs4, x, part, lane);
+            x.template load<SH::E / 4 / WAVE>(xs4, lane);
+            tk_run<SH, SC::KQ, EARLY, false>(r, a, l, c, sw, x, part, lane);
+            tk_eat<SH, SC::KQ + EARLY, LATE>(r, x, part, lane);
             tk_barrier();
             if (att_cu) {
                 TkAtt<SH> pa;
@@ -841,12 +793,12 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             }
             tk_refill<SH, SC::KQ + EARLY, LATE, false>(r, a, l, c, sw, lane);
         }
-        tk_phase<SH, SC::KO, SH::SL_O, false, XR>(r, a, l, c, sw, xs4, part, lane);
-        tk_phase<SH, SC::KA, SH::SL_A, false, XR>(r, a, l, c, sw, xs4, part, lane);
-        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true, true>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
+        tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
     }
     // classifier: the ring index is 0 again (SLP is a multiple of TK_NB); refills run off the stream's end
-    tk_phase<SH, 0, SH::SL_C, true, XR>(r, a, L, c, sw, xs4, part, lane);
+    tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
 template <class SH>
