@@ -361,17 +361,31 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
 //   * x is staged once per 32 rows (4 waves x 8) instead of once per 8.
 // Same pairing rules and epilogues as gemv_kernel.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float q4_dword_dot(unsigned q, const float4& xl, const float4& xh, float acc) {
-    const unsigned lo = q & 0x0F0F0F0Fu, hi = (q >> 4) & 0x0F0F0F0Fu;   // bytes = nibbles of elems 4i.. / 16+4i..
-    acc = fmaf((float)(lo & 0xFF), xl.x, acc);
-    acc = fmaf((float)((lo >> 8) & 0xFF), xl.y, acc);
-    acc = fmaf((float)((lo >> 16) & 0xFF), xl.z, acc);
-    acc = fmaf((float)(lo >> 24), xl.w, acc);
-    acc = fmaf((float)(hi & 0xFF), xh.x, acc);
-    acc = fmaf((float)((hi >> 8) & 0xFF), xh.y, acc);
-    acc = fmaf((float)((hi >> 16) & 0xFF), xh.z, acc);
-    acc = fmaf((float)(hi >> 24), xh.w, acc);
-    return acc;
+// byte N of a dword as float: ONE v_cvt_f32_ubyteN.  Written as asm because the optimiser folds
+// `((q & 0x0F0F0F0F) >> 8) & 0xFF` into `(q >> 8) & 0x0F`, which no longer matches the byte-convert pattern and costs
+// a shift + an and + a convert per weight (measured: 3.2 VALU ops per weight instead of 1.75).
+template <int N>
+__device__ __forceinline__ float cvt_ubyte(unsigned v) {
+    float f;
+    if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(v));
+    else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(v));
+    else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(v));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(v));
+    return f;
+}
+// One dword = bytes 4i..4i+3 of a block: low nibbles are elements 4i.., high nibbles elements 16+4i...
+// lo += sum n_lo x ;  hi16 += sum (16 n_hi) x   -- the high nibbles are converted in place (q & 0xF0F0F0F0 = 16 n),
+// the exact factor 1/16 is applied once per block by the caller.
+__device__ __forceinline__ void q4_dword_dot(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
+    const unsigned l = q & 0x0F0F0F0Fu, h = q & 0xF0F0F0F0u;
+    lo = fmaf(cvt_ubyte<0>(l), xl.x, lo);
+    lo = fmaf(cvt_ubyte<1>(l), xl.y, lo);
+    lo = fmaf(cvt_ubyte<2>(l), xl.z, lo);
+    lo = fmaf(cvt_ubyte<3>(l), xl.w, lo);
+    hi16 = fmaf(cvt_ubyte<0>(h), xh.x, hi16);
+    hi16 = fmaf(cvt_ubyte<1>(h), xh.y, hi16);
+    hi16 = fmaf(cvt_ubyte<2>(h), xh.z, hi16);
+    hi16 = fmaf(cvt_ubyte<3>(h), xh.w, hi16);
 }
 
 template <int EPI, bool NORM, int NP>
@@ -474,11 +488,12 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
         const float xs8 = 8.0f * xsum[b];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            float t = 0.f;
-            t = q4_dword_dot(wq[i].x, xl[0], xh[0], t);
-            t = q4_dword_dot(wq[i].y, xl[1], xh[1], t);
-            t = q4_dword_dot(wq[i].z, xl[2], xh[2], t);
-            t = q4_dword_dot(wq[i].w, xl[3], xh[3], t);
+            float tl = 0.f, th = 0.f;
+            q4_dword_dot(wq[i].x, xl[0], xh[0], tl, th);
+            q4_dword_dot(wq[i].y, xl[1], xh[1], tl, th);
+            q4_dword_dot(wq[i].z, xl[2], xh[2], tl, th);
+            q4_dword_dot(wq[i].w, xl[3], xh[3], tl, th);
+            const float t = fmaf(th, 0.0625f, tl);
             const float d = live ? __half2float(wd[i]) : 0.f;
             acc[i] = fmaf(d, t - xs8, acc[i]);
         }
