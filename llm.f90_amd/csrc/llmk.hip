@@ -84,7 +84,7 @@ struct llmk_ctx {
     int n_cu = 256;
     // persistent whole-token kernel (token_kernel.h)
     bool use_tk = false;
-    int tk_shape = 0;      // 1 TinyLlama-1.1B, 2 the small parity shape
+    int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
@@ -248,11 +248,11 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     a.rms_att = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;
     a.rms_ffn = (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data;
     a.rms_final = (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data;
-    a.wqkv = (const float*)c->t[LLMK_WQKV].data;
-    a.wo = (const float*)c->t[LLMK_WO].data;
-    a.w13 = (const float*)c->t[LLMK_W13].data;
-    a.w2 = (const float*)c->t[LLMK_W2].data;
-    a.wcls = (const float*)c->t[LLMK_WCLS].data;
+    a.wqkv = c->t[LLMK_WQKV].data;
+    a.wo = c->t[LLMK_WO].data;
+    a.w13 = c->t[LLMK_W13].data;
+    a.w2 = c->t[LLMK_W2].data;
+    a.wcls = c->t[LLMK_WCLS].data;
     a.kc = c->d_kc;
     a.vc = c->d_vc;
     a.rope = c->d_rope;
@@ -277,7 +277,12 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     return hipGetLastError();
 }
 hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false) {
-    return c->tk_shape == 1 ? launch_token_kernel_t<TkTinyLlama>(c, direct) : launch_token_kernel_t<TkSmall>(c, direct);
+    switch (c->tk_shape) {
+        case 1: return launch_token_kernel_t<TkTinyLlama>(c, direct);
+        case 2: return launch_token_kernel_t<TkSmall>(c, direct);
+        case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct);
+        default: return launch_token_kernel_t<TkSmallF16>(c, direct);
+    }
 }
 
 // Allocate the exchange state of the persistent kernel if cfg matches the instantiated shape TK.
@@ -285,7 +290,7 @@ template <class TK>
 int tk_setup(llmk_ctx* c, int id) {
     const llmk_config& g = c->cfg;
     if (c->use_tk || g.emb_dim != TK::E || g.hidden_dim != TK::H || g.n_heads != TK::NH || g.n_kv_heads != TK::NKV ||
-        g.vocab_size != TK::V)
+        g.vocab_size != TK::V || g.weight_type != TK::WT)
         return LLMK_OK;
     const size_t lds = (size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float);   // scores + exp(scores)
     c->tk_lds = lds < 96 * 1024 ? 96 * 1024 : lds;   // > 80 KB: never two workgroups on one CU
@@ -668,10 +673,11 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));
     // The whole-token persistent kernel serves the shapes it is instantiated for, on a full 256-CU part
-    if (rc == LLMK_OK && !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && cfg->weight_type == LLMK_TYPE_F32 &&
-        c->n_cu == TK_NCU && tp_size == 1) {
+    if (rc == LLMK_OK && !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && c->n_cu == TK_NCU && tp_size == 1) {
         rc = tk_setup<TkTinyLlama>(c, 1);
         if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
+        if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
+        if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
     }
     if (rc == LLMK_OK) {
         CK(hipMemset(c->d_logits, 0, ((size_t)V + 4) * sizeof(float)));

@@ -46,11 +46,11 @@ struct TokenArgs {
     const float* rms_att;    // [L][E]
     const float* rms_ffn;    // [L][E]
     const float* rms_final;  // [E]
-    const float* wqkv;       // [L][E+2KV][E]
-    const float* wo;         // [L][E][E]
-    const float* w13;        // [L][2H][E]
-    const float* w2;         // [L][E][H]
-    const float* wcls;       // [V][E]
+    const void* wqkv;        // [L][E+2KV][E]   f32 or f16 rows (TkShape::WT)
+    const void* wo;          // [L][E][E]
+    const void* w13;         // [L][2H][E]
+    const void* w2;          // [L][E][H]
+    const void* wcls;        // [V][E]
     float* kc;               // [L][S][KV]
     float* vc;
     const float* rope;       // [hs/2]
@@ -70,37 +70,48 @@ struct TokenArgs {
     int nosync;              // debug: do not wait for exchange tags (wrong results; measures the pure streaming rate)
     // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
     int q0, qn, o0, on;
+    int c0, cn;              // this CU's rows of the classifier
 };
 
-template <int E_, int H_, int NH_, int NKV_, int V_>
+template <int E_, int H_, int NH_, int NKV_, int V_, int WT_ = WT_F32>
 struct TkShape {
-    static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_;
+    static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_, WT = WT_;
     static constexpr int HS = E / NH, KV = NKV * HS, KVMUL = NH / NKV, QKV = E + 2 * KV;
+    // ---- weight tiles.  A tile is TK_TCOLS (8) lane loads of 16 bytes = 8 "segments" of 1 KB.  f32: one row x 8
+    // segments (2048 columns).  f16: a row of 2048 columns is 4 segments, so a tile is RPT = 2 consecutive rows x LPT = 4
+    // segments -- the x fragment a lane needs (LPT segments x 16/BW columns) is 32 floats either way.
+    static constexpr int BW = (WT == WT_F16) ? 2 : 4;                    // bytes per weight
+    static constexpr int VPL = 16 / BW;                                  // weights per 16-byte lane load
+    static constexpr int LPR_E = E * BW / 1024, LPR_H = H * BW / 1024;   // 1 KB segments per row, K = E / K = H
+    static constexpr int RPT = (WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1;   // rows per tile
+    static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
     // rows per CU and tiles per CU for each phase
     // The NH attention CUs own NO rows of the QKV and wo matrices (the two phases either side of attention): their q poll,
     // K/V rows and attention never queue behind their own weight prefetch, and nobody waits for them to catch up on
-    // streaming after attention.  The other NCU_W CUs split those rows as evenly as whole RoPE pairs / rows allow.
+    // streaming after attention.  The other NCU_W CUs split those rows as evenly as whole RoPE pairs / tile rows allow.
     static constexpr int NCU_W = TK_NCU - NH;
     static constexpr int QB = (QKV / 2) / NCU_W, QX = (QKV / 2) % NCU_W;      // pairs per CU, CUs with one pair more
-    static constexpr int OB = E / NCU_W, OX = E % NCU_W;
-    static constexpr int R_Q = 2 * (QB + (QX > 0 ? 1 : 0)), R_O = OB + (OX > 0 ? 1 : 0);   // MAX rows per CU
-    static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU, R_C = V / TK_NCU;
-    static constexpr int TPR_E = (E / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = E
-    static constexpr int TPR_H = (H / 4 / WAVE + TK_TCOLS - 1) / TK_TCOLS;  // tiles per row, K = H
-    static constexpr int NT_Q = R_Q * TPR_E, NT_O = R_O * TPR_E, NT_A = R_A * TPR_E, NT_D = R_D * TPR_H, NT_C = R_C * TPR_E;
+    static constexpr int OB = (E / RPT) / NCU_W, OX = (E / RPT) % NCU_W;      // tile-row groups per CU, CUs with one more
+    static constexpr int CB = (V / RPT) / TK_NCU, CX = (V / RPT) % TK_NCU;    // classifier: the same over all CUs
+    static constexpr int R_Q = 2 * (QB + (QX > 0 ? 1 : 0)), R_O = RPT * (OB + (OX > 0 ? 1 : 0));   // MAX rows per CU
+    static constexpr int R_C = RPT * (CB + (CX > 0 ? 1 : 0));
+    static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU;
+    static constexpr int TPR_H = (LPR_H + LPT - 1) / LPT;                // column parts of a w2 row
+    static constexpr int NT_Q = R_Q / RPT, NT_O = R_O / RPT, NT_A = R_A / RPT, NT_D = (R_D / RPT) * TPR_H, NT_C = R_C / RPT;
     static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
                          SL_A = (NT_A + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
-    // w2 rows are TPR_H tiles wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
+    // w2 rows are TPR_H parts wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
     // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
-    static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D + NW_D - 1) / NW_D;
+    static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D / RPT + NW_D - 1) / NW_D;
     static constexpr int SL_LAYER = SL_Q + SL_O + SL_A + SL_D;
-    static constexpr int MAXP = (NT_A > NT_C ? NT_A : NT_C) > NT_D ? (NT_A > NT_C ? NT_A : NT_C) : NT_D;
-    static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % TK_NCU == 0, "rows must split over CUs");
-    static_assert(E % 256 == 0 && H % 256 == 0, "rows are whole 1 KB segments");
+    static constexpr int MAXP0 = R_A > R_C ? R_A : R_C, MAXP1 = R_D * TPR_H, MAXP = MAXP0 > MAXP1 ? MAXP0 : MAXP1;   // partial sums per phase
+    static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % RPT == 0, "rows must split over CUs");
+    static_assert(E * BW % 1024 == 0 && H * BW % 1024 == 0, "rows are whole 1 KB segments");
+    static_assert(LPR_E <= LPT && R_Q % RPT == 0 && (R_A / 2) % RPT == 0 && R_D % RPT == 0, "a K = E row is one tile row; row ranges are whole tiles");
     static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
     static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
     static_assert(HS == 64, "in-kernel attention is written for head_size 64");
-    static_assert(TPR_H <= TK_NS && TPR_E == 1, "every column part of a w2 row needs a wave; K = E rows are one tile");
+    static_assert(TPR_H <= TK_NS, "every column part of a w2 row needs a wave");
 };
 
 // LDS carve (bytes): xs (streaming input, up to H floats) | xraw (E) | partial | attention scratch
@@ -231,54 +242,86 @@ struct TkNorm {
 // flow around the loads hipcc can count them, so consuming the oldest of the TK_NB tiles waits with
 // vmcnt(24) and leaves the three younger tiles in flight; a skipped load would force vmcnt(0).
 struct TkTile {
-    const float4* p;  // row base + first column of the tile (the zero block when the slot is empty)
-    int ncol;         // real vector columns (0..8); columns >= ncol read zeros
-    int pidx;         // partial index (tile index within the CU's phase; MAXP = junk slot)
+    const float4* p;  // first segment of the tile's first row (the zero block when the slot is empty)
+    int rstride;      // float4 units between the tile's rows (RPT > 1)
+    int ncol;         // real segments per tile row (0..LPT); segments >= ncol read zeros
+    int pidx;         // partial index of the tile's first row (MAXP = junk slot); row s of the tile: pidx + s * pstep
+    int pstep;
 };
 
+template <class SH>
 __device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t, const float4* zp, int lane) {
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
-        const float4* pj = (j < t.ncol) ? t.p + j * WAVE : zp;   // wave-uniform select, no branch
+        const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
+        const float4* pj = (jj < t.ncol) ? t.p + s * t.rstride + jj * WAVE : zp;   // wave-uniform select, no branch
         b[j] = ldg_nt(pj + lane);
     }
 }
-// Phases whose rows are ONE tile wide (K = E <= 2048) dot every tile against the same x fragment: it is read
-// from LDS once per phase into registers, not once per tile -- 7 waves x 8 KB of ds_read per slot was
-// ~0.2 us of LDS time in the middle of every slot of the critical path.
+// Every tile of a phase is dotted against the same x fragment (the LPT segments of a row, or of one column part of a
+// w2 row): it is read from LDS once per phase into registers, not once per tile -- 7 waves x 8 KB of ds_read per
+// slot was ~0.2 us of LDS time in the middle of every slot of the critical path.  32 floats per lane for f32 and f16.
+template <class SH>
 struct TkX {
-    float4 v[TK_TCOLS];
-    template <int NC>
-    __device__ __forceinline__ void load(const float4* xs, int lane) {
+    static constexpr int F4 = SH::VPL / 4;          // float4 of x per segment and lane: 1 (f32) or 2 (f16)
+    float4 v[SH::LPT * F4];
+    // segments seg0 .. seg0+LPT-1 of a vector with nseg segments; segments past the end read as zero
+    __device__ __forceinline__ void load(const float4* xs, int seg0, int nseg, int lane) {
 #pragma unroll
-        for (int j = 0; j < TK_TCOLS; ++j) v[j] = (j < NC) ? xs[j * WAVE + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // column part `part` of a K-wide vector (K/4/WAVE vector columns in all): columns past the end read as zero
-    template <int K>
-    __device__ __forceinline__ void load_part(const float4* xs, int part, int lane) {
-        const int nc = K / 4 / WAVE - part * TK_TCOLS;
+        for (int j = 0; j < SH::LPT; ++j) {
+            const bool in = seg0 + j < nseg;
 #pragma unroll
-        for (int j = 0; j < TK_TCOLS; ++j) {
-            const float4 x = xs[(j < nc) ? part * TK_TCOLS * WAVE + j * WAVE + lane : lane];
-            v[j] = (j < nc) ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int h = 0; h < F4; ++h) {
+                const float4 x = xs[in ? ((seg0 + j) * WAVE + lane) * F4 + h : lane];
+                v[j * F4 + h] = in ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     }
 };
-// per-lane partial dot of one tile: four independent FMA chains (x,y,z,w) instead of one 32-deep chain
-__device__ __forceinline__ float tk_dot(const float4 (&b)[TK_TCOLS], const TkX& x) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int j = 0; j < TK_TCOLS; ++j) {
-        acc.x = fmaf(b[j].x, x.v[j].x, acc.x);
-        acc.y = fmaf(b[j].y, x.v[j].y, acc.y);
-        acc.z = fmaf(b[j].z, x.v[j].z, acc.z);
-        acc.w = fmaf(b[j].w, x.v[j].w, acc.w);
-    }
-    return (acc.x + acc.y) + (acc.z + acc.w);
+__device__ __forceinline__ float4 tk_h2f_lo(const float4& w) {   // halves 0..3 of a 16-byte vector of 8
+    const __half2 a = *reinterpret_cast<const __half2*>(&w.x), b = *reinterpret_cast<const __half2*>(&w.y);
+    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
 }
-__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const TkX& x, float* part, int lane) {
-    const float acc = wave_sum(tk_dot(b, x));
-    if (lane == 0) part[t.pidx] = acc;
+__device__ __forceinline__ float4 tk_h2f_hi(const float4& w) {   // halves 4..7
+    const __half2 a = *reinterpret_cast<const __half2*>(&w.z), b = *reinterpret_cast<const __half2*>(&w.w);
+    return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
+}
+// per-lane partial dots of one tile (one per tile row): four independent FMA chains (x,y,z,w) instead of one long chain
+template <class SH>
+__device__ __forceinline__ void tk_dot(const float4 (&b)[TK_TCOLS], const TkX<SH>& x, float (&out)[SH::RPT]) {
+#pragma unroll
+    for (int s = 0; s < SH::RPT; ++s) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int jj = 0; jj < SH::LPT; ++jj) {
+            const float4& w = b[s * SH::LPT + jj];
+            if constexpr (SH::WT == WT_F16) {
+                const float4 lo = tk_h2f_lo(w), hi = tk_h2f_hi(w);
+                const float4 &xl = x.v[2 * jj], &xh = x.v[2 * jj + 1];
+                acc.x = fmaf(lo.x, xl.x, acc.x); acc.y = fmaf(lo.y, xl.y, acc.y);
+                acc.z = fmaf(lo.z, xl.z, acc.z); acc.w = fmaf(lo.w, xl.w, acc.w);
+                acc.x = fmaf(hi.x, xh.x, acc.x); acc.y = fmaf(hi.y, xh.y, acc.y);
+                acc.z = fmaf(hi.z, xh.z, acc.z); acc.w = fmaf(hi.w, xh.w, acc.w);
+            } else {
+                acc.x = fmaf(w.x, x.v[jj].x, acc.x);
+                acc.y = fmaf(w.y, x.v[jj].y, acc.y);
+                acc.z = fmaf(w.z, x.v[jj].z, acc.z);
+                acc.w = fmaf(w.w, x.v[jj].w, acc.w);
+            }
+        }
+        out[s] = (acc.x + acc.y) + (acc.z + acc.w);
+    }
+}
+template <class SH>
+__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const TkX<SH>& x, float* part, int lane) {
+    float v[SH::RPT];
+    tk_dot<SH>(b, x, v);
+#pragma unroll
+    for (int s = 0; s < SH::RPT; ++s) v[s] = wave_sum(v[s]);
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = v[s];
+    }
 }
 
 // Static per-wave schedule: SLP slots per layer (padded to an even count so the 2-deep ring has the
@@ -291,43 +334,36 @@ struct TkSched {
     static constexpr int KQ = 0, KO = KQ + SH::SL_Q, KA = KO + SH::SL_O, KD = KA + SH::SL_A, KP = KD + SH::SL_D;
 };
 
-template <int JUNK>
+template <class SH>
 __device__ __forceinline__ TkTile tk_null(const float4* zp) {
     TkTile t;
-    t.p = zp; t.ncol = 0; t.pidx = JUNK;
+    t.p = zp; t.rstride = 0; t.ncol = 0; t.pidx = SH::MAXP; t.pstep = 0;
     return t;
 }
-
-template <int K_, int TPR, int NT, int JUNK>
-__device__ __forceinline__ TkTile tk_mk(const float* mat, long long row, int ti, const float4* zp) {
-    TkTile t;
-    const bool live = ti < NT;
-    const int part = (TPR == 1) ? 0 : ti % TPR;
-    t.ncol = live ? min(TK_TCOLS, K_ / 4 / WAVE - part * TK_TCOLS) : 0;
-    t.p = live ? reinterpret_cast<const float4*>(mat + row * K_) + part * TK_TCOLS * WAVE : zp;
-    t.pidx = live ? ti : JUNK;
-    return t;
+// row r of a [rows][K] matrix of SH's weight type
+template <class SH, int K>
+__device__ __forceinline__ const float4* tk_rowp(const void* mat, long long r) {
+    return reinterpret_cast<const float4*>(static_cast<const char*>(mat) + (size_t)r * K * SH::BW);
 }
 
-// tile ti of a CU's run-time row range [row0, row0+n) of a K = E matrix (a row is one tile)
+// tile ti of a CU's run-time row range [row0, row0+n) of a K = E matrix: RPT consecutive (= contiguous) rows
 template <class SH>
-__device__ __forceinline__ TkTile tk_row_tile(const float* mat, long long row0, int ti, int n, const float4* zp) {
+__device__ __forceinline__ TkTile tk_row_tile(const void* mat, long long row0, int ti, int n, const float4* zp) {
     TkTile t;
-    const bool live = ti < n;
-    t.ncol = live ? min(TK_TCOLS, SH::E / 4 / WAVE) : 0;
-    t.p = live ? reinterpret_cast<const float4*>(mat + (row0 + ti) * SH::E) : zp;
-    t.pidx = live ? ti : SH::MAXP;
+    const bool live = ti * SH::RPT < n;
+    t.ncol = live ? SH::LPR_E : 0;
+    t.p = live ? tk_rowp<SH, SH::E>(mat, row0 + ti * SH::RPT) : zp;
+    t.rstride = SH::LPR_E * WAVE;
+    t.pidx = live ? ti * SH::RPT : SH::MAXP;
+    t.pstep = live ? 1 : 0;
     return t;
 }
 
 template <class SH, int K>
 __device__ __forceinline__ TkTile tk_cls_at(const TokenArgs& a, int c, int sw) {
-    if constexpr (K < SH::SL_C) {
-        const int ti = K * TK_NS + sw;
-        return tk_mk<SH::E, SH::TPR_E, SH::NT_C, SH::MAXP>(a.wcls, (long long)c * SH::R_C + ti / SH::TPR_E, ti, a.zeros);
-    } else {
-        return tk_null<SH::MAXP>(a.zeros);
-    }
+    if constexpr (K >= SH::SL_C) return tk_null<SH>(a.zeros);
+    else if constexpr (SH::CX == 0) return tk_row_tile<SH>(a.wcls, (long long)c * SH::R_C, K * TK_NS + sw, SH::R_C, a.zeros);   // even split: compile-time count
+    else return tk_row_tile<SH>(a.wcls, a.c0, K * TK_NS + sw, a.cn, a.zeros);
 }
 
 // descriptor of slot K (compile-time) of layer l; K >= SLP looks into layer l+1; past the last
@@ -345,22 +381,32 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
         } else if constexpr (K < SC::KA) {
             return tk_row_tile<SH>(a.wo, (long long)l * SH::E + a.o0, (K - SC::KO) * TK_NS + sw, a.on, a.zeros);
         } else if constexpr (K < SC::KD) {
-            const int ti = (K - SC::KA) * TK_NS + sw;
-            const int r = ti / SH::TPR_E;  // 0..R_A-1: (gate0, up0, gate1, up1, ...)
-            return tk_mk<SH::E, SH::TPR_E, SH::NT_A, SH::MAXP>(
-                a.w13, (long long)l * 2 * SH::H + (r & 1) * SH::H + c * (SH::R_A / 2) + (r >> 1), ti, a.zeros);
+            // w1|w3: tile 2m is RPT gate rows, tile 2m+1 the RPT up rows of the same hidden units (SwiGLU pairs stay in the CU);
+            // partials are laid out (gate, up) per hidden unit
+            const int ti = (K - SC::KA) * TK_NS + sw, m = ti >> 1, gu = ti & 1;
+            const bool live = ti < SH::NT_A;
+            TkTile t;
+            t.ncol = live ? SH::LPR_E : 0;
+            t.p = live ? tk_rowp<SH, SH::E>(a.w13, (long long)l * 2 * SH::H + gu * SH::H + c * (SH::R_A / 2) + m * SH::RPT) : a.zeros;
+            t.rstride = SH::LPR_E * WAVE;
+            t.pidx = live ? 2 * m * SH::RPT + gu : SH::MAXP;
+            t.pstep = live ? 2 : 0;
+            return t;
         } else if constexpr (K < SC::KP) {
+            // w2: RPT rows x column part `part` (LPT segments; the last part is ragged)
             constexpr int P = SH::TPR_H;
             const int part = sw % P, nw = (TK_NS - part + P - 1) / P;      // waves that share this column part
-            const int row = (K - SC::KD) * nw + sw / P;
-            const bool live = row < SH::R_D;
+            const int rg = (K - SC::KD) * nw + sw / P;                     // group of RPT rows
+            const bool live = rg < SH::R_D / SH::RPT;
             TkTile t;
-            t.ncol = live ? min(TK_TCOLS, SH::H / 4 / WAVE - part * TK_TCOLS) : 0;
-            t.p = live ? reinterpret_cast<const float4*>(a.w2 + ((long long)l * SH::E + c * SH::R_D + row) * SH::H) + part * TK_TCOLS * WAVE : a.zeros;
-            t.pidx = live ? row * P + part : SH::MAXP;
+            t.ncol = live ? min(SH::LPT, SH::LPR_H - part * SH::LPT) : 0;
+            t.p = live ? tk_rowp<SH, SH::H>(a.w2, (long long)l * SH::E + c * SH::R_D + rg * SH::RPT) + part * SH::LPT * WAVE : a.zeros;
+            t.rstride = SH::LPR_H * WAVE;
+            t.pidx = live ? rg * SH::RPT * P + part : SH::MAXP;
+            t.pstep = live ? P : 0;
             return t;
         } else {
-            return tk_null<SH::MAXP>(a.zeros);
+            return tk_null<SH>(a.zeros);
         }
     }
 }
@@ -545,12 +591,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         tk_barrier();
         TK_STAMP(3);
         if (lane < a.qn) {
-            float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-            for (int p = 0; p < SH::TPR_E; ++p) {
-                v0 += part[lane * SH::TPR_E + p];
-                v1 += part[(lane ^ 1) * SH::TPR_E + p];
-            }
+            float v0 = part[lane], v1 = part[lane ^ 1];
             v0 = v0 / xn_att;
             v1 = v1 / xn_att;
             const int r = a.q0 + lane;
@@ -618,9 +659,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         tk_barrier();
         TK_STAMP(8);
         if (lane < a.on) {
-            float v = 0.f;
-#pragma unroll
-            for (int p = 0; p < SH::TPR_E; ++p) v += part[lane * SH::TPR_E + p];
+            const float v = part[lane];
             const int r = a.o0 + lane;
             tk_publish(a.g_xa + r, e_o, xraw[r] + v);
         }
@@ -634,12 +673,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         tk_barrier();
         TK_STAMP(11);
         if (lane < SH::R_A / 2) {
-            float gsum = 0.f, usum = 0.f;
-#pragma unroll
-            for (int p = 0; p < SH::TPR_E; ++p) {
-                gsum += part[(2 * lane) * SH::TPR_E + p];
-                usum += part[(2 * lane + 1) * SH::TPR_E + p];
-            }
+            float gsum = part[2 * lane], usum = part[2 * lane + 1];
             gsum = gsum / xn_ffn;
             usum = usum / xn_ffn;
             const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
@@ -669,12 +703,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     const float xn_fin = nrmf.apply(xraw, xs, lane);
     tk_barrier();
     tk_barrier();
-    for (int j = lane; j < SH::R_C; j += WAVE) {
-        float v = 0.f;
-#pragma unroll
-        for (int p = 0; p < SH::TPR_E; ++p) v += part[j * SH::TPR_E + p];
-        a.logits[c * SH::R_C + j] = v / xn_fin;
-    }
+    const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
+    for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = part[j] / xn_fin;
     if (!ok && lane == 0) {
         atomicOr(a.err, 0x1000u);
         if (a.herr) __hip_atomic_store(a.herr, 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -692,13 +722,13 @@ struct TkRing {
 
 // slots K .. K+N-1 (compile-time) of layer l: consume ring entry K % NB, refill it with slot K + NB
 template <class SH, int K, int N, bool CLS>
-__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const TkX& x, float* part, int lane) {
+__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
     if constexpr (N > 0) {
         constexpr int R = K % TK_NB;
-        tk_consume(r.b[R], r.t[R], x, part, lane);
+        tk_consume<SH>(r.b[R], r.t[R], x, part, lane);
         if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
         else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
-        tk_issue(r.b[R], r.t[R], a.zeros, lane);
+        tk_issue<SH>(r.b[R], r.t[R], a.zeros, lane);
         tk_run<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, x, part, lane);
     }
 }
@@ -709,16 +739,20 @@ __device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int
 // N tiles at once: all per-lane dots first, then the N wave reductions (independent DPP chains the
 // scheduler can interleave), then ONE lane-0 block of LDS writes
 template <class SH, int K, int N>
-__device__ __forceinline__ void tk_eat(const TkRing& r, const TkX& x, float* part, int lane) {
+__device__ __forceinline__ void tk_eat(const TkRing& r, const TkX<SH>& x, float* part, int lane) {
     if constexpr (N > 0) {
-        float v[N];
+        float v[N][SH::RPT];
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = tk_dot(r.b[(K + i) % TK_NB], x);
+        for (int i = 0; i < N; ++i) tk_dot<SH>(r.b[(K + i) % TK_NB], x, v[i]);
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int s = 0; s < SH::RPT; ++s) v[i][s] = wave_sum(v[i][s]);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) part[r.t[(K + i) % TK_NB].pidx] = v[i];
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int s = 0; s < SH::RPT; ++s) part[r.t[(K + i) % TK_NB].pidx + s * r.t[(K + i) % TK_NB].pstep] = v[i][s];
         }
     }
 }
@@ -728,7 +762,7 @@ __device__ __forceinline__ void tk_refill(TkRing& r, const TokenArgs& a, int l, 
         constexpr int R = K % TK_NB;
         if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
         else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
-        tk_issue(r.b[R], r.t[R], a.zeros, lane);
+        tk_issue<SH>(r.b[R], r.t[R], a.zeros, lane);
         tk_refill<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, lane);
     }
 }
@@ -739,9 +773,9 @@ __device__ __forceinline__ void tk_phase(TkRing& r, const TokenArgs& a, int l, i
                                          float* part, int lane) {
     constexpr int LATE = S < TK_NB ? S : TK_NB, EARLY = S - LATE;
     tk_barrier();
-    TkX x;
-    if constexpr (WIDE) x.template load_part<SH::H>(xs4, sw % SH::TPR_H, lane);
-    else x.template load<SH::E / 4 / WAVE>(xs4, lane);
+    TkX<SH> x;
+    if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
+    else x.load(xs4, 0, SH::LPR_E, lane);
     tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
     tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
     tk_barrier();
@@ -752,7 +786,7 @@ template <class SH, int K>
 __device__ __forceinline__ void tk_prime(TkRing& r, const TokenArgs& a, int c, int sw, int lane) {
     if constexpr (K < TK_NB) {
         r.t[K] = tk_at<SH, K>(a, 0, c, sw);
-        tk_issue(r.b[K], r.t[K], a.zeros, lane);
+        tk_issue<SH>(r.b[K], r.t[K], a.zeros, lane);
         tk_prime<SH, K + 1>(r, a, c, sw, lane);
     }
 }
@@ -779,8 +813,8 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             // which would otherwise queue behind 100+ KB of prefetch in this CU's memory pipeline
             constexpr int LATE = SH::SL_Q < TK_NB ? SH::SL_Q : TK_NB, EARLY = SH::SL_Q - LATE;
             tk_barrier();
-            TkX x;
-            x.template load<SH::E / 4 / WAVE>(xs4, lane);
+            TkX<SH> x;
+            x.load(xs4, 0, SH::LPR_E, lane);
             tk_run<SH, SC::KQ, EARLY, false>(r, a, l, c, sw, x, part, lane);
             tk_eat<SH, SC::KQ + EARLY, LATE>(r, x, part, lane);
             tk_barrier();
@@ -816,8 +850,10 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         const int n = c - blk - ((c % HPC) > ap ? 1 : 0);            // rank among the CUs that own QKV / wo rows
         a.qn = att_cu ? 0 : 2 * (SH::QB + (n < SH::QX ? 1 : 0));
         a.q0 = 2 * (n * SH::QB + min(n, SH::QX));
-        a.on = att_cu ? 0 : SH::OB + (n < SH::OX ? 1 : 0);
-        a.o0 = n * SH::OB + min(n, SH::OX);
+        a.on = att_cu ? 0 : SH::RPT * (SH::OB + (n < SH::OX ? 1 : 0));
+        a.o0 = SH::RPT * (n * SH::OB + min(n, SH::OX));
+        a.cn = SH::RPT * (SH::CB + (c < SH::CX ? 1 : 0));
+        a.c0 = SH::RPT * (c * SH::CB + min(c, SH::CX));
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH>(a, lds, c, lane, tid); }
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
@@ -825,5 +861,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
 
 typedef TkShape<2048, 5632, 32, 4, 32000> TkTinyLlama;   // /root/reference/llama2.f90:102-108
 typedef TkShape<256, 768, 4, 2, 1024> TkSmall;           // tests/golden/tk-small*.npz: pinned to the real reference
+typedef TkShape<2048, 5632, 32, 4, 32000, WT_F16> TkTinyLlamaF16;   // BASELINE.json configs[2]: the same model, f16 matrices
+typedef TkShape<512, 1536, 8, 2, 1024, WT_F16> TkSmallF16;          // parity shape for the f16 tiles (tests: tk-small16)
 
 }  // namespace llmk

@@ -72,6 +72,8 @@ SHAPES: Dict[str, LlamaShape] = {
     "tiny-70bish": LlamaShape(1024, 3584, 3, 8, 1, 800, 64),  # E:nh:nkv = 70B ratios / 8, hs 128
     # smallest shape the persistent whole-token kernel is instantiated for (rows divide over 256 CUs)
     "tk-small": LlamaShape(256, 768, 2, 4, 2, 1024, 64),
+    # the same for f16 matrices (a row must be whole 1 KB segments at 2 bytes per weight)
+    "tk-small16": LlamaShape(512, 1536, 2, 8, 2, 1024, 64),
 }
 
 

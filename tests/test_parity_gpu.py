@@ -37,7 +37,7 @@ def test_device_argmax_matches_reference_tokens(tag, gguf):
     m.close()
 
 
-@pytest.mark.parametrize("shape", ["tiny-gqa", "tiny-mha", "tiny-hs64", "tiny-hs128", "tiny-70bish"])
+@pytest.mark.parametrize("shape", ["tiny-gqa", "tiny-mha", "tiny-hs64", "tiny-hs128", "tiny-70bish", "tk-small16"])
 @pytest.mark.parametrize("wtype", [1, 2], ids=["f16", "q4_0"])
 def test_f16_q4_match_oracle_on_decoded_weights(shape, wtype, gguf):
     """f16/q4_0 arithmetic lives in reference branches that are not under /root/reference (parity
@@ -162,3 +162,33 @@ def test_tinyllama_size_token_kernel_vs_multikernel_vs_oracle(gguf):
     assert rel_err(tl[:k], ol).max() <= REL_TOL
     assert rel_err(rl[:k], ol).max() <= REL_TOL
     assert np.array_equal(tt[:k], ot)
+
+
+@pytest.mark.parametrize("flags", [0, llmk.FLAG_MULTI_KERNEL], ids=["token-kernel", "multikernel"])
+def test_f16_token_kernel_shape_matches_oracle_over_the_whole_context(flags, gguf):
+    """tk-small16 is the shape the f16 persistent token kernel is instantiated for (two-row tiles): every position up
+    to seq_len against the f32 reference path on the host-decoded weights, both implementations."""
+    s = gguf.SHAPES["tk-small16"]
+    fw = gguf.synth_fused(s, 2024, 1)
+    otoks, ologits = Oracle(fw.as_f32(), "omp").generate(s.seq_len)
+    m = llmk.Llmk(fw, flags=flags)
+    toks, logits = m.generate(s.seq_len)
+    assert rel_err(logits, ologits).max() <= REL_TOL
+    margin = np.sort(ologits, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ologits).max()
+    assert np.array_equal(toks[safe], otoks[safe])
+    m.close()
+
+
+def test_tinyllama_f16_token_kernel_matches_multi_kernel_path(gguf):
+    """BASELINE.json configs[2] (TinyLlama f16): the persistent kernel against the per-GEMV path on the same weights"""
+    s = gguf.SHAPES["tinyllama"]
+    fw = gguf.synth_fused(s, 20260928, 1)
+    a = llmk.Llmk(fw, flags=llmk.FLAG_MULTI_KERNEL)
+    rt, rl = a.generate(40)
+    a.close()
+    b = llmk.Llmk(fw)
+    t, l = b.generate(40)
+    assert rel_err(l, rl).max() <= REL_TOL
+    assert np.array_equal(t, rt)
+    b.close()
