@@ -392,11 +392,15 @@ template <int EPI, bool NORM, int NP>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);          // [4]
-    float4* xs = reinterpret_cast<float4*>(smem_raw + 16);    // [8][nblk] float4 (transposed x)
+    float4* xs = reinterpret_cast<float4*>(smem_raw + 16);    // [8][xp] float4 (transposed x), row pitch xp = nblk + 1
     constexpr int NR = 2 * NP;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = a.K, nx4 = K >> 2, nblk = K >> 5;
-    float* xsum = reinterpret_cast<float*>(xs + 8 * nblk);    // [nblk] block sums of the staged x
+    // +1 float4 of pitch: the 8 lanes that stage one block's 8 vectors write 8 different rows of the transposed
+    // array; at a pitch of nblk*16 bytes (a multiple of the bank width) they all hit the same banks (rocprofv3:
+    // SQ_LDS_BANK_CONFLICT 5.6x SQ_ACTIVE_INST_LDS on the 7B shapes)
+    const int xp = nblk + 1;
+    float* xsum = reinterpret_cast<float*>(xs + 8 * xp);      // [nblk] block sums of the staged x
     const int npairs = (EPI == EPI_SWIGLU) ? a.H : (a.rows >> 1);
     const int g0 = (blockIdx.x * GEMV_WAVES + wid) * NP;      // first pair of this wave
     const uint4* Wn = reinterpret_cast<const uint4*>(a.W);
@@ -421,29 +425,32 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
         }
     }
     // ---- stage x: transposed float4 groups + per-block sums ------------------------------------
+    float xn = 1.f;
     {
         const float4* xg = reinterpret_cast<const float4*>(a.x);
         float ss = 0.f;
         for (int i = tid; i < nx4; i += GEMV_THREADS) {
             const float4 v = xg[i];
             if (NORM) ss = dot4(v, v, ss);
-            xs[(i & 7) * nblk + (i >> 3)] = v;
+            xs[(i & 7) * xp + (i >> 3)] = v;
         }
         if (NORM) {
             ss = wave_sum(ss);
             if (lane == 0) red[wid] = ss;
             __syncthreads();
             ss = red[0] + red[1] + red[2] + red[3];
-            const float xn = sqrtf(ss / (float)K + 1e-5f);
+            // rmsnorm (llama2.f90:450-457): x*w is staged, the division by sqrt(mean(x^2)+eps) is linear in the dot
+            // product and is applied ONCE to each finished row sum instead of K times per block
+            xn = sqrtf(ss / (float)K + 1e-5f);
             const float4* wg = reinterpret_cast<const float4*>(a.norm_w);
             for (int i = tid; i < nx4; i += GEMV_THREADS) {
-                const int li = (i & 7) * nblk + (i >> 3);
+                const int li = (i & 7) * xp + (i >> 3);
                 float4 v = xs[li];
                 const float4 nw = wg[i];
-                v.x = v.x * nw.x / xn;
-                v.y = v.y * nw.y / xn;
-                v.z = v.z * nw.z / xn;
-                v.w = v.w * nw.w / xn;
+                v.x = v.x * nw.x;
+                v.y = v.y * nw.y;
+                v.z = v.z * nw.z;
+                v.w = v.w * nw.w;
                 xs[li] = v;
             }
         }
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const float4 v = xs[m * nblk + b];
+                const float4 v = xs[m * xp + b];
                 t += (v.x + v.y) + (v.z + v.w);
             }
             xsum[b] = t;
@@ -482,8 +489,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
         float4 xl[4], xh[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            xl[m] = xs[m * nblk + b];
-            xh[m] = xs[(4 + m) * nblk + b];
+            xl[m] = xs[m * xp + b];
+            xh[m] = xs[(4 + m) * xp + b];
         }
         const float xs8 = 8.0f * xsum[b];
 #pragma unroll
@@ -504,6 +511,10 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[i] = wave_sum(acc[i]);
+    if (NORM) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc[i] = acc[i] / xn;
+    }
     if (lane == 0) {
 #pragma unroll
         for (int j = 0; j < NP; ++j)

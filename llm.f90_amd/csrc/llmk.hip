@@ -137,7 +137,7 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
         default: {   // q4_0: dedicated kernel, up to 8 rows per wave (kernels.h); fewer when the matrix is
                      // too small to give every CU at least two workgroups that way
             const int npairs = (EPI == EPI_SWIGLU) ? a.H : a.rows / 2;
-            const size_t smem = 16 + (size_t)a.K * sizeof(float) + (size_t)(a.K / 32) * sizeof(float);
+            const size_t smem = 16 + (size_t)a.K * sizeof(float) + 8 * 16 + (size_t)(a.K / 32) * sizeof(float);   // x (pitch nblk+1) + block sums
             const int want = 2 * n_cu;
 #define Q4_LAUNCH(NP_)                                                                                           \
             do {                                                                                                 \
