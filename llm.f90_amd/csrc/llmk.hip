@@ -479,7 +479,7 @@ int pf_setup(llmk_ctx* c) {
     return LLMK_OK;
 }
 // P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; returns KS through *ks_out
-hipError_t pf_gemm(llmk_ctx* c, const float* W, const float* X, int rows, int K, int T, int* ks_out) {
+hipError_t pf_gemm(llmk_ctx* c, const void* W, const float* X, int rows, int K, int T, int* ks_out) {
     PfGemmArgs a;
     a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
     int ks, kslice;
@@ -487,12 +487,20 @@ hipError_t pf_gemm(llmk_ctx* c, const float* W, const float* X, int rows, int K,
     a.kslice = kslice;
     *ks_out = ks;
     const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
+#define PF_LAUNCH(NG_)                                                                                     \
+    do {                                                                                                   \
+        if (c->cfg.weight_type == LLMK_TYPE_F16)                                                           \
+            hipLaunchKernelGGL((pf_gemm_kernel<NG_, WT_F16>), grid, block, 0, c->stream, a);                \
+        else                                                                                               \
+            hipLaunchKernelGGL((pf_gemm_kernel<NG_, WT_F32>), grid, block, 0, c->stream, a);                \
+    } while (0)
     switch ((T + 15) / 16) {
-        case 1: hipLaunchKernelGGL(pf_gemm_kernel<1>, grid, block, 0, c->stream, a); break;
-        case 2: hipLaunchKernelGGL(pf_gemm_kernel<2>, grid, block, 0, c->stream, a); break;
-        case 3: hipLaunchKernelGGL(pf_gemm_kernel<3>, grid, block, 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(pf_gemm_kernel<4>, grid, block, 0, c->stream, a); break;
+        case 1: PF_LAUNCH(1); break;
+        case 2: PF_LAUNCH(2); break;
+        case 3: PF_LAUNCH(3); break;
+        default: PF_LAUNCH(4); break;
     }
+#undef PF_LAUNCH
     return hipGetLastError();
 }
 // one batch of T <= PF_TMAX prompt positions pos0 .. pos0+T-1 (1-based) through all layers; X[T-1] ends up in d_x
@@ -506,10 +514,11 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
     e.P = c->pf_P; e.xn = c->pf_xn; e.rope = c->d_rope; e.Tp = Tp; e.T = T; e.pos0 = pos0;
     e.E = E; e.KV = KV; e.hs = c->hs; e.H = H;
     for (int l = 0; l < c->L; ++l) {
-        const float* wqkv = (const float*)c->t[LLMK_WQKV].data + (size_t)l * QKV * E;
-        const float* wo = (const float*)c->t[LLMK_WO].data + (size_t)l * E * E;
-        const float* w13 = (const float*)c->t[LLMK_W13].data + (size_t)l * 2 * H * E;
-        const float* w2 = (const float*)c->t[LLMK_W2].data + (size_t)l * E * H;
+        const size_t bw = c->cfg.weight_type == LLMK_TYPE_F16 ? 2 : 4;
+        const char* wqkv = (const char*)c->t[LLMK_WQKV].data + (size_t)l * QKV * E * bw;
+        const char* wo = (const char*)c->t[LLMK_WO].data + (size_t)l * E * E * bw;
+        const char* w13 = (const char*)c->t[LLMK_W13].data + (size_t)l * 2 * H * E * bw;
+        const char* w2 = (const char*)c->t[LLMK_W2].data + (size_t)l * E * H * bw;
         float* kc = c->d_kc + (size_t)l * c->S * KV;
         float* vc = c->d_vc + (size_t)l * c->S * KV;
         // rmsnorm + QKV + RoPE + KV write                                                 llama2.f90:527-565
@@ -826,7 +835,7 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     if (rc) return rc;
     for (int i = 0; i < n; ++i)
         if (tokens[i] < 1 || tokens[i] > c->V) return LLMK_E_ARG;
-    const bool batched = c->cfg.weight_type == LLMK_TYPE_F32 && c->tp_size == 1 && !c->comm && c->E % PF_KSTEP == 0 &&
+    const bool batched = (c->cfg.weight_type == LLMK_TYPE_F32 || c->cfg.weight_type == LLMK_TYPE_F16) && c->tp_size == 1 && !c->comm && c->E % PF_KSTEP == 0 &&
                          c->H % PF_KSTEP == 0 && c->KV % 16 == 0 && !(getenv("LLMK_PREFILL") && getenv("LLMK_PREFILL")[0] == '0');
     if (!batched) {
         for (int i = 0; i < n; ++i) {
@@ -886,7 +895,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     if (kernel == 7) {   // the prefill w1|w3 GEMM at PF_TMAX positions (whatever the workspaces hold: timing only)
-        if (c->cfg.weight_type != LLMK_TYPE_F32 || c->tp_size != 1 || c->E % PF_KSTEP || c->H % PF_KSTEP) return LLMK_E_ARG;
+        if (c->cfg.weight_type == LLMK_TYPE_Q4_0 || c->tp_size != 1 || c->E % PF_KSTEP || c->H % PF_KSTEP) return LLMK_E_ARG;
         rc = pf_setup(c);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->pf_Xs, 0, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
@@ -904,7 +913,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
         }
         if (kernel == 7) {
             int ks;
-            return pf_gemm(c, (const float*)c->t[LLMK_W13].data + (size_t)l * 2 * c->H * c->E, c->pf_Xs, 2 * c->H, c->E, PF_TMAX, &ks);
+            return pf_gemm(c, (const char*)c->t[LLMK_W13].data + (size_t)l * 2 * c->H * c->t[LLMK_W13].row_bytes, c->pf_Xs, 2 * c->H, c->E, PF_TMAX, &ks);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);

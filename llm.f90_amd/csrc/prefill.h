@@ -29,7 +29,7 @@ constexpr int PF_WAVES = 4;
 typedef float pf_v4f __attribute__((ext_vector_type(4)));
 
 struct PfGemmArgs {
-    const float* W;      // [rows][K]
+    const void* W;       // [rows][K]  f32 or f16 (template parameter WT)
     const float* X;      // [T][K]   (activations, L2-resident)
     float* P;            // [KS][Tp][rows] partial sums, Tp = 16*NG
     int rows, K, T;
@@ -39,17 +39,23 @@ struct PfGemmArgs {
 constexpr int PF_KSTEP = 64;                 // columns per pipeline step (4 MFMA chunks of 16)
 constexpr int PF_LDW = PF_KSTEP + 4;         // LDS row pitch in floats (+16 bytes: the 16 tokens of a read spread over banks)
 
-template <int NG>
+// f16 weights: a lane's 16 bytes are 8 columns, so a chunk is 32 columns (8 MFMA steps after the exact half -> float
+// conversion) and a 64-column step has two chunks; the activation side is f32 either way.
+template <int NG, int WT>
 __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) {
     constexpr int TP = NG * 16;
+    constexpr int BW = (WT == WT_F16) ? 2 : 4;          // bytes per weight
+    constexpr int CPL = 16 / BW;                          // columns per lane load: 4 / 8
+    constexpr int CW = 4 * CPL;                           // columns per chunk (4 lane groups): 16 / 32
+    constexpr int NJ = PF_KSTEP / CW;                     // chunks per step: 4 / 2
     __shared__ __attribute__((aligned(16))) float xs[2][TP][PF_LDW];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int row0 = blockIdx.x * 64 + wid * 16, ks = blockIdx.y;
     const int kb = ks * a.kslice, ke = min(a.K, kb + a.kslice);
     const int nsteps = (ke - kb) / PF_KSTEP;
-    const int li = lane & 15, lk = (lane >> 4) * 4;
+    const int li = lane & 15, lk = (lane >> 4) * CPL;
     const bool active = row0 < a.rows;                               // ragged last block: idle waves still take the barriers
-    const float* wp = a.W + (size_t)min(row0 + li, a.rows - 1) * a.K + kb + lk;
+    const char* wp = static_cast<const char*>(a.W) + ((size_t)min(row0 + li, a.rows - 1) * a.K + kb + lk) * BW;
     // activation staging: thread -> (token, 16-byte column group) of the TP x 64 tile, TP*16/256 vectors per thread
     constexpr int XV = TP * (PF_KSTEP / 4) / (PF_WAVES * WAVE);
     const float* xg[XV];
@@ -66,11 +72,11 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
 
     // Weights and activations of step s+1 are requested before the MFMAs of step s (one register stage ahead).
-    // Measured alternatives on MI355X (w1|w3 GEMM, 64 positions): this form 47 us; two stages ahead with the
+    // Measured alternatives on MI355X (f32 w1|w3 GEMM, 64 positions): this form 47 us; two stages ahead with the
     // stages rotated by name (loop written out three times) 77 us -- 150 registers, 3 waves/SIMD instead of 4.
-    float4 wc[4], wn[4], xr[XV];
+    float4 wc[NJ], wn[NJ], xr[XV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wc[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * 16));
+    for (int j = 0; j < NJ; ++j) wc[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * CW * BW));
 #pragma unroll
     for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
 #pragma unroll
@@ -80,32 +86,44 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     for (int s = 0; s < nsteps; ++s) {
         const int kn = min(s + 1, nsteps - 1) * PF_KSTEP;             // clamped: the loads stay unconditional
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wn[j] = ldg_nt(reinterpret_cast<const float4*>(wp + kn + j * 16));
+        for (int j = 0; j < NJ; ++j) wn[j] = ldg_nt(reinterpret_cast<const float4*>(wp + (kn + j * CW) * BW));
 #pragma unroll
         for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + kn);
         const float* xb = &xs[s & 1][0][0];
         if (active) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float4 x[NG];
+            for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * 16 + lk);
-                // component-major: the NG accumulators are independent chains the matrix core can interleave
+                for (int h = 0; h < CPL / 4; ++h) {      // 4 columns at a time: one float4 of activations per token group
+                    float4 w;
+                    if constexpr (WT == WT_F16) {
+                        const __half2 p0 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].x : &wc[j].z);
+                        const __half2 p1 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].y : &wc[j].w);
+                        w = make_float4(__low2float(p0), __high2float(p0), __low2float(p1), __high2float(p1));
+                    } else {
+                        w = wc[j];
+                    }
+                    float4 x[NG];
 #pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].x, x[g].x, acc[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g)
+                        x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * CW + lk + 4 * h);
+                    // component-major: the NG accumulators are independent chains the matrix core can interleave
 #pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].y, x[g].y, acc[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[g].x, acc[g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].z, x[g].z, acc[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[g].y, acc[g], 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[j].w, x[g].w, acc[g], 0, 0, 0);
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[g].w, acc[g], 0, 0, 0);
+                }
             }
         }
         // the other buffer was last read in step s-1, which every wave left through the barrier below
 #pragma unroll
         for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[(s + 1) & 1][0][0] + xo[i]) = xr[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wc[j] = wn[j];
+        for (int j = 0; j < NJ; ++j) wc[j] = wn[j];
         __syncthreads();
     }
     if (active) {

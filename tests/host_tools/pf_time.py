@@ -1,12 +1,12 @@
-"""prefill timing: python tests/host_tools/pf_time.py [n ...]"""
-import sys, time
+"""prefill timing: [LLMK_WT=1 for f16] python tests/host_tools/pf_time.py [n ...]"""
+import os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
 import llm_f90_amd
 from llm_f90_amd import llmk
 from llm_f90_amd.tools import gguf
 s = gguf.SHAPES["tinyllama"]
-fw = gguf.synth_fused(s, 20260928)
+fw = gguf.synth_fused(s, 20260928, int(os.environ.get('LLMK_WT', '0')))
 m = llmk.Llmk(fw)
 rng = np.random.default_rng(1)
 for n in [int(a) for a in sys.argv[1:]] or [16, 32, 64, 128, 512]:

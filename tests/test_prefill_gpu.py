@@ -106,10 +106,9 @@ def test_prefill_argument_errors(gguf):
     m.close()
 
 
-@pytest.mark.parametrize("wtype", [1, 2], ids=["f16", "q4_0"])
-def test_prefill_other_weight_types_fall_back(wtype, gguf):
-    """f16 / q4_0 contexts take the token-by-token pass inside llmk_prefill: same answer as llmk_forward"""
-    fw = gguf.synth_fused(gguf.SHAPES["tiny-gqa"], 4242, wtype)
+def test_prefill_q4_falls_back_to_the_token_by_token_pass(gguf):
+    """q4_0 contexts take the token-by-token pass inside llmk_prefill: bit-identical to llmk_forward"""
+    fw = gguf.synth_fused(gguf.SHAPES["tiny-gqa"], 4242, 2)
     prompt = [2, 40, 41, 42, 43]
     a = llmk.Llmk(fw)
     for pos, tok in enumerate(prompt, 1):
@@ -117,3 +116,26 @@ def test_prefill_other_weight_types_fall_back(wtype, gguf):
     b = llmk.Llmk(fw)
     assert np.array_equal(b.prefill(prompt, 1), ref)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-hs64", 33), ("tk-small16", 40), ("tiny-hs128", 5)])
+def test_prefill_f16_matches_oracle_on_decoded_weights(shape, n, gguf):
+    """f16 matrices go through the same batched MFMA GEMMs (exact half -> float conversion of the A operand): pinned, like
+    the f16 decode path, to the f32 reference arithmetic on the host-decoded weights; then decoding continues from the cache"""
+    s = gguf.SHAPES[shape]
+    fw = gguf.synth_fused(s, 4242, 1)
+    rng = np.random.default_rng(3)
+    prompt = [2] + (rng.integers(3, s.vocab_size, n - 1) + 1).tolist()
+    o = Oracle(fw.as_f32(), "omp")
+    for pos, tok in enumerate(prompt, 1):
+        ol = o.forward(tok, pos)
+    m = llmk.Llmk(fw)
+    lg = m.prefill(prompt, 1)
+    assert rel_err(lg[None], ol[None]).max() <= REL_TOL
+    tok = int(np.argmax(ol)) + 1
+    for pos in range(n + 1, min(n + 5, s.seq_len) + 1):
+        ol = o.forward(tok, pos)
+        lg = m.forward(tok, pos)
+        assert rel_err(lg[None], ol[None]).max() <= REL_TOL
+        tok = int(np.argmax(ol)) + 1
+    m.close()
