@@ -254,8 +254,11 @@ __device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t,
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
-        const float4* pj = (jj < t.ncol) ? t.p + s * t.rstride + jj * WAVE : zp;   // wave-uniform select, no branch
-        b[j] = ldg_nt(pj + lane);
+        const bool real = jj < t.ncol;                                             // wave-uniform select, no branch
+        const float4* pj = real ? t.p + s * t.rstride + jj * WAVE : zp;
+        // an empty segment is ONE 16-byte access for the whole wave (every lane reads the same zero vector), not a 1 KB
+        // sweep of the zero block: it still counts in vmcnt, but costs the CU's memory pipeline one line instead of eight
+        b[j] = ldg_nt(pj + (real ? lane : 0));
     }
 }
 // Every tile of a phase is dotted against the same x fragment (the LPT segments of a row, or of one column part of a
