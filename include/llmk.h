@@ -144,8 +144,9 @@ int llmk_forward(llmk_ctx *ctx, int token, int pos, float *logits_out);
 /* The prompt loop of llama2.f90:376-402 as ONE call: tokens[0..n) (1-based ids) sit at
  * positions pos0 .. pos0+n-1 (1-based); their KV-cache rows are written and logits_out[vocab_size] receives the
  * logits of the LAST position -- what n llmk_forward calls would leave behind, within the 1e-4 parity bar (only the
- * order of the dot-product partial sums differs).  f32 and f16 single-GPU contexts batch up to 64 positions per pass
- * through MFMA GEMMs (a layer's weights cross HBM once per batch); q4_0 / tensor-parallel contexts run the token-by-token pass inside. */
+ * order of the dot-product partial sums differs).  single-GPU contexts (f32, f16, q4_0) batch up to 64 positions per pass
+ * through MFMA GEMMs (a layer's weights cross HBM once per batch); tensor-parallel contexts, and shapes whose emb_dim /
+ * hidden_dim is not a multiple of the GEMM's column step (64; 128 for q4_0), run the token-by-token pass inside. */
 int llmk_prefill(llmk_ctx* ctx, const int* tokens, int n, int pos0, float* logits_out);
 
 /* Same pass, but the temperature-0 consumer (`token = maxloc(logits,DIM=1)`, llama2.f90:388) runs

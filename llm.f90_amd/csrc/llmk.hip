@@ -451,9 +451,10 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
 // K slices of a GEMM: enough (64-row strip x slice) blocks for >= 2 per CU, slices whole multiples of PF_KSTEP columns
 void pf_split(const llmk_ctx* c, int rows, int K, int* ks_out, int* kslice_out) {
     const int strips = (rows + 63) / 64;
+    const int step = c->cfg.weight_type == LLMK_TYPE_Q4_0 ? PF_KSTEP_Q4 : PF_KSTEP;
     int ks = (2 * c->n_cu + strips - 1) / strips;
-    int kslice = ((K + ks - 1) / ks + PF_KSTEP - 1) / PF_KSTEP * PF_KSTEP;
-    if (kslice < 2 * PF_KSTEP) kslice = 2 * PF_KSTEP;
+    int kslice = ((K + ks - 1) / ks + step - 1) / step * step;
+    if (kslice < 2 * step) kslice = 2 * step;
     *kslice_out = kslice;
     *ks_out = (K + kslice - 1) / kslice;
 }
@@ -479,6 +480,31 @@ int pf_setup(llmk_ctx* c) {
     return LLMK_OK;
 }
 // P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; returns KS through *ks_out
+// q4_0: W = nibble plane of the layer, Wsc = its scale plane
+hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, const void* Wsc, const float* X, int rows, int K, int T, int* ks_out) {
+    PfGemmQ4Args a;
+    a.Wn = (const uint4*)W; a.Sc = (const __half*)Wsc; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
+    int ks, kslice;
+    pf_split(c, rows, K, &ks, &kslice);
+    a.kslice = kslice;
+    *ks_out = ks;
+    const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
+    const int NG = (T + 15) / 16;
+    const size_t smem = (size_t)2 * NG * 16 * PF_LDW_Q4 * sizeof(float);
+#define PFQ(NG_)                                                                                                              \
+    do {                                                                                                                      \
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_q4_kernel<NG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(pf_gemm_q4_kernel<NG_>, grid, block, smem, c->stream, a);                                          \
+    } while (0)
+    switch (NG) {
+        case 1: PFQ(1); break;
+        case 2: PFQ(2); break;
+        case 3: PFQ(3); break;
+        default: PFQ(4); break;
+    }
+#undef PFQ
+    return hipGetLastError();
+}
 hipError_t pf_gemm(llmk_ctx* c, const void* W, const float* X, int rows, int K, int T, int* ks_out) {
     PfGemmArgs a;
     a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
@@ -514,18 +540,21 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
     e.P = c->pf_P; e.xn = c->pf_xn; e.rope = c->d_rope; e.Tp = Tp; e.T = T; e.pos0 = pos0;
     e.E = E; e.KV = KV; e.hs = c->hs; e.H = H;
     for (int l = 0; l < c->L; ++l) {
-        const size_t bw = c->cfg.weight_type == LLMK_TYPE_F16 ? 2 : 4;
-        const char* wqkv = (const char*)c->t[LLMK_WQKV].data + (size_t)l * QKV * E * bw;
-        const char* wo = (const char*)c->t[LLMK_WO].data + (size_t)l * E * E * bw;
-        const char* w13 = (const char*)c->t[LLMK_W13].data + (size_t)l * 2 * H * E * bw;
-        const char* w2 = (const char*)c->t[LLMK_W2].data + (size_t)l * E * H * bw;
+        // layer l of tensor tid: data plane (and the q4_0 scale plane), rows_per_layer rows
+        auto gemm = [&](int tid, int rows_per_layer, const float* X, int K, int* ks) -> hipError_t {
+            const DevTensor& dt = c->t[tid];
+            const char* w = (const char*)dt.data + (size_t)l * rows_per_layer * dt.row_bytes;
+            if (c->cfg.weight_type == LLMK_TYPE_Q4_0)
+                return pf_gemm_q4(c, w, (const char*)dt.scales + (size_t)l * rows_per_layer * dt.scale_row_bytes, X, rows_per_layer, K, T, ks);
+            return pf_gemm(c, w, X, rows_per_layer, K, T, ks);
+        };
         float* kc = c->d_kc + (size_t)l * c->S * KV;
         float* vc = c->d_vc + (size_t)l * c->S * KV;
         // rmsnorm + QKV + RoPE + KV write                                                 llama2.f90:527-565
         hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
                            (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E);
         HIPRET(hipGetLastError());
-        HIPRET(pf_gemm(c, wqkv, c->pf_Xs, QKV, E, T, &e.KS));
+        HIPRET(gemm(LLMK_WQKV, QKV, c->pf_Xs, E, &e.KS));
         e.rows = QKV; e.out = c->pf_Q; e.kc = kc; e.vc = vc;
         hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
@@ -544,7 +573,7 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
 #undef ATT
         HIPRET(hipGetLastError());
         // x += wo . xb                                                                    :603-605
-        HIPRET(pf_gemm(c, wo, c->pf_XB, E, E, T, &e.KS));
+        HIPRET(gemm(LLMK_WO, E, c->pf_XB, E, &e.KS));
         e.rows = E; e.out = c->pf_X;
         hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
@@ -552,12 +581,12 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
         hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
                            (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E);
         HIPRET(hipGetLastError());
-        HIPRET(pf_gemm(c, w13, c->pf_Xs, 2 * H, E, T, &e.KS));
+        HIPRET(gemm(LLMK_W13, 2 * H, c->pf_Xs, E, &e.KS));
         e.rows = 2 * H; e.out = c->pf_HB;
         hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
         // x += w2 . hb                                                                    :618-620
-        HIPRET(pf_gemm(c, w2, c->pf_HB, E, H, T, &e.KS));
+        HIPRET(gemm(LLMK_W2, E, c->pf_HB, H, &e.KS));
         e.rows = E; e.out = c->pf_X;
         hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
@@ -835,8 +864,8 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     if (rc) return rc;
     for (int i = 0; i < n; ++i)
         if (tokens[i] < 1 || tokens[i] > c->V) return LLMK_E_ARG;
-    const bool batched = (c->cfg.weight_type == LLMK_TYPE_F32 || c->cfg.weight_type == LLMK_TYPE_F16) && c->tp_size == 1 && !c->comm && c->E % PF_KSTEP == 0 &&
-                         c->H % PF_KSTEP == 0 && c->KV % 16 == 0 && !(getenv("LLMK_PREFILL") && getenv("LLMK_PREFILL")[0] == '0');
+    const int pf_step = c->cfg.weight_type == LLMK_TYPE_Q4_0 ? PF_KSTEP_Q4 : PF_KSTEP;
+    const bool batched = c->tp_size == 1 && !c->comm && c->E % pf_step == 0 && c->H % pf_step == 0 && c->KV % 16 == 0 && !(getenv("LLMK_PREFILL") && getenv("LLMK_PREFILL")[0] == '0');
     if (!batched) {
         for (int i = 0; i < n; ++i) {
             rc = run_token(c, tokens[i], pos0 + i, false);

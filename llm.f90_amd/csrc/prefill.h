@@ -136,6 +136,116 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     }
 }
 
+// ---- q4_0 weights (device layout of llmk_upload: nibble plane [rows][K/2] + f16 scale plane [rows][K/32]) -------------
+// A lane load is ONE block: 16 bytes of nibbles = 32 columns of its row, plus the block's scale; the 4 lane groups of a
+// wave cover 4 blocks = 128 columns, which is the pipeline step.  Byte j of a block holds element j (low nibble) and
+// element 16+j (high nibble); the A operand of MFMA step (dword i, byte c) is (n-8)*d computed exactly as the decode
+// path does ((n - 8) * d in f32), against X[t][k0 + 4i + c] (low) and X[t][k0 + 16 + 4i + c] (high).
+constexpr int PF_KSTEP_Q4 = 128;
+constexpr int PF_LDW_Q4 = PF_KSTEP_Q4 + 4;
+
+struct PfGemmQ4Args {
+    const uint4* Wn;     // [rows][K/32] blocks of 16 nibble bytes
+    const __half* Sc;    // [rows][K/32]
+    const float* X;      // [T][K]
+    float* P;            // [KS][Tp][rows]
+    int rows, K, T;
+    int kslice;          // columns per K slice (multiple of PF_KSTEP_Q4)
+};
+
+template <int NG>
+__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_q4_kernel(PfGemmQ4Args a) {
+    constexpr int TP = NG * 16;
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    float* xs = reinterpret_cast<float*>(pf_smem);                    // [2][TP][PF_LDW_Q4]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int row0 = blockIdx.x * 64 + wid * 16, ks = blockIdx.y;
+    const int kb = ks * a.kslice, ke = min(a.K, kb + a.kslice);
+    const int nsteps = (ke - kb) / PF_KSTEP_Q4;
+    const int li = lane & 15, lg = lane >> 4;                         // row of the strip, block of the step
+    const bool active = row0 < a.rows;
+    const int nblk = a.K >> 5;
+    const size_t wrow = (size_t)min(row0 + li, a.rows - 1) * nblk + (kb >> 5) + lg;
+    constexpr int XV = TP * (PF_KSTEP_Q4 / 4) / (PF_WAVES * WAVE);
+    const float* xg[XV];
+    int xo[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int idx = tid + i * PF_WAVES * WAVE, t = idx / (PF_KSTEP_Q4 / 4), c4 = idx % (PF_KSTEP_Q4 / 4);
+        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + kb + c4 * 4;
+        xo[i] = t * PF_LDW_Q4 + c4 * 4;
+    }
+    pf_v4f acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+
+    uint4 wc = ldg_nt(a.Wn + wrow), wn;
+    __half dc = a.Sc[wrow], dn;
+    float4 xr[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(xs + xo[i]) = xr[i];
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int sn = min(s + 1, nsteps - 1);                          // clamped: the loads stay unconditional
+        wn = ldg_nt(a.Wn + wrow + sn * (PF_KSTEP_Q4 / 32));
+        dn = a.Sc[wrow + sn * (PF_KSTEP_Q4 / 32)];
+#pragma unroll
+        for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + sn * PF_KSTEP_Q4);
+        const float* xb = xs + (s & 1) * TP * PF_LDW_Q4;
+        if (active) {
+            const float d = __half2float(dc), d16 = d * 0.0625f, m8 = -8.0f * d;
+            const unsigned q[4] = {wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned lo = q[i] & 0x0F0F0F0Fu, hi = q[i] & 0xF0F0F0F0u;     // hi bytes = 16 * nibble
+                float4 xl[NG], xh[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float* xrow = xb + (g * 16 + li) * PF_LDW_Q4 + lg * 32 + 4 * i;
+                    xl[g] = *reinterpret_cast<const float4*>(xrow);
+                    xh[g] = *reinterpret_cast<const float4*>(xrow + 16);
+                }
+                const float a0 = fmaf(cvt_ubyte<0>(lo), d, m8), a1 = fmaf(cvt_ubyte<1>(lo), d, m8);
+                const float a2 = fmaf(cvt_ubyte<2>(lo), d, m8), a3 = fmaf(cvt_ubyte<3>(lo), d, m8);
+                const float b0 = fmaf(cvt_ubyte<0>(hi), d16, m8), b1 = fmaf(cvt_ubyte<1>(hi), d16, m8);
+                const float b2 = fmaf(cvt_ubyte<2>(hi), d16, m8), b3 = fmaf(cvt_ubyte<3>(hi), d16, m8);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, xl[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, xl[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, xl[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, xl[g].w, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, xh[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, xh[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, xh[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b3, xh[g].w, acc[g], 0, 0, 0);
+            }
+        }
+        float* xw = xs + ((s + 1) & 1) * TP * PF_LDW_Q4;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(xw + xo[i]) = xr[i];
+        wc = wn;
+        dc = dn;
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float* dst = a.P + ((size_t)ks * TP + g * 16 + li) * a.rows + row0 + (lane >> 4) * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
+        }
+    }
+}
+
 // x[t] = token_embedding_table(:, token_t)                                              llama2.f90:520
 __global__ void pf_embed_kernel(const float* __restrict__ table, const int* __restrict__ tokens0, float* __restrict__ X, int E) {
     const int t = blockIdx.y;

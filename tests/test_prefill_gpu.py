@@ -106,9 +106,10 @@ def test_prefill_argument_errors(gguf):
     m.close()
 
 
-def test_prefill_q4_falls_back_to_the_token_by_token_pass(gguf):
-    """q4_0 contexts take the token-by-token pass inside llmk_prefill: bit-identical to llmk_forward"""
-    fw = gguf.synth_fused(gguf.SHAPES["tiny-gqa"], 4242, 2)
+def test_prefill_falls_back_to_the_token_by_token_pass_when_the_shape_does_not_tile(gguf):
+    """q4_0 with a hidden size that is not a multiple of the 128-column step (tiny-hs64: H = 704): llmk_prefill runs the
+    token-by-token pass inside and is bit-identical to llmk_forward"""
+    fw = gguf.synth_fused(gguf.SHAPES["tiny-hs64"], 4242, 2)
     prompt = [2, 40, 41, 42, 43]
     a = llmk.Llmk(fw)
     for pos, tok in enumerate(prompt, 1):
@@ -116,6 +117,29 @@ def test_prefill_q4_falls_back_to_the_token_by_token_pass(gguf):
     b = llmk.Llmk(fw)
     assert np.array_equal(b.prefill(prompt, 1), ref)
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-70bish", 33), ("tk-small16", 40), ("tk-small", 7)])
+def test_prefill_q4_matches_oracle_on_decoded_weights(shape, n, gguf):
+    """q4_0 matrices: the A operand of the MFMA is (nibble - 8) * d computed in registers; pinned, like the q4_0 decode
+    path, to the f32 reference arithmetic on the host-decoded weights; then decoding continues from the cache"""
+    s = gguf.SHAPES[shape]
+    fw = gguf.synth_fused(s, 4242, 2)
+    rng = np.random.default_rng(4)
+    prompt = [2] + (rng.integers(3, s.vocab_size, n - 1) + 1).tolist()
+    o = Oracle(fw.as_f32(), "omp")
+    for pos, tok in enumerate(prompt, 1):
+        ol = o.forward(tok, pos)
+    m = llmk.Llmk(fw)
+    lg = m.prefill(prompt, 1)
+    assert rel_err(lg[None], ol[None]).max() <= REL_TOL
+    tok = int(np.argmax(ol)) + 1
+    for pos in range(n + 1, min(n + 5, s.seq_len) + 1):
+        ol = o.forward(tok, pos)
+        lg = m.forward(tok, pos)
+        assert rel_err(lg[None], ol[None]).max() <= REL_TOL
+        tok = int(np.argmax(ol)) + 1
+    m.close()
 
 
 @pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-hs64", 33), ("tk-small16", 40), ("tiny-hs128", 5)])
