@@ -1,6 +1,6 @@
 """prefill timing: [LLMK_WT=1 for f16] python tests/host_tools/pf_time.py [n ...]"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import llm_f90_amd
 from llm_f90_amd import llmk

@@ -1,6 +1,7 @@
 """prefill timing on the Llama-2-7B q4_0 shapes: python tests/host_tools/pf_time_7b.py [n ...]"""
+import os
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import llm_f90_amd
 from llm_f90_amd import llmk

@@ -1,5 +1,5 @@
-import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import llm_f90_amd
 from llm_f90_amd import llmk
 from llm_f90_amd.tools import gguf

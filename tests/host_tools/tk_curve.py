@@ -1,6 +1,7 @@
 """token kernel duration vs KV length: python tests/host_tools/tk_curve.py [positions...]"""
+import os
 import sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import llm_f90_amd
 from llm_f90_amd import llmk
 from llm_f90_amd.tools import gguf

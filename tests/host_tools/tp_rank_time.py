@@ -2,8 +2,9 @@
 rank 0 of 8 of a 70B-shaped model with fewer layers (per-layer times are what matter).
     python tests/host_tools/tp_rank_time.py [layers=4] [tp=8]
 """
+import os
 import sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import llm_f90_amd
 from llm_f90_amd import llmk
