@@ -53,19 +53,40 @@ def bytes_per_token(s: gguf.LlamaShape, wtype: int, mean_pos: float) -> float:
             + V * 4)                             # logits write
 
 
-def pmc_traffic(kernel_substr: str):
-    """HBM read bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC pass
-    (profiles/rNN_pmc_fetch_size.csv: FETCH_SIZE x 2 x 1024, the gfx950 correction of
-    MI355X_MICROARCH.md); None when no profile is committed."""
+def pmc_traffic(kernel_substr: str, shape_name: str, type_name: str):
+    """HBM read bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC pass OF THIS
+    workload (profiles/rNN*_<shape>_<type>_pmc_fetch_size.csv: FETCH_SIZE x 2 x 1024, the gfx950 correction of
+    MI355X_MICROARCH.md); None when no profile of this shape and weight type is committed.  (Round-1 files carry no
+    workload in their name: they are all TinyLlama f32.)"""
+    import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{shape_name}_{type_name}_pmc_fetch_size.csv")))
+    if not files and (shape_name, type_name) == ("tinyllama", "f32"):
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r01*_pmc_fetch_size.csv")))
     if not files:
         return None
-    import csv
     for row in csv.DictReader(open(files[-1])):
         if kernel_substr in row["kernel"]:
             return float(row["avg_FETCH_SIZE"]) * 2 * 1024
     return None
+
+
+def transcript_ids(text: bytes, V: int):
+    """1-based token ids of a CLI transcript over tools.gguf.vocab_strings (unique printable strings)."""
+    ids, i = [], 0
+    while i < len(text):
+        m = re.match(rb"<(\d{5})>", text[i:])
+        if m:
+            ids.append(int(m.group(1)) + 1); i += 7
+        elif text.startswith(b"<unk>", i):
+            ids.append(1); i += 5
+        elif text.startswith(b"</s>", i):
+            ids.append(3); i += 4
+        elif text.startswith(b"<s>", i):
+            ids.append(2); i += 3
+        else:
+            ids.append(3 + text[i] - 32 + 1); i += 1
+    return ids
 
 
 def cpu_baseline(fw, shape_name: str, wtype: int, n_ref: int = 128):
@@ -83,7 +104,9 @@ def cpu_baseline(fw, shape_name: str, wtype: int, n_ref: int = 128):
                 r = subprocess.run(cmd, capture_output=True, timeout=600, cwd=td)
                 m = re.search(rb"([0-9.Ee+-]+)\s*tokens/second", r.stdout)
                 if r.returncode == 0 and m:
-                    return {"value": float(m.group(1)), "unit": "tokens/s", "cores": 1, "kind": "reference",
+                    lines = r.stdout.split(b"\n")          # line 0: " data offset ...", line 1: the generated text
+                    return {"_ids": transcript_ids(lines[1].rstrip(b" "), fw.shape.vocab_size) if len(lines) > 1 else [],
+                            "value": float(m.group(1)), "unit": "tokens/s", "cores": 1, "kind": "reference",
                             "sample": f"oracle/_ref/llm_ref (real reference, amdflang -O3 -march=native -ffast-math "
                                       f"-funroll-loops) -n {n_ref} -t 0 on the same synthetic GGUF, 1 thread pinned; "
                                       f"host has {os.cpu_count()} logical cores"}
@@ -259,11 +282,13 @@ def main():
 
     step = m.forward_greedy if a.greedy_on_device else None
     token = 2
+    gpu_ids = []                 # the greedy transcript, compared with the reference's own at the end
     for pos in range(1, W + 1):  # untimed warm-up (first call also captures the hipGraph)
         if step:
             token = step(token, pos)
         else:
             token = int(np.argmax(m.forward(token, pos))) + 1
+        gpu_ids.append(token)
     barrier()
     lib, h, lg = llmk.lib(), m._h, m._logits
     import ctypes as C
@@ -277,6 +302,7 @@ def main():
         else:
             rc = lib.llmk_forward(h, token, pos, lgp)
             token = int(lg.argmax()) + 1
+        gpu_ids.append(token)
         if rc:
             raise SystemExit(f"llmk_forward failed: {rc}")
     barrier()
@@ -305,9 +331,10 @@ def main():
         # 176.2 MB a layer streams).
         try:
             ms, b = m.time_kernel(6, 100)
-            out["roofline"] = {"bound": "hbm", "kernel": "token_kernel<TinyLlama> (persistent whole-token pass: 22 layers + classifier)",
+            out["roofline"] = {"bound": "hbm", "kernel": f"token_kernel<{a.shape}, {a.type}> (persistent whole-token pass: "
+                                                         f"{shape.n_layers} layers + classifier)",
                                "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("token_kernel"),
+                               "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("token_kernel", a.shape, a.type),
                                "bytes_per_launch": b, "us_per_launch": ms * 1000,
                                "note": f"bytes_per_launch = algorithmic bytes of one token at KV length {W + K}"}
         except llmk.LlmkError:
@@ -319,16 +346,29 @@ def main():
                 kms, kb = m.time_kernel(k, 5 * shape.n_layers)
                 per_k[KERNEL_NAMES[k]] = {"us": round(kms * 1000, 3), "GBps": round(kb / kms / 1e6, 1)}
             ach = b / (ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "gemv_kernel<f32,SWIGLU,NORM> (rmsnorm+w1|w3 GEMV+SwiGLU)",
+            kname = "gemv_q4_kernel<SWIGLU,NORM>" if wtype == 2 else f"gemv_kernel<{a.type},SWIGLU,NORM>"
+            out["roofline"] = {"bound": "hbm", "kernel": kname + " (rmsnorm+w1|w3 GEMV+SwiGLU)",
                                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": pmc_traffic("gemv_kernel<0, 3, true"), "bytes_per_launch": b,
+                               "traffic": pmc_traffic("gemv_q4_kernel<3, true" if wtype == 2 else f"gemv_kernel<{wtype}, 3, true", a.shape, a.type),
+                               "bytes_per_launch": b,
                                "us_per_launch": ms * 1000, "kernels": per_k}
         tok_gbs = bpt * (tok_s / (1 if a.tp else world)) / 1e9 / (world if a.tp else 1)   # per-GPU HBM rate
         out["token_roofline"] = {"bytes_per_token": bpt, "achieved": tok_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": tok_gbs / HBM_PEAK_GBS, "roofline_tok_s": HBM_PEAK_GBS * 1e9 / bpt}
         out["setup_s"] = {"weights_gen": round(t_gen, 1), "upload": round(t_up, 1)}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fw, a.shape, wtype) if fw is not None else None
+            cb = cpu_baseline(fw, a.shape, wtype) if fw is not None else None
+            if cb is not None and "_ids" in cb:
+                # free parity check at the bench's own size: the REAL reference's greedy transcript (same weights, same
+                # box, positions 1..n) against the ids the GPU just produced in the timed loop
+                ref_ids = cb.pop("_ids")
+                n = min(len(ref_ids), len(gpu_ids))
+                same = [x == y for x, y in zip(ref_ids[:n], gpu_ids[:n])]
+                first = same.index(False) if False in same else None
+                cb["ids_match"] = f"{sum(same)}/{n}"
+                cb["first_mismatch_pos"] = None if first is None else first + 1
+                out["ids_match"] = cb["ids_match"]
+            out["cpu_baseline"] = cb
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     rep.close()

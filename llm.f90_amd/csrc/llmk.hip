@@ -84,6 +84,8 @@ struct llmk_ctx {
     int n_cu = 256;
     // persistent whole-token kernel (token_kernel.h)
     bool use_tk = false;
+    bool tk_short_grid = false;   // libllmk_debug.so only (LLMK_TK_INJECT_TIMEOUT)
+    bool tk_retired = false;   // the token kernel timed out once on this ctx: it stays on the multi-kernel path
     int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x
     float4* d_zeros = nullptr;
@@ -105,11 +107,27 @@ size_t row_bytes_for(int type, int K) {
     return 0;
 }
 
+// llmk_create walks the token pass once with g_prepare set: nothing is launched, but every kernel whose dynamic LDS
+// request (the staged activation vector, the attention score row) exceeds the 64 KB default limit gets its limit raised,
+// so a long context or a wide contraction fails at create (LLMK_E_SHAPE beyond 160 KB) and never at the first forward.
+thread_local bool g_prepare = false;
+constexpr size_t LDS_DEFAULT_LIMIT = 64 * 1024, LDS_MAX = 160 * 1024;
+template <class F>
+bool prepare_only(F kernel, size_t smem, hipError_t* e) {
+    if (!g_prepare) return false;
+    *e = smem > LDS_MAX ? hipErrorInvalidValue
+       : smem > LDS_DEFAULT_LIMIT ? hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+                                  : hipSuccess;
+    return true;
+}
+
 template <int WT, int EPI, bool NORM, int ROWS, int NCH>
 hipError_t launch_gemv(hipStream_t st, const GemvArgs& a) {
     const int njobs = (EPI == EPI_SWIGLU) ? a.H : a.rows / ROWS;
     const int blocks = (njobs + GEMV_WAVES - 1) / GEMV_WAVES;
     const size_t smem = 16 + (size_t)a.K * sizeof(float);
+    hipError_t pe;
+    if (prepare_only(gemv_kernel<WT, EPI, NORM, ROWS, NCH>, smem, &pe)) return pe;
     hipLaunchKernelGGL((gemv_kernel<WT, EPI, NORM, ROWS, NCH>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a);
     return hipGetLastError();
 }
@@ -142,6 +160,8 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
 #define Q4_LAUNCH(NP_)                                                                                           \
             do {                                                                                                 \
                 const int blocks = (npairs + GEMV_WAVES * NP_ - 1) / (GEMV_WAVES * NP_);                         \
+                hipError_t pe;                                                                                   \
+                if (prepare_only(gemv_q4_kernel<EPI, NORM, NP_>, smem, &pe)) return pe;                          \
                 hipLaunchKernelGGL((gemv_q4_kernel<EPI, NORM, NP_>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a); \
             } while (0)
             if (npairs / (GEMV_WAVES * 4) >= want) Q4_LAUNCH(4);
@@ -158,8 +178,12 @@ hipError_t launch_attn(llmk_ctx* c, int l) {
     const float* vc = c->d_vc + (size_t)l * c->S * c->KVl;
     const size_t smem = (516 + (size_t)c->S) * sizeof(float);
 #define ATT(HS_)                                                                                                 \
-    hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nhl), dim3(256), smem, c->stream, c->d_q, kc, vc, c->d_xb,     \
-                       c->d_tokpos, c->KVl, c->kv_mul)
+    do {                                                                                                         \
+        hipError_t pe;                                                                                           \
+        if (prepare_only(attn_kernel<HS_>, smem, &pe)) return pe;                                                \
+        hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nhl), dim3(256), smem, c->stream, c->d_q, kc, vc, c->d_xb, \
+                           c->d_tokpos, c->KVl, c->kv_mul);                                                      \
+    } while (0)
     switch (c->hs) {
         case 16: ATT(16); break;
         case 32: ATT(32); break;
@@ -272,8 +296,8 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     a.trace = c->d_trace;
     a.L = c->L;
     a.S = c->S;
-    a.nosync = getenv("LLMK_TK_NOSYNC") ? 1 : 0;
-    hipLaunchKernelGGL((token_kernel<TK>), dim3(TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
+    a.nosync = (TK_DEBUG && getenv("LLMK_TK_NOSYNC")) ? 1 : 0;   // libllmk_debug.so only
+    hipLaunchKernelGGL((token_kernel<TK>), dim3((TK_DEBUG && c->tk_short_grid) ? TK_NCU - 1 : TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
     return hipGetLastError();
 }
 hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false) {
@@ -295,13 +319,20 @@ int tk_setup(llmk_ctx* c, int id) {
     const size_t lds = (size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float);   // scores + exp(scores)
     c->tk_lds = lds < 96 * 1024 ? 96 * 1024 : lds;   // > 80 KB: never two workgroups on one CU
     if (c->tk_lds > 160 * 1024) return LLMK_OK;      // context too long for the in-LDS score row: multi-kernel path
+    // The kernel spins on its peers, so all TK_NCU workgroups must be co-resident: one per CU by construction (the LDS
+    // request excludes a second one), which needs n_cu >= TK_NCU (checked by the caller) and a register/LDS budget the
+    // hardware admits.  Assert it with the occupancy query instead of assuming it; a part that cannot host the grid takes
+    // the multi-kernel path.  (hipLaunchCooperativeKernel would run the same check per launch for +15-19 us each.)
+    HIPCHK(hipFuncSetAttribute((const void*)token_kernel<TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, token_kernel<TK>, TK_THREADS, c->tk_lds));
+    if (per_cu < 1 || (long long)per_cu * c->n_cu < TK_NCU) return LLMK_OK;
     const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H;
     HIPCHK(hipMalloc(&c->d_gran, ngran * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
-    if (getenv("LLMK_TK_TRACE")) HIPCHK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));
+    if (TK_DEBUG && getenv("LLMK_TK_TRACE")) HIPCHK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));   // libllmk_debug.so only
     HIPCHK(hipMemset(c->d_gran, 0, ngran * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->d_zeros, 0, (size_t)TK_NCU * TK_WAVES * 1024));
-    HIPCHK(hipFuncSetAttribute((const void*)token_kernel<TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
     c->use_tk = true;
     c->tk_shape = id;
     return LLMK_OK;
@@ -413,6 +444,24 @@ int check_ready(llmk_ctx* c) {
     return LLMK_OK;
 }
 
+// The persistent kernel reported a timed-out exchange (its workgroups were not all running: the GPU was shared, or a
+// wedged peer).  Its error word is sticky by design (every CU drains instead of spinning on), so: clear it, retire the
+// token kernel for this context and tell the user once.  The caller re-runs the SAME position on the multi-kernel path,
+// which rewrites that position's KV rows and recomputes x from the embedding: nothing of the failed launch survives.
+int tk_retire(llmk_ctx* c, unsigned code, int pos) {
+    HIPCHK(hipMemsetAsync(c->d_logits + c->V, 0, sizeof(float), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
+    c->h_next[1] = 0;
+    c->use_tk = false;
+    c->tk_retired = true;
+    if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }
+    if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
+    fprintf(stderr, "llmk: the persistent token kernel timed out waiting for its peer workgroups (code 0x%x, position %d); "
+                    "this context continues on the multi-kernel path\n", code, pos);
+    return LLMK_OK;
+}
+
 int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
     int rc = check_ready(c);
     if (rc) return rc;
@@ -420,31 +469,36 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
     HIPCHK(hipSetDevice(c->cfg.device));
     c->h_tokpos[0] = token - 1;
     c->h_tokpos[1] = pos;
-    c->h_tokpos[2] += 1;  // token serial: makes every exchange epoch of this pass unique
     const bool timed = (c->cfg.flags & LLMK_FLAG_TIMINGS) != 0;
-    if (c->tp_size > 1 || c->comm) {   // tensor-parallel: eager launches with RCCL collectives in between
-        rc = enqueue_token_tp(c);
-        if (rc) return rc;
-        HIPCHK(enqueue_tail(c, greedy));
-    } else if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
-        HIPCHK(enqueue_token(c, greedy, timed));
-    } else if (c->use_tk && !greedy && c->tk_direct) {
-        reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
-        HIPCHK(launch_token_kernel(c, true));
-    } else {
-        hipGraphExec_t* g = greedy ? &c->graph_greedy : &c->graph_logits;
-        if (!*g) {
-            rc = build_graph(c, greedy, g);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        c->h_tokpos[2] += 1;  // token serial: makes every exchange epoch of this pass unique
+        // debug library only: launch the token kernel one workgroup short at this position, so its peers really time out
+        c->tk_short_grid = TK_DEBUG && c->use_tk && getenv("LLMK_TK_INJECT_TIMEOUT") && atoi(getenv("LLMK_TK_INJECT_TIMEOUT")) == pos;
+        if (c->tp_size > 1 || c->comm) {   // tensor-parallel: eager launches with the collectives in between
+            rc = enqueue_token_tp(c);
             if (rc) return rc;
+            HIPCHK(enqueue_tail(c, greedy));
+        } else if (timed || (c->cfg.flags & LLMK_FLAG_NO_GRAPH)) {
+            HIPCHK(enqueue_token(c, greedy, timed));
+        } else if (c->use_tk && !greedy && c->tk_direct) {
+            reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
+            HIPCHK(launch_token_kernel(c, true));
+        } else {
+            hipGraphExec_t* g = greedy ? &c->graph_greedy : &c->graph_logits;
+            if (!*g) {
+                rc = build_graph(c, greedy, g);
+                if (rc) return rc;
+            }
+            HIPCHK(hipGraphLaunch(*g, c->stream));
         }
-        HIPCHK(hipGraphLaunch(*g, c->stream));
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->use_tk) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!c->use_tk) return LLMK_OK;
         const unsigned err = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
-        if (err != 0) return LLMK_E_TIMEOUT;
+        if (err == 0) return LLMK_OK;
+        rc = tk_retire(c, err, pos);   // then once more, on the multi-kernel path
+        if (rc) return rc;
     }
-    return LLMK_OK;
+    return LLMK_E_TIMEOUT;
 }
 
 // ---- batched prefill (prefill.h) ------------------------------------------------------------------------
@@ -634,6 +688,9 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     // rows and vocab rows; every local extent must keep the alignment rules above
     const int kalign = cfg->weight_type == LLMK_TYPE_Q4_0 ? 32 : cfg->weight_type == LLMK_TYPE_F16 ? 8 : 4;
     if (nkv % tp_size || H % tp_size || V % tp_size || (H / tp_size) % kalign || ((V / tp_size) & 1)) return LLMK_E_SHAPE;
+    // the contraction slices of wo (the local heads' columns) and of w2 must start and end on the weight type's
+    // column granule (q4_0: a 32-weight block), and the local K/V rows must keep their RoPE pairs
+    if (((nh / tp_size) * hs) % kalign || (((nkv / tp_size) * hs) & 1)) return LLMK_E_SHAPE;
     if (cfg->weight_type != LLMK_TYPE_F32 && cfg->weight_type != LLMK_TYPE_F16 && cfg->weight_type != LLMK_TYPE_Q4_0)
         return LLMK_E_TYPE;
     int ndev = 0;
@@ -716,6 +773,18 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
         if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
         if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
+    }
+    if (rc == LLMK_OK) {   // raise the dynamic-LDS limits the token pass needs, or reject the shape here (see g_prepare)
+        g_prepare = true;
+        hipError_t pe = launch_qkv(c, 0);
+        if (pe == hipSuccess) pe = launch_attn(c, 0);
+        if (pe == hipSuccess) pe = launch_wo(c, 0);
+        if (pe == hipSuccess) pe = launch_w13(c, 0);
+        if (pe == hipSuccess) pe = launch_w2(c, 0);
+        if (pe == hipSuccess) pe = launch_cls(c);
+        g_prepare = false;
+        if (pe == hipErrorInvalidValue) rc = LLMK_E_SHAPE;   // context or contraction width needs more than 160 KB of LDS
+        else CK(pe);
     }
     if (rc == LLMK_OK) {
         CK(hipMemset(c->d_logits, 0, ((size_t)V + 4) * sizeof(float)));
@@ -906,7 +975,10 @@ int llmk_reset(llmk_ctx* c) {
     const size_t kvn = (size_t)c->L * c->S * c->KVl * sizeof(float);
     HIPCHK(hipMemsetAsync(c->d_kc, 0, kvn, c->stream));
     HIPCHK(hipMemsetAsync(c->d_vc, 0, kvn, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_logits + c->V, 0, sizeof(float), c->stream));   // the token kernel's sticky error word
     HIPCHK(hipStreamSynchronize(c->stream));
+    reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
+    c->h_next[1] = 0;
     for (int i = 0; i < 5; ++i) c->times[i] = 0.f;
     return LLMK_OK;
 }
@@ -961,6 +1033,8 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[6], c->ev[7]));
     *avg_ms = ms / (float)iters;
+    if (kernel == 6) c->h_tokpos[2] += iters + 3;   // the device-side serial was bumped once per launch: keep the host's in step
+                                                     // (exchange epochs must stay unique per serial)
     if (bytes_per_launch) {
         const int tids[8] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS, -1, LLMK_W13};
         double b = 0;

@@ -40,6 +40,13 @@ constexpr int TK_THREADS = TK_WAVES * WAVE;
 constexpr int TK_TCOLS = 8;               // 16-byte vector columns per tile (8 x 64 lanes x 4 floats = 2048)
 constexpr unsigned TK_SPIN_LIMIT = 1u << 22;
 constexpr int TK_TRACE_N = 16 * 64;       // stamps per CU: 16 per layer, first 64 layers
+// Timing aids (wall-clock stamps of the service wave, "do not wait for tags") exist only in the debug build
+// (make -C llm.f90_amd debug -> libllmk_debug.so, -DLLMK_TK_DEBUG): in the product library every use below folds away.
+#ifdef LLMK_TK_DEBUG
+constexpr bool TK_DEBUG = true;
+#else
+constexpr bool TK_DEBUG = false;
+#endif
 
 struct TokenArgs {
     const float* emb;        // [V][E]
@@ -65,9 +72,9 @@ struct TokenArgs {
     float* logits;           // [V]
     unsigned* err;           // sticky error word (0 = ok)
     const float4* zeros;     // [NCU*TK_WAVES] 1 KB blocks of zeros: what empty ring slots / ragged row ends read
-    unsigned long long* trace;  // optional [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave (debug)
+    unsigned long long* trace;  // debug build only: [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave
     int L, S;
-    int nosync;              // debug: do not wait for exchange tags (wrong results; measures the pure streaming rate)
+    int nosync;              // debug build only: do not wait for exchange tags (wrong results; measures the pure streaming rate)
     // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
     int q0, qn, o0, on;
     int c0, cn;              // this CU's rows of the classifier
@@ -161,7 +168,7 @@ template <int NL>
 __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* dst,
                                                unsigned* err, int lane, bool nowait, unsigned long long* dbg) {
     for (unsigned spin = 0;; ++spin) {
-        const unsigned long long tp0 = dbg ? wall_clock64() : 0;
+        const unsigned long long tp0 = (TK_DEBUG && dbg) ? wall_clock64() : 0;
         tk_v4u r[NL];
         // NO predicate on the loads: a per-load condition makes hipcc branch around each one and wait
         // vmcnt(0) per element (NL dependent round trips instead of one)
@@ -176,7 +183,7 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
             *reinterpret_cast<float2*>(dst + i) = make_float2(__uint_as_float(r[k].x), __uint_as_float(r[k].z));
         }
         if (__all(ok) || nowait) {
-            if (dbg && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
+            if (TK_DEBUG && dbg && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
             return true;
         }
         if ((spin & 63) == 63) {
@@ -496,15 +503,15 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
         const float d = row16_sum(dot4(qv, kcur[sub], 0.f));
         if (wid == 0 && lane == LPT - 1) att[npast] = d / scale;
     }
-    if (dbg) dbg[0] = wall_clock64();
+    if (TK_DEBUG && dbg) dbg[0] = wall_clock64();
     tk_barrier();
-    if (dbg) dbg[1] = wall_clock64();
+    if (TK_DEBUG && dbg) dbg[1] = wall_clock64();
     // every wave folds max and sum over ALL scores itself: no cross-wave reduction, no extra barriers.  exp() is
     // evaluated once per score here (each wave keeps its own copy of what it wrote: same values, benign overlap)
     float m = -INFINITY;
     for (int t = lane; t < pos; t += WAVE) m = fmaxf(m, att[t]);
     m = wave_max(m);
-    if (dbg) dbg[3] = wall_clock64();
+    if (TK_DEBUG && dbg) dbg[3] = wall_clock64();
     float s = 0.f;
     for (int t = lane; t < pos; t += WAVE) {
         const float e = expf(att[t] - m);
@@ -512,7 +519,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
         s += e;
     }
     s = wave_sum(s);
-    if (dbg) dbg[4] = wall_clock64();
+    if (TK_DEBUG && dbg) dbg[4] = wall_clock64();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < pos; base += TILE) {
@@ -539,7 +546,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
         }
     }
     red[(wid * TPW + tl) * LPT + sub] = acc;   // the service wave folds the waves*TPW partials per dim
-    if (dbg) dbg[2] = wall_clock64();
+    if (TK_DEBUG && dbg) dbg[2] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +575,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         rope_cs[lane] = cosf(rval);
         rope_cs[SH::HS / 2 + lane] = sinf(rval);
     }
-    unsigned long long* tr = a.trace ? a.trace + (size_t)c * TK_TRACE_N : nullptr;
+    unsigned long long* tr = (TK_DEBUG && a.trace) ? a.trace + (size_t)c * TK_TRACE_N : nullptr;
+    const bool nosync = TK_DEBUG && a.nosync != 0;
 #define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
 
     for (int l = 0; l < L; ++l) {
@@ -584,7 +592,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
             } else {
-                ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+                ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
             }
             TK_STAMP(1);
             xn_att = nrm.apply(xraw, xs, lane);
@@ -627,7 +635,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 qs[lane] = __uint_as_float((unsigned)xq);
                 qs[SH::HS + lane] = __uint_as_float((unsigned)xk);
                 qs[2 * SH::HS + lane] = __uint_as_float((unsigned)xv);
-                if (__all(good) || a.nosync) break;
+                if (__all(good) || nosync) break;
                 if ((spin & 63) == 63) {
                     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
                     if (spin > TK_SPIN_LIMIT) {
@@ -656,7 +664,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_xb + my_head * SH::HS + lane, e_att, o);
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        if (!att_cu) ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        if (!att_cu) ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         TK_STAMP(7);
         tk_barrier();
         tk_barrier();
@@ -668,7 +676,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
-        ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+        ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
         TK_STAMP(9);
         const float xn_ffn = nrm.apply(xraw, xs, lane);
         tk_barrier();
@@ -683,7 +691,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        ok = tk_gather<SH::H>(a.g_hb, e_a, xs, a.err, lane, a.nosync != 0, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        ok = tk_gather<SH::H>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -702,7 +710,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     TkNorm<SH::E> nrmf;
     nrmf.prefetch(a.rms_final, lane);
-    ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, a.nosync != 0) && ok;
+    ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
     const float xn_fin = nrmf.apply(xraw, xs, lane);
     tk_barrier();
     tk_barrier();

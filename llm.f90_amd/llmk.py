@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libllmk.so")
+# LLMK_LIB selects another build of the same ABI (csrc/libllmk_debug.so: the persistent kernel's timing aids)
+LIB_PATH = os.environ.get("LLMK_LIB") or os.path.join(_HERE, "csrc", "libllmk.so")
 
 TENSOR_IDS = {
     "token_embedding_table": 0, "rms_att_weight": 1, "rms_ffn_weight": 2, "wqkv": 3, "wo": 4, "w13": 5, "w2": 6,

@@ -74,6 +74,10 @@ SHAPES: Dict[str, LlamaShape] = {
     "tk-small": LlamaShape(256, 768, 2, 4, 2, 1024, 64),
     # the same for f16 matrices (a row must be whole 1 KB segments at 2 bytes per weight)
     "tk-small16": LlamaShape(512, 1536, 2, 8, 2, 1024, 64),
+    # long-context parity shapes: the KV length crosses the timestep tile of the attention kernels several times
+    # (persistent kernel and attn_kernel<64>: 256 timesteps per tile; attn_kernel<128>: 128)
+    "tk-small-long": LlamaShape(256, 768, 2, 4, 2, 1024, 704),
+    "tiny-hs128-long": LlamaShape(512, 1376, 2, 4, 4, 640, 320),
 }
 
 

@@ -46,10 +46,12 @@ def test_cli_device_argmax_and_verbose_timings(gguf, tmp_path):
     ref = bytes(g["stdout"]).split(b"\n")
     out = _run(["-m", path, "-n", str(int(g["n"])), "--device-argmax"], str(tmp_path)).split(b"\n")
     assert out[1] == ref[1]
-    out = _run(["-m", path, "-n", str(int(g["n"])), "-v"], str(tmp_path))
+    out = _run(["-m", path, "-n", str(int(g["n"])), "-v", "--timings"], str(tmp_path))
     assert ref[1] in out
     t = [float(x) for x in re.findall(rb"^\s+[1-5]\s+([0-9.Ee+-]+)\s*$", out, re.M)]
-    assert len(t) == 5 and t[0] > 0 and t[3] > 0 and t[4] > 0    # hipEvent section timers are live under -v
+    assert len(t) == 5 and t[0] > 0 and t[3] > 0 and t[4] > 0    # hipEvent section timers are live under --timings
+    out = _run(["-m", path, "-n", str(int(g["n"])), "-v"], str(tmp_path))
+    assert ref[1] in out                                          # -v alone: the fast path, verbose prints only
 
 
 @pytest.mark.parametrize("wtype", [1, 2], ids=["f16", "q4_0"])

@@ -3,7 +3,7 @@ golden vectors produced by the real reference (tests/golden/make_golden.py). CPU
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, REL_TOL, load_golden, rel_err
+from conftest import GOLDEN_CASES, REL_TOL, compact_err, load_golden, rel_err, safe_positions
 from oracle.oracle import Oracle
 
 
@@ -19,6 +19,20 @@ def test_oracle_matches_reference(tag, flavour, gguf):
     assert err.max() <= 1e-5, err
     assert err.max() <= REL_TOL
     assert np.array_equal(toks, g["tokens"])            # bit-exact greedy ids (1-based)
+
+
+def test_oracle_matches_reference_at_full_tinyllama_size(gguf):
+    """BASELINE.json configs[0]: the real reference at its compiled-in TinyLlama-1.1B dims, 320 positions on the synthetic
+    weights bench.py uses (compact golden).  The oracle replays the first positions teacher-forced with the reference's
+    own tokens (a CPU token is ~0.3 s here; the GPU tests replay all 320)."""
+    g = load_golden("tinyllama")
+    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
+    n = 12
+    toks, logits = Oracle(fw, "omp").generate(n, prompt=g["tokens"][:n].tolist())
+    err = compact_err(logits, g, n)
+    assert err.max() <= 1e-5, err
+    ok = safe_positions(g, n)
+    assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][:n][ok])
 
 
 def test_omp_flavour_is_bit_identical_to_strict(gguf):

@@ -4,7 +4,7 @@ and (b) the oracle on the same seeded inputs.  Tolerance (BASELINE.json): logits
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, REL_TOL, load_golden, rel_err
+from conftest import GOLDEN_CASES, REL_TOL, compact_err, load_golden, rel_err, safe_positions
 from llm_f90_amd import llmk
 from oracle.oracle import Oracle
 
@@ -138,30 +138,67 @@ def test_token_kernel_full_context_reset_and_determinism(gguf):
     m.close()
 
 
-def test_tinyllama_size_token_kernel_vs_multikernel_vs_oracle(gguf):
-    """BASELINE.json's full size (TinyLlama-1.1B f32, 4.4 GB of synthetic weights).  The oracle checks the
-    first positions (seconds of CPU); the two independent GPU paths must agree to rounding over 300
-    positions, which crosses the 256-timestep tile of the in-kernel attention."""
-    s = gguf.SHAPES["tinyllama"]
-    fw = gguf.synth_fused(s, 20260928)
-    n = 300
-    ref = llmk.Llmk(fw, flags=llmk.FLAG_MULTI_KERNEL)
-    rt, rl = ref.generate(n)
-    ref.close()
-    m = llmk.Llmk(fw)
-    assert m.time_kernel(6, 1)[0] > 0              # the persistent kernel is what runs
-    tt, tl = m.generate(n)
+@pytest.mark.parametrize("flags", [0, llmk.FLAG_MULTI_KERNEL], ids=["token-kernel", "multikernel"])
+def test_tinyllama_f32_matches_the_real_reference_over_320_positions(flags, gguf):
+    """BASELINE.json configs[1] at FULL size against the REAL reference (tests/golden/tinyllama.npz: the unmodified-dims
+    llama2.f90 run for 320 positions on the same synthetic weights): every position's top-8 logits, 64 probe columns and
+    checksums within 1e-4 of the position's max |logit|, greedy ids identical wherever the reference's own top-1 margin is
+    above the tolerance.  Teacher-forced with the reference's tokens, so a near-tie cannot derail the comparison.  KV
+    lengths 257..320 run the second 256-timestep tile of tk_attention / attn_kernel<64>."""
+    g = load_golden("tinyllama")
+    n = int(g["n"])
+    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
+    m = llmk.Llmk(fw, flags=flags)
+    if flags == 0:
+        assert m.time_kernel(6, 1)[0] > 0          # the persistent whole-token kernel is what runs
+        m.reset()
+    _, logits = m.generate(n, prompt=g["tokens"].tolist())
     m.close()
-    err = rel_err(tl, rl)
-    assert err.max() <= 2e-5, err.max()            # same arithmetic, different summation order
-    margin = np.sort(rl, axis=1)
-    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(rl).max()
-    assert np.array_equal(tt[safe], rt[safe])
-    k = 4
-    ot, ol = Oracle(fw, "omp").generate(k)
-    assert rel_err(tl[:k], ol).max() <= REL_TOL
-    assert rel_err(rl[:k], ol).max() <= REL_TOL
-    assert np.array_equal(tt[:k], ot)
+    err = compact_err(logits, g)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    ok = safe_positions(g)
+    assert ok.sum() > n // 2
+    assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][ok])
+    # free-running greedy decode reproduces the reference transcript up to its first near-tie
+    first_unsafe = int(np.argmin(ok)) if not ok.all() else n
+    m = llmk.Llmk(fw, flags=flags)
+    toks, _ = m.generate(first_unsafe, want_logits=False, greedy_on_device=True) if first_unsafe else (np.zeros(0, np.int32), None)
+    m.close()
+    assert np.array_equal(toks, g["tokens"][:first_unsafe])
+
+
+def test_tinyllama_f16_token_kernel_matches_oracle_over_300_positions(gguf):
+    """BASELINE.json configs[2] at full size: the f16 persistent kernel against the f32 reference path (oracle, bit-identical
+    to the real reference on every golden) run on the host-decoded f16 weights, 300 positions (KV lengths cross 256),
+    teacher-forced with the oracle's tokens."""
+    s = gguf.SHAPES["tinyllama"]
+    fw = gguf.synth_fused(s, 20260928, 1)
+    n = 300
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    m = llmk.Llmk(fw)
+    assert m.time_kernel(6, 1)[0] > 0
+    m.reset()
+    _, l = m.generate(n, prompt=ot.tolist())
+    m.close()
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+
+
+@pytest.mark.parametrize("shape,hs_tile", [("tiny-gqa", 1024), ("tiny-mha", 512)])
+def test_long_context_small_heads_match_oracle(shape, hs_tile, gguf):
+    """head sizes 16 and 32: attn_kernel's timestep tile is 1024 / 512 there; contexts past it against the oracle (which is
+    bit-identical to the real reference on the committed goldens, tests/test_oracle.py)"""
+    s0 = gguf.SHAPES[shape]
+    s = gguf.LlamaShape(s0.emb_dim, s0.hidden_dim, s0.n_layers, s0.n_heads, s0.n_kv_heads, s0.vocab_size, hs_tile + 40)
+    fw = gguf.synth_fused(s, 606)
+    ot, ol = Oracle(fw, "omp").generate(s.seq_len)
+    m = llmk.Llmk(fw)
+    _, l = m.generate(s.seq_len, prompt=ot.tolist())
+    m.close()
+    assert rel_err(l, ol).max() <= REL_TOL
 
 
 @pytest.mark.parametrize("flags", [0, llmk.FLAG_MULTI_KERNEL], ids=["token-kernel", "multikernel"])
@@ -210,3 +247,88 @@ def test_tinyllama_token_kernel_is_bit_reproducible_and_mode_independent(gguf, m
     t3, l3 = b.generate(24)
     assert np.array_equal(l1, l3) and np.array_equal(t1, t3)
     b.close()
+
+
+def test_token_kernel_timeout_retires_it_and_the_token_is_redone_on_the_multi_kernel_path(gguf):
+    """The persistent kernel spins on its peer workgroups; if one is missing (GPU shared, a wedged launch) every spin is
+    bounded and the pass reports LLMK_E_TIMEOUT internally.  The shim must then clear the sticky device word, retire the
+    token kernel for the ctx and redo the SAME position on the multi-kernel path -- the caller sees a correct answer and a
+    warning.  The debug library (make -C llm.f90_amd debug) launches the kernel one workgroup short at the position named
+    by LLMK_TK_INJECT_TIMEOUT, so the timeout is real; the product library has no such knob."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    dbg = os.path.join(ROOT, "llm.f90_amd", "csrc", "libllmk_debug.so")
+    assert os.path.exists(dbg), "libllmk_debug.so not built (make -C llm.f90_amd debug)"
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import llm_f90_amd\n"
+        "from llm_f90_amd import llmk\n"
+        "from llm_f90_amd.tools import gguf\n"
+        "from conftest import load_golden, rel_err, REL_TOL\n"
+        "g = load_golden('tk-small')\n"
+        "fw = gguf.synth_fused(gguf.SHAPES['tk-small'], int(g['seed']))\n"
+        "m = llmk.Llmk(fw)\n"
+        "assert m.time_kernel(6, 1)[0] > 0\n"
+        "m.reset()\n"
+        "toks, logits = m.generate(int(g['n']))\n"
+        "assert rel_err(logits, g['logits']).max() <= REL_TOL\n"
+        "assert np.array_equal(toks, g['tokens'])\n"
+        "try:\n"
+        "    m.time_kernel(6, 1); raise SystemExit('token kernel still active')\n"
+        "except llmk.LlmkError:\n"
+        "    pass\n"
+        "t2, l2 = m.generate(int(g['n']))\n"            # later sequences on the same ctx keep working
+        "assert np.array_equal(t2, g['tokens'])\n"
+        "print('FALLBACK-OK')\n")
+    env = dict(os.environ, LLMK_LIB=dbg, LLMK_TK_INJECT_TIMEOUT="3")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0 and b"FALLBACK-OK" in r.stdout, r.stdout + r.stderr
+    assert b"timed out" in r.stderr and b"multi-kernel path" in r.stderr
+
+
+def test_llama2_7b_column_geometry_q4_0_matches_oracle(gguf):
+    """BASELINE.json configs[3] at its REAL column geometry -- E 4096, H 11008 (5.375 KB of nibbles per w2 row), head size
+    128, MHA, V 32000 -- with 2 layers so the oracle (f32 reference path on the host-decoded q4_0 weights) finishes in
+    seconds.  160 positions: KV lengths cross the 128-timestep tile of the head-size-128 attention."""
+    s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 192)
+    fw = gguf.synth_fused(s, 7, 2)
+    n = 160
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    for flags in (0, llmk.FLAG_MULTI_KERNEL):
+        m = llmk.Llmk(fw, flags=flags)
+        _, l = m.generate(n, prompt=ot.tolist())
+        m.close()
+        err = rel_err(l, ol)
+        assert err.max() <= REL_TOL, (flags, err.max(), int(np.argmax(err)))
+        assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+
+
+def test_llama2_7b_full_shape_q4_0_properties():
+    """BASELINE.json configs[3] at FULL size (32 layers, 3.7 GB of q4_0 blocks generated directly in block format -- an f32
+    copy for the oracle would be 27 GB): size-independent properties.  (1) two runs are bit-identical; (2) the device
+    argmax picks the host argmax; (3) the default path and the multi-kernel path agree to rounding; (4) llmk_prefill of k
+    tokens leaves the logits k sequential llmk_forward calls leave."""
+    import bench
+    from llm_f90_amd.tools import gguf
+    s = gguf.SHAPES["llama2-7b"]
+    m = bench.build_streamed(s, 2, None, 0, 0, 0, 1, None)
+    n = 24
+    t1, l1 = m.generate(n)
+    t2, l2 = m.generate(n)
+    assert np.all(np.isfinite(l1)) and np.abs(l1).max() > 1e-3
+    assert np.array_equal(l1, l2) and np.array_equal(t1, t2)
+    t3, _ = m.generate(n, want_logits=False, greedy_on_device=True)
+    assert np.array_equal(t3, t1)
+    m.reset()
+    lg = m.prefill([2] + t1[:n - 1].tolist(), 1)
+    assert rel_err(lg[None], l1[n - 1][None]).max() <= REL_TOL
+    m.close()
+    ref = bench.build_streamed(s, 2, None, 0, llmk.FLAG_MULTI_KERNEL, 0, 1, None)
+    _, lr = ref.generate(n, prompt=t1.tolist())
+    ref.close()
+    assert rel_err(l1, lr).max() <= 2e-5

@@ -57,6 +57,29 @@ def test_prefill_matches_oracle(shape, n, gguf):
     m.close()
 
 
+@pytest.mark.parametrize("tag,ks", [("tk-small-long", [255, 256, 257, 300, 513, 704]), ("tiny-hs128-long", [127, 129, 200, 257, 320])])
+def test_prefill_long_prompts_match_the_real_reference(tag, ks, gguf):
+    """Long-context goldens from the real reference: the first k positions of its transcript go through llmk_prefill in
+    one call; the logits of position k must match the reference's -- the batched attention (attn_kernel with a batch
+    dimension) crosses its 256- (head size 64) / 128-timestep (head size 128) tile, at batch boundaries and inside."""
+    g = load_golden(tag)
+    fw = gguf.synth_fused(gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+    fed = [2] + g["tokens"].tolist()                     # token fed at position p (1-based) is fed[p-1]
+    m = llmk.Llmk(fw)
+    for k in ks:
+        m.reset()
+        lg = m.prefill(fed[:k], 1)
+        assert rel_err(lg[None], g["logits"][k - 1][None]).max() <= REL_TOL, k
+    # prefill, then decode across the next tile boundary on the same cache
+    m.reset()
+    k = ks[0] - 20
+    lg = m.prefill(fed[:k], 1)
+    for pos in range(k + 1, k + 41):
+        lg = m.forward(fed[pos - 1], pos)
+        assert rel_err(lg[None], g["logits"][pos - 1][None]).max() <= REL_TOL, pos
+    m.close()
+
+
 def test_prefill_in_two_calls_and_after_decode(gguf):
     """prefill may start at any position: decode 5 tokens, prefill 20 more, compare with the all-sequential run"""
     s = gguf.SHAPES["tiny-gqa"]
