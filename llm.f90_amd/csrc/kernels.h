@@ -41,8 +41,9 @@ struct GemvArgs {
     int E, KV, hs;
     // SWIGLU
     int H;
-    // q4_0 only: scales live after the nibbles
-    const void* W_scales;
+    // q4_0 only (device layout of llmk_upload): a row is its K/2 nibble bytes followed by its K/32 f16 block scales,
+    // rows are row_stride bytes apart (16-byte aligned)
+    int row_stride;
 };
 
 // Wave64 reductions on the DPP crossbar (quad_perm / row_shr / row_bcast), result broadcast through
@@ -115,8 +116,8 @@ __device__ __forceinline__ float dot8h(const uint4& w, const float4& x0, const f
 // Weight-type traits: how one lane pulls "one vector" (16 B) of a row and dots it against x in LDS.
 //   VE = weights per 16-byte vector.  Row r, vector v  <->  weights [v*VE, (v+1)*VE).
 // x in LDS: f32/f16 natural order (float4 xs[K/4]).
-// q4_0 (device layout, re-packed by llmk_upload): nibbles [rows][K/2] bytes, then f16 scales
-// [rows][K/32]; one vector = the 16 nibble bytes of one 32-weight block, low nibbles = elements
+// q4_0 (device layout, re-packed by llmk_upload): per row K/2 nibble bytes, then the row's K/32 f16 scales
+// (row stride = 9K/16 rounded up to 16 bytes); one vector = the 16 nibble bytes of one 32-weight block, low nibbles = elements
 // 0..15, high nibbles = elements 16..31 (ggml block_q4_0).  x is staged TRANSPOSED for it:
 // xs[m*nblk + b] = x[32b+4m .. 32b+4m+3], so the 8 float4 reads a lane needs are lane-contiguous.
 // ------------------------------------------------------------------------------------------------
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
     const int njobs = (EPI == EPI_SWIGLU) ? a.H : (a.rows / ROWS);
     const size_t rb = WTraits<WT>::row_bytes(K);
     const char* Wb = reinterpret_cast<const char*>(a.W);
-    const __half* Sb = reinterpret_cast<const __half*>(a.W_scales);
+    const __half* Sb = nullptr;   // (the generic kernel is not instantiated for q4_0: gemv_q4_kernel below)
 
     const int g = blockIdx.x * GEMV_WAVES + wid;
     const bool active = g < njobs;                 // wave-uniform
@@ -403,8 +404,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     float* xsum = reinterpret_cast<float*>(xs + 8 * xp);      // [nblk] block sums of the staged x
     const int npairs = (EPI == EPI_SWIGLU) ? a.H : (a.rows >> 1);
     const int g0 = (blockIdx.x * GEMV_WAVES + wid) * NP;      // first pair of this wave
-    const uint4* Wn = reinterpret_cast<const uint4*>(a.W);
-    const __half* Sc = reinterpret_cast<const __half*>(a.W_scales);
+    const char* Wb = reinterpret_cast<const char*>(a.W);
+    const size_t RS = (size_t)a.row_stride;
+    const int soff = K >> 1;                                  // a row's scales follow its K/2 nibble bytes
 
     int rows[NR];
 #pragma unroll
@@ -420,8 +422,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
         const int b = min(lane, nblk - 1);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            wq[i] = ldg_nt(Wn + (size_t)rows[i] * nblk + b);
-            wd[i] = Sc[(size_t)rows[i] * nblk + b];
+            const char* rp = Wb + (size_t)rows[i] * RS;
+            wq[i] = ldg_nt(reinterpret_cast<const uint4*>(rp) + b);
+            wd[i] = reinterpret_cast<const __half*>(rp + soff)[b];
         }
     }
     // ---- stage x: transposed float4 groups + per-block sums ------------------------------------
@@ -482,8 +485,9 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
             const int nb = min(bl + WAVE, nblk - 1);
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
-                nq[i] = ldg_nt(Wn + (size_t)rows[i] * nblk + nb);
-                nd[i] = Sc[(size_t)rows[i] * nblk + nb];
+                const char* rp = Wb + (size_t)rows[i] * RS;
+                nq[i] = ldg_nt(reinterpret_cast<const uint4*>(rp) + nb);
+                nd[i] = reinterpret_cast<const __half*>(rp + soff)[nb];
             }
         }
         float4 xl[4], xh[4];
@@ -676,20 +680,22 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     }
 }
 
-// q4_0 re-pack on upload: ggml blocks {f16 d; u8 qs[16]} (18 B, 2-byte aligned) -> 16-byte aligned
-// nibble vectors + a separate f16 scale plane, so the GEMV issues dwordx4 loads.
-__global__ void q4_repack_kernel(const uint8_t* __restrict__ src, uint4* __restrict__ nib, __half* __restrict__ sc,
-                                 size_t nblocks) {
+// q4_0 re-pack on upload: ggml blocks {f16 d; u8 qs[16]} (18 B, 2-byte aligned), bpr per row -> device rows of
+// row_stride bytes: bpr 16-byte aligned nibble vectors (so the GEMV issues dwordx4 loads), then the row's bpr f16 scales.
+__global__ void q4_repack_kernel(const uint8_t* __restrict__ src, char* __restrict__ dst, size_t nblocks, int bpr,
+                                 size_t row_stride) {
     for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += (size_t)gridDim.x * blockDim.x) {
         const uint16_t* p = reinterpret_cast<const uint16_t*>(src + b * 18);
-        uint16_t h = p[0];
-        sc[b] = *reinterpret_cast<__half*>(&h);
+        const size_t row = b / bpr;
+        const int j = (int)(b - row * bpr);
+        char* rp = dst + row * row_stride;
+        reinterpret_cast<uint16_t*>(rp + (size_t)bpr * 16)[j] = p[0];
         uint4 v;
         v.x = (unsigned)p[1] | ((unsigned)p[2] << 16);
         v.y = (unsigned)p[3] | ((unsigned)p[4] << 16);
         v.z = (unsigned)p[5] | ((unsigned)p[6] << 16);
         v.w = (unsigned)p[7] | ((unsigned)p[8] << 16);
-        nib[b] = v;
+        reinterpret_cast<uint4*>(rp)[j] = v;
     }
 }
 

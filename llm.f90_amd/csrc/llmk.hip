@@ -46,10 +46,8 @@ struct TensorDesc {
 };
 
 struct DevTensor {
-    void* data = nullptr;    // f32/f16 rows, or q4_0 nibble plane
-    void* scales = nullptr;  // q4_0 f16 scale plane
-    size_t row_bytes = 0;    // bytes per row in `data`
-    size_t scale_row_bytes = 0;
+    void* data = nullptr;    // f32/f16 rows; q4_0: rows of K/2 nibble bytes followed by the row's K/32 f16 scales
+    size_t row_bytes = 0;    // bytes per row in `data` (q4_0: 9K/16 rounded up to 16)
     int type = LLMK_TYPE_F32;
     bool uploaded = false;
     size_t rows_uploaded = 0;
@@ -86,7 +84,7 @@ struct llmk_ctx {
     bool use_tk = false;
     bool tk_short_grid = false;   // libllmk_debug.so only (LLMK_TK_INJECT_TIMEOUT)
     bool tk_retired = false;   // the token kernel timed out once on this ctx: it stays on the multi-kernel path
-    int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape
+    int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape, 5 Llama-2-7B q4_0
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
@@ -97,6 +95,9 @@ struct llmk_ctx {
 };
 
 namespace {
+
+constexpr size_t TENSOR_SLACK = 64 * 1024;
+size_t q4_row_stride(int K) { return (size_t)K / 2 + (size_t)((K / 32 + 63) / 64) * 128; }
 
 size_t row_bytes_for(int type, int K) {
     switch (type) {
@@ -202,7 +203,7 @@ GemvArgs base_args(llmk_ctx* c, int tid, int l, const float* x, const float* nor
     const TensorDesc& d = c->desc[tid];
     const size_t lrows = d.layered ? (size_t)l * d.rows : 0;
     a.W = (const char*)t.data + lrows * t.row_bytes;
-    a.W_scales = t.scales ? (const char*)t.scales + lrows * t.scale_row_bytes : nullptr;
+    a.row_stride = (int)t.row_bytes;
     a.x = x;
     a.norm_w = norm_w;
     a.y = y;
@@ -305,7 +306,8 @@ hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false) {
         case 1: return launch_token_kernel_t<TkTinyLlama>(c, direct);
         case 2: return launch_token_kernel_t<TkSmall>(c, direct);
         case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct);
-        default: return launch_token_kernel_t<TkSmallF16>(c, direct);
+        case 4: return launch_token_kernel_t<TkSmallF16>(c, direct);
+        default: return launch_token_kernel_t<TkLlama7BQ4>(c, direct);
     }
 }
 
@@ -535,9 +537,9 @@ int pf_setup(llmk_ctx* c) {
 }
 // P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; returns KS through *ks_out
 // q4_0: W = nibble plane of the layer, Wsc = its scale plane
-hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, const void* Wsc, const float* X, int rows, int K, int T, int* ks_out) {
+hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, int* ks_out) {
     PfGemmQ4Args a;
-    a.Wn = (const uint4*)W; a.Sc = (const __half*)Wsc; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
+    a.W = (const char*)W; a.RS = row_stride; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
     int ks, kslice;
     pf_split(c, rows, K, &ks, &kslice);
     a.kslice = kslice;
@@ -599,7 +601,7 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
             const DevTensor& dt = c->t[tid];
             const char* w = (const char*)dt.data + (size_t)l * rows_per_layer * dt.row_bytes;
             if (c->cfg.weight_type == LLMK_TYPE_Q4_0)
-                return pf_gemm_q4(c, w, (const char*)dt.scales + (size_t)l * rows_per_layer * dt.scale_row_bytes, X, rows_per_layer, K, T, ks);
+                return pf_gemm_q4(c, w, (int)dt.row_bytes, X, rows_per_layer, K, T, ks);
             return pf_gemm(c, w, X, rows_per_layer, K, T, ks);
         };
         float* kc = c->d_kc + (size_t)l * c->S * KV;
@@ -738,14 +740,15 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         DevTensor& t = c->t[i];
         t.type = d.matrix ? cfg->weight_type : LLMK_TYPE_F32;
         const size_t rows = (size_t)d.rows * (d.layered ? L : 1);
-        if (t.type == LLMK_TYPE_Q4_0) {
-            t.row_bytes = (size_t)d.K / 2;
-            t.scale_row_bytes = (size_t)d.K / 32 * 2;
-            CK(hipMalloc(&t.data, rows * t.row_bytes));
-            CK(hipMalloc(&t.scales, rows * t.scale_row_bytes));
-        } else {
-            t.row_bytes = row_bytes_for(t.type, d.K);
-            CK(hipMalloc(&t.data, rows * t.row_bytes));
+        // TENSOR_SLACK bytes past the last row: the persistent kernel's last tile of a CU's row range may cover a few rows
+        // beyond it (token_kernel.h, NT_Q / NG_A), which for the last rows of the last layer lie past the tensor
+        // q4_0 device row: K/2 nibble bytes (16-byte vectors, one per 32-weight block), then the K/32 f16 block scales,
+        // zero-padded to whole groups of 64 (a wave-wide scale load past a ragged row end must read finite zeros)
+        t.row_bytes = t.type == LLMK_TYPE_Q4_0 ? q4_row_stride(d.K) : row_bytes_for(t.type, d.K);
+        CK(hipMalloc(&t.data, rows * t.row_bytes + TENSOR_SLACK));
+        if (rc == LLMK_OK) {
+            if (t.type == LLMK_TYPE_Q4_0) CK(hipMemset(t.data, 0, rows * t.row_bytes + TENSOR_SLACK));
+            else CK(hipMemset((char*)t.data + rows * t.row_bytes, 0, TENSOR_SLACK));
         }
     }
     const size_t kvn = (size_t)L * S * c->KVl;
@@ -773,6 +776,7 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
         if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
         if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
+        if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4>(c, 5);
     }
     if (rc == LLMK_OK) {   // raise the dynamic-LDS limits the token pass needs, or reject the shape here (see g_prepare)
         g_prepare = true;
@@ -829,9 +833,8 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
             const size_t nb = cr * blocks_per_row;
             hipError_t e = hipMemcpy2D(tmp, col_bytes, src + r * spitch + col_off, spitch, col_bytes, cr, hipMemcpyHostToDevice);
             if (e == hipSuccess) {
-                uint4* nib = (uint4*)((char*)t.data + (first_row + r) * t.row_bytes);
-                __half* sc = (__half*)((char*)t.scales + (first_row + r) * t.scale_row_bytes);
-                hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, tmp, nib, sc, nb);
+                hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, tmp, (char*)t.data + (first_row + r) * t.row_bytes,
+                                   nb, (int)blocks_per_row, t.row_bytes);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
             }
@@ -1041,7 +1044,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
         if (kernel == 6) {
             double w = 0;
             const int mats[5] = {LLMK_WQKV, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS};
-            for (int m : mats) w += (double)c->desc[m].rows * (c->desc[m].layered ? c->L : 1) * (double)c->t[m].row_bytes;
+            for (int m : mats) w += (double)c->desc[m].rows * (c->desc[m].layered ? c->L : 1) * (double)row_bytes_for(c->t[m].type, c->desc[m].K);
             b = w + (2.0 * c->L + 1) * c->E * 4 + c->E * 4 + 2.0 * c->L * c->KV * 4.0 * c->h_tokpos[1] +
                 2.0 * c->L * c->KV * 4 + c->V * 4.0;
         } else if (kernel == 1) {
@@ -1165,7 +1168,6 @@ int llmk_destroy(llmk_ctx* c) {
     if (c->graph_greedy) hipGraphExecDestroy(c->graph_greedy);
     for (int i = 0; i < LLMK_N_TENSORS; ++i) {
         if (c->t[i].data) hipFree(c->t[i].data);
-        if (c->t[i].scales) hipFree(c->t[i].scales);
     }
     void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,
                    c->d_gran, c->d_zeros, c->d_trace, c->d_part, c->pf_X, c->pf_Xs, c->pf_Q, c->pf_XB, c->pf_HB, c->pf_P,

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     }
 }
 
-// ---- q4_0 weights (device layout of llmk_upload: nibble plane [rows][K/2] + f16 scale plane [rows][K/32]) -------------
+// ---- q4_0 weights (device layout of llmk_upload: rows of K/2 nibble bytes + K/32 f16 scales, RS bytes apart) -----------
 // A lane load is ONE block: 16 bytes of nibbles = 32 columns of its row, plus the block's scale; the 4 lane groups of a
 // wave cover 4 blocks = 128 columns, which is the pipeline step.  Byte j of a block holds element j (low nibble) and
 // element 16+j (high nibble); the A operand of MFMA step (dword i, byte c) is (n-8)*d computed exactly as the decode
@@ -145,8 +145,8 @@ constexpr int PF_KSTEP_Q4 = 128;
 constexpr int PF_LDW_Q4 = PF_KSTEP_Q4 + 4;
 
 struct PfGemmQ4Args {
-    const uint4* Wn;     // [rows][K/32] blocks of 16 nibble bytes
-    const __half* Sc;    // [rows][K/32]
+    const char* W;       // [rows] x RS bytes: K/32 blocks of 16 nibble bytes, then K/32 f16 scales
+    int RS;              // row stride in bytes
     const float* X;      // [T][K]
     float* P;            // [KS][Tp][rows]
     int rows, K, T;
@@ -165,7 +165,11 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_q4_kernel(PfGemmQ4Arg
     const int li = lane & 15, lg = lane >> 4;                         // row of the strip, block of the step
     const bool active = row0 < a.rows;
     const int nblk = a.K >> 5;
-    const size_t wrow = (size_t)min(row0 + li, a.rows - 1) * nblk + (kb >> 5) + lg;
+    const char* rowp = a.W + (size_t)min(row0 + li, a.rows - 1) * a.RS;
+    const uint4* Wn = reinterpret_cast<const uint4*>(rowp);
+    const __half* Sc = reinterpret_cast<const __half*>(rowp + (a.K >> 1));
+    const size_t wrow = (size_t)(kb >> 5) + lg;
+    (void)nblk;
     constexpr int XV = TP * (PF_KSTEP_Q4 / 4) / (PF_WAVES * WAVE);
     const float* xg[XV];
     int xo[XV];
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_q4_kernel(PfGemmQ4Arg
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
 
-    uint4 wc = ldg_nt(a.Wn + wrow), wn;
-    __half dc = a.Sc[wrow], dn;
+    uint4 wc = ldg_nt(Wn + wrow), wn;
+    __half dc = Sc[wrow], dn;
     float4 xr[XV];
 #pragma unroll
     for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_q4_kernel(PfGemmQ4Arg
 
     for (int s = 0; s < nsteps; ++s) {
         const int sn = min(s + 1, nsteps - 1);                          // clamped: the loads stay unconditional
-        wn = ldg_nt(a.Wn + wrow + sn * (PF_KSTEP_Q4 / 32));
-        dn = a.Sc[wrow + sn * (PF_KSTEP_Q4 / 32)];
+        wn = ldg_nt(Wn + wrow + sn * (PF_KSTEP_Q4 / 32));
+        dn = Sc[wrow + sn * (PF_KSTEP_Q4 / 32)];
 #pragma unroll
         for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + sn * PF_KSTEP_Q4);
         const float* xb = xs + (s & 1) * TP * PF_LDW_Q4;

@@ -5,7 +5,7 @@
 // (5 launches per layer) -- the weight stream stops at every dependency.  Weights
 // do not depend on activations, so here the stream never stops: each of the 7 STREAMING waves of a CU
 // walks a static list of 8 KB row tiles (its share of qkv, wo, w1|w3, w2 of every layer, then the
-// classifier) and always has TK_NB tiles requested ahead in registers (non-temporal 16-byte loads),
+// classifier) and always has NB (TkShape::NB) tiles requested ahead in registers (non-temporal 16-byte loads),
 // across phase and layer boundaries.  The one SERVICE wave per CU never touches the weight stream
 // (so its polls are not queued behind 40 KB of outstanding loads -- vmcnt retires in order): it
 // gathers the phase's input vector from the exchange buffers into LDS, applies rmsnorm, and after
@@ -34,7 +34,8 @@ namespace llmk {
 
 constexpr int TK_NCU = 256;               // one workgroup per CU
 constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
-constexpr int TK_NB = 5;                  // register tiles a streaming wave keeps requested ahead (5 x 8 KB)
+// register tiles a streaming wave keeps requested ahead: TkShape::NB (5 x 8 KB for f32 / f16; 3 for q4_0, whose x fragment
+// takes 64 registers instead of 32 and whose tiles carry 8 scale registers)
 constexpr int TK_NS = TK_WAVES - 1;
 constexpr int TK_THREADS = TK_WAVES * WAVE;
 constexpr int TK_TCOLS = 8;               // 16-byte vector columns per tile (8 x 64 lanes x 4 floats = 2048)
@@ -86,11 +87,22 @@ struct TkShape {
     static constexpr int HS = E / NH, KV = NKV * HS, KVMUL = NH / NKV, QKV = E + 2 * KV;
     // ---- weight tiles.  A tile is TK_TCOLS (8) lane loads of 16 bytes = 8 "segments" of 1 KB.  f32: one row x 8
     // segments (2048 columns).  f16: a row of 2048 columns is 4 segments, so a tile is RPT = 2 consecutive rows x LPT = 4
-    // segments -- the x fragment a lane needs (LPT segments x 16/BW columns) is 32 floats either way.
-    static constexpr int BW = (WT == WT_F16) ? 2 : 4;                    // bytes per weight
-    static constexpr int VPL = 16 / BW;                                  // weights per 16-byte lane load
-    static constexpr int LPR_E = E * BW / 1024, LPR_H = H * BW / 1024;   // 1 KB segments per row, K = E / K = H
-    static constexpr int RPT = (WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1;   // rows per tile
+    // segments -- the x fragment a lane needs (LPT segments x VPL columns) is 32 floats either way.
+    // q4_0 (nibble plane, 16 bytes = one 32-weight block): a row of 4096 columns is 2 segments, a tile is RPT = 4 rows x
+    // LPT = 2 segments; lane l owns blocks l and l + 64 of every row (64 floats of x, fixed for the whole phase) and
+    // fetches each block's f16 scale (stored right behind the row's nibbles) with its own 2-byte load (8 more loads per
+    // tile, 1/8 of the bytes).  Rows need not be whole segments: see tk_issue.
+    static constexpr bool Q4 = WT == WT_Q4_0;
+    static constexpr int VPL = Q4 ? 32 : (WT == WT_F16 ? 8 : 4);         // weights per 16-byte lane load
+    static constexpr int SEGW = WAVE * VPL;                              // weights per 1 KB segment
+    // bytes between rows, K = E / K = H (q4_0 device row: K/2 nibble bytes, then the row's K/32 f16 scales, 16-byte aligned)
+    // (the scale area is zero-padded to whole groups of 64 scales: llmk.hip q4_row_stride)
+    static constexpr int RB_E = Q4 ? E / 2 + (E / 32 + 63) / 64 * 128 : E / VPL * 16, RB_H = Q4 ? H / 2 + (H / 32 + 63) / 64 * 128 : H / VPL * 16;
+    static constexpr int LPR_E = (E + SEGW - 1) / SEGW, LPR_H = (H + SEGW - 1) / SEGW;   // 1 KB segments per row (q4_0: last may be ragged)
+    static constexpr int NBLK_E = E / 32, NBLK_H = H / 32;               // q4_0 blocks per row
+    static constexpr int NBP_E = NBLK_E + 1, NBP_H = NBLK_H + 1;         // q4_0: pitch (in float4) of the transposed x image in LDS
+    static constexpr int NB = Q4 ? 3 : 5;                                // ring depth (q4_0: 4 would spill, 237 VGPRs at 3)
+    static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
     static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
     // rows per CU and tiles per CU for each phase
     // The NH attention CUs own NO rows of the QKV and wo matrices (the two phases either side of attention): their q poll,
@@ -104,20 +116,26 @@ struct TkShape {
     static constexpr int R_C = RPT * (CB + (CX > 0 ? 1 : 0));
     static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU;
     static constexpr int TPR_H = (LPR_H + LPT - 1) / LPT;                // column parts of a w2 row
-    static constexpr int NT_Q = R_Q / RPT, NT_O = R_O / RPT, NT_A = R_A / RPT, NT_D = (R_D / RPT) * TPR_H, NT_C = R_C / RPT;
+    // a CU's row count need not be a multiple of RPT: the last tile then also covers rows of the NEXT CU (recomputed,
+    // their partial sums land in slots nobody reads).  The weight allocations carry RPT rows of slack at their end.
+    static constexpr int NG_A = (R_A / 2 + RPT - 1) / RPT;               // gate (= up) tiles per CU
+    static constexpr int NT_Q = (R_Q + RPT - 1) / RPT, NT_O = R_O / RPT, NT_A = 2 * NG_A, NT_D = (R_D / RPT) * TPR_H, NT_C = R_C / RPT;
     static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
                          SL_A = (NT_A + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
     // w2 rows are TPR_H parts wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
     // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
     static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D / RPT + NW_D - 1) / NW_D;
     static constexpr int SL_LAYER = SL_Q + SL_O + SL_A + SL_D;
-    static constexpr int MAXP0 = R_A > R_C ? R_A : R_C, MAXP1 = R_D * TPR_H, MAXP = MAXP0 > MAXP1 ? MAXP0 : MAXP1;   // partial sums per phase
+    static constexpr int RA_P = 2 * RPT * NG_A, RQ_P = RPT * NT_Q;       // partial slots incl. the recomputed neighbour rows
+    static constexpr int MAXP00 = RA_P > R_C ? RA_P : R_C, MAXP0 = MAXP00 > RQ_P ? MAXP00 : RQ_P, MAXP1 = R_D * TPR_H,
+                         MAXP = MAXP0 > MAXP1 ? MAXP0 : MAXP1;           // partial sums per phase
     static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % RPT == 0, "rows must split over CUs");
-    static_assert(E * BW % 1024 == 0 && H * BW % 1024 == 0, "rows are whole 1 KB segments");
-    static_assert(LPR_E <= LPT && R_Q % RPT == 0 && (R_A / 2) % RPT == 0 && R_D % RPT == 0, "a K = E row is one tile row; row ranges are whole tiles");
+    static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
+    static_assert(LPR_E <= LPT && (Q4 || (R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
+                  "a K = E row is one tile row; row ranges are whole tiles (q4_0: QKV / w1|w3 may end in a shared tile)");
     static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
     static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
-    static_assert(HS == 64, "in-kernel attention is written for head_size 64");
+    static_assert(HS == 64 || HS == 128, "in-kernel attention is written for head sizes 64 and 128");
     static_assert(TPR_H <= TK_NS, "every column part of a w2 row needs a wave");
 };
 
@@ -125,7 +143,10 @@ struct TkShape {
 template <class SH>
 struct TkLds {
     static constexpr int XS = 0;
-    static constexpr int XRAW = XS + SH::H * 4;
+    // q4_0: the streaming input is staged TRANSPOSED, xs4[m * NBP + b] = x[32 b + 4 m .. + 3], so the eight float4 a lane
+    // needs for block b are lane-contiguous (conflict-free ds_read_b128); pitch NBP = blocks + 1
+    static constexpr int XS_BYTES = SH::Q4 ? 8 * (SH::NBP_H > SH::NBP_E ? SH::NBP_H : SH::NBP_E) * 16 : SH::H * 4;
+    static constexpr int XRAW = XS + XS_BYTES;
     static constexpr int PART = XRAW + SH::E * 4;
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
     static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
@@ -164,9 +185,17 @@ __device__ __forceinline__ float4 tk_ldkv(__amdgpu_buffer_rsrc_t rs, int voff) {
 // list's handoff-payload row), so: 16-byte sc1 loads (two granules each), ALL of a lane's NL loads in
 // flight at once, so a pass costs one round trip.
 // Returns false on timeout / sticky error.
-template <int NL>
+// NBP > 0: the values are written in the transposed q4_0 image (see TkLds), element e -> float4 (e>>2): block (e>>5),
+// group (e>>2)&7
+template <int NBP>
+__device__ __forceinline__ int tk_xoff(int e) {
+    if constexpr (NBP > 0) return ((((e >> 2) & 7) * NBP + (e >> 5)) << 2) + (e & 3);
+    else return e;
+}
+template <int NL, int NBP>
 __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* dst,
                                                unsigned* err, int lane, bool nowait, unsigned long long* dbg) {
+    const int dst0 = tk_xoff<NBP>(2 * (first_pair + lane));
     for (unsigned spin = 0;; ++spin) {
         const unsigned long long tp0 = (TK_DEBUG && dbg) ? wall_clock64() : 0;
         tk_v4u r[NL];
@@ -179,8 +208,10 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
-            const int i = 2 * (first_pair + lane + k * WAVE);
-            *reinterpret_cast<float2*>(dst + i) = make_float2(__uint_as_float(r[k].x), __uint_as_float(r[k].z));
+            // element 2 * (first_pair + lane + 64 k): lane part + a compile-time stride per k (natural order: 128 floats;
+            // transposed image: 64 pairs = 32 float4 = 4 blocks further along the same group row = 16 floats), so the
+            // address is ONE per-lane register plus an immediate
+            *reinterpret_cast<float2*>(dst + dst0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(__uint_as_float(r[k].x), __uint_as_float(r[k].z));
         }
         if (__all(ok) || nowait) {
             if (TK_DEBUG && dbg && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
@@ -196,19 +227,26 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
         __builtin_amdgcn_s_sleep(1);
     }
 }
-template <int N>
+template <int N, int NBP = 0>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
                                           int lane, bool nowait = false, unsigned long long* dbg = nullptr) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     if constexpr (NL <= 24) {
-        return tk_gather_part<NL>(rs, 0, epoch, dst, err, lane, nowait, dbg);
-    } else {      // long vectors in two register-sized halves
+        return tk_gather_part<NL, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
+    } else if constexpr (NL <= 48) {      // long vectors in register-sized pieces
         constexpr int H0 = NL / 2, H1 = NL - H0;
-        const bool a = tk_gather_part<H0>(rs, 0, epoch, dst, err, lane, nowait, dbg);
-        const bool b = tk_gather_part<H1>(rs, H0 * WAVE, epoch, dst, err, lane, nowait, dbg ? dbg + 2 : nullptr);
+        const bool a = tk_gather_part<H0, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
+        const bool b = tk_gather_part<H1, NBP>(rs, H0 * WAVE, epoch, dst, err, lane, nowait, dbg ? dbg + 2 : nullptr);
         return a && b;
+    } else {
+        constexpr int Q0 = NL / 4, Q3 = NL - 3 * Q0;
+        const bool a = tk_gather_part<Q0, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
+        const bool b = tk_gather_part<Q0, NBP>(rs, Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
+        const bool c = tk_gather_part<Q0, NBP>(rs, 2 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
+        const bool d = tk_gather_part<Q3, NBP>(rs, 3 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
+        return a && b && c && d;
     }
 }
 
@@ -226,8 +264,10 @@ struct TkNorm {
     // Stages xs = x*w and returns xn = sqrt(mean(x^2)+1e-5).  The division by xn is linear in the dot
     // product, so it is applied ONCE to each finished row sum (W.(x*w))/xn by the epilogue instead
     // of 2048 times here -- the service wave is the serial section of every phase.
+    template <int NBP = 0>   // NBP > 0: xs is the transposed q4_0 image
     __device__ __forceinline__ float apply(const float* xraw, float* xs, int lane) const {
         float ss = 0.f;
+        const int xs0 = tk_xoff<NBP>(4 * lane);     // float4 lane + 64 k: 8 blocks further per k in the transposed image
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const float4 x = reinterpret_cast<const float4*>(xraw)[lane + k * WAVE];
@@ -237,7 +277,7 @@ struct TkNorm {
             o.y = x.y * w[k].y;
             o.z = x.z * w[k].z;
             o.w = x.w * w[k].w;
-            reinterpret_cast<float4*>(xs)[lane + k * WAVE] = o;
+            *reinterpret_cast<float4*>(xs + xs0 + k * (NBP > 0 ? 32 : 4 * WAVE)) = o;
         }
         ss = wave_sum(ss);
         return sqrtf(ss / (float)E + 1e-5f);
@@ -246,7 +286,7 @@ struct TkNorm {
 
 // Every ring slot is exactly TK_TCOLS unconditional loads: a slot with no tile, and the columns past a
 // ragged row end, read a 1 KB block of ZEROS (L2-resident) instead of being skipped.  With no control
-// flow around the loads hipcc can count them, so consuming the oldest of the TK_NB tiles waits with
+// flow around the loads hipcc can count them, so consuming the oldest of the NB tiles waits with
 // vmcnt(24) and leaves the three younger tiles in flight; a skipped load would force vmcnt(0).
 struct TkTile {
     const float4* p;  // first segment of the tile's first row (the zero block when the slot is empty)
@@ -254,10 +294,19 @@ struct TkTile {
     int ncol;         // real segments per tile row (0..LPT); segments >= ncol read zeros
     int pidx;         // partial index of the tile's first row (MAXP = junk slot); row s of the tile: pidx + s * pstep
     int pstep;
+    int soff;         // q4_0 only: bytes from p to the f16 scale of the tile's first block (same row)
+};
+
+typedef _Float16 tk_h2 __attribute__((ext_vector_type(2)));
+// one ring entry: the 8 weight vectors of a tile (+ for q4_0 the 8 block scales that go with them)
+template <class SH>
+struct TkSlot {
+    float4 b[TK_TCOLS];
+    unsigned short sc[SH::Q4 ? TK_TCOLS : 1];
 };
 
 template <class SH>
-__device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t, const float4* zp, int lane) {
+__device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
@@ -265,7 +314,21 @@ __device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t,
         const float4* pj = real ? t.p + s * t.rstride + jj * WAVE : zp;
         // an empty segment is ONE 16-byte access for the whole wave (every lane reads the same zero vector), not a 1 KB
         // sweep of the zero block: it still counts in vmcnt, but costs the CU's memory pipeline one line instead of eight
-        b[j] = ldg_nt(pj + (real ? lane : 0));
+        e.b[j] = ldg_nt(pj + (real ? lane : 0));
+    }
+    if constexpr (SH::Q4) {
+        // the blocks' f16 scales.  A ragged last segment (K = H) needs no per-lane predicate: lanes past the row end read
+        // the row's zero padding as scales (the scale area is padded to whole groups of 64) and whatever follows the
+        // row's nibbles as nibbles (its own scales: finite integers after conversion), and their x fragment is zero
+        // (TkX::load_q4), so they contribute 0 * (0 - 0) = 0.
+#pragma unroll
+        for (int j = 0; j < TK_TCOLS; ++j) {
+            const int s = j / SH::LPT, jj = j % SH::LPT;
+            const bool real = jj < t.ncol;
+            const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(t.p + s * t.rstride) + t.soff) + jj * WAVE
+                                            : reinterpret_cast<const unsigned short*>(zp);
+            e.sc[j] = __builtin_nontemporal_load(pj + (real ? lane : 0));
+        }
     }
 }
 // Every tile of a phase is dotted against the same x fragment (the LPT segments of a row, or of one column part of a
@@ -273,8 +336,9 @@ __device__ __forceinline__ void tk_issue(float4 (&b)[TK_TCOLS], const TkTile& t,
 // slot was ~0.2 us of LDS time in the middle of every slot of the critical path.  32 floats per lane for f32 and f16.
 template <class SH>
 struct TkX {
-    static constexpr int F4 = SH::VPL / 4;          // float4 of x per segment and lane: 1 (f32) or 2 (f16)
+    static constexpr int F4 = SH::VPL / 4;          // float4 of x per segment and lane: 1 (f32), 2 (f16), 8 (q4_0: one block)
     float4 v[SH::LPT * F4];
+    float xs8[SH::Q4 ? SH::LPT : 1];                // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
     // segments seg0 .. seg0+LPT-1 of a vector with nseg segments; segments past the end read as zero
     __device__ __forceinline__ void load(const float4* xs, int seg0, int nseg, int lane) {
 #pragma unroll
@@ -287,6 +351,24 @@ struct TkX {
             }
         }
     }
+    // q4_0: blocks (seg0 + j) * 64 + lane of a vector of nblk blocks staged transposed at pitch NBP (TkLds); blocks past
+    // the end read as zero
+    template <int NBP>
+    __device__ __forceinline__ void load_q4(const float4* xs, int seg0, int nblk, int lane) {
+#pragma unroll
+        for (int j = 0; j < SH::LPT; ++j) {
+            const int b = (seg0 + j) * WAVE + lane;
+            const bool in = b < nblk;
+            float t = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 x = xs[m * NBP + (in ? b : 0)];
+                v[j * 8 + m] = in ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+                t += (v[j * 8 + m].x + v[j * 8 + m].y) + (v[j * 8 + m].z + v[j * 8 + m].w);
+            }
+            xs8[j] = 8.0f * t;
+        }
+    }
 };
 __device__ __forceinline__ float4 tk_h2f_lo(const float4& w) {   // halves 0..3 of a 16-byte vector of 8
     const __half2 a = *reinterpret_cast<const __half2*>(&w.x), b = *reinterpret_cast<const __half2*>(&w.y);
@@ -297,8 +379,62 @@ __device__ __forceinline__ float4 tk_h2f_hi(const float4& w) {   // halves 4..7
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
 }
 // per-lane partial dots of one tile (one per tile row): four independent FMA chains (x,y,z,w) instead of one long chain
+// One dword of a q4_0 block (bytes 4i..4i+3: low nibbles = elements 4i.., high nibbles = elements 16+4i..) against its 8
+// activations, as ONE asm statement: lo += sum n_lo x, hi16 += sum (16 n_hi) x.  Same arithmetic as q4_dword_dot
+// (kernels.h); written out so that exactly four temporaries are live -- left to itself the scheduler hoists the 64
+// conversions of a tile ahead of their FMAs and the kernel spills (the ring and the x fragment already hold 190 VGPRs).
+// The low and high chains alternate, so dependent FMAs are four issue slots apart.
+__device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
+    unsigned l, h;
+    float t0, t1;
+    asm("v_and_b32 %[l], 0x0f0f0f0f, %[q]\n\t"
+        "v_and_b32 %[h], 0xf0f0f0f0, %[q]\n\t"
+        "v_cvt_f32_ubyte0 %[t0], %[l]\n\t"
+        "v_cvt_f32_ubyte0 %[t1], %[h]\n\t"
+        "v_fmac_f32 %[lo], %[t0], %[a0]\n\t"
+        "v_fmac_f32 %[hi], %[t1], %[b0]\n\t"
+        "v_cvt_f32_ubyte1 %[t0], %[l]\n\t"
+        "v_cvt_f32_ubyte1 %[t1], %[h]\n\t"
+        "v_fmac_f32 %[lo], %[t0], %[a1]\n\t"
+        "v_fmac_f32 %[hi], %[t1], %[b1]\n\t"
+        "v_cvt_f32_ubyte2 %[t0], %[l]\n\t"
+        "v_cvt_f32_ubyte2 %[t1], %[h]\n\t"
+        "v_fmac_f32 %[lo], %[t0], %[a2]\n\t"
+        "v_fmac_f32 %[hi], %[t1], %[b2]\n\t"
+        "v_cvt_f32_ubyte3 %[t0], %[l]\n\t"
+        "v_cvt_f32_ubyte3 %[t1], %[h]\n\t"
+        "v_fmac_f32 %[lo], %[t0], %[a3]\n\t"
+        "v_fmac_f32 %[hi], %[t1], %[b3]"
+        : [lo] "+v"(lo), [hi] "+v"(hi16), [l] "=&v"(l), [h] "=&v"(h), [t0] "=&v"(t0), [t1] "=&v"(t1)
+        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
+          [b2] "v"(xh.z), [b3] "v"(xh.w));
+}
+
 template <class SH>
-__device__ __forceinline__ void tk_dot(const float4 (&b)[TK_TCOLS], const TkX<SH>& x, float (&out)[SH::RPT]) {
+__device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, float (&out)[SH::RPT]) {
+    const float4 (&b)[TK_TCOLS] = e.b;
+    if constexpr (SH::Q4) {
+        // sum_i (n_i - 8) d x_i = d (sum_i n_i x_i - 8 sum_i x_i): low nibbles are elements 0..15 of the block, high nibbles
+        // elements 16..31 (ggml block_q4_0); same arithmetic as gemv_q4_kernel (kernels.h)
+#pragma unroll
+        for (int s = 0; s < SH::RPT; ++s) {
+            float acc = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < SH::LPT; ++jj) {
+                const float4& w = b[s * SH::LPT + jj];
+                const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+                float tl = 0.f, th = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
+                const float t = fmaf(th, 0.0625f, tl);
+                const unsigned short hs = e.sc[s * SH::LPT + jj];
+                const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
+                acc = fmaf(d, t - x.xs8[jj], acc);
+            }
+            out[s] = acc;
+        }
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < SH::RPT; ++s) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -323,7 +459,7 @@ __device__ __forceinline__ void tk_dot(const float4 (&b)[TK_TCOLS], const TkX<SH
     }
 }
 template <class SH>
-__device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const TkTile& t, const TkX<SH>& x, float* part, int lane) {
+__device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t, const TkX<SH>& x, float* part, int lane) {
     float v[SH::RPT];
     tk_dot<SH>(b, x, v);
 #pragma unroll
@@ -340,7 +476,7 @@ __device__ __forceinline__ void tk_consume(const float4 (&b)[TK_TCOLS], const Tk
 // (null when past the end).  Everything but l, c, sw is a compile-time constant.
 template <class SH>
 struct TkSched {
-    static constexpr int SLP = (SH::SL_LAYER + TK_NB - 1) / TK_NB * TK_NB;   // padded slots per layer
+    static constexpr int SLP = (SH::SL_LAYER + SH::NB - 1) / SH::NB * SH::NB;   // padded slots per layer
     static constexpr int KQ = 0, KO = KQ + SH::SL_Q, KA = KO + SH::SL_O, KD = KA + SH::SL_A, KP = KD + SH::SL_D;
 };
 
@@ -348,12 +484,13 @@ template <class SH>
 __device__ __forceinline__ TkTile tk_null(const float4* zp) {
     TkTile t;
     t.p = zp; t.rstride = 0; t.ncol = 0; t.pidx = SH::MAXP; t.pstep = 0;
+    t.soff = 0;
     return t;
 }
 // row r of a [rows][K] matrix of SH's weight type
 template <class SH, int K>
 __device__ __forceinline__ const float4* tk_rowp(const void* mat, long long r) {
-    return reinterpret_cast<const float4*>(static_cast<const char*>(mat) + (size_t)r * K * SH::BW);
+    return reinterpret_cast<const float4*>(static_cast<const char*>(mat) + (size_t)r * (K == SH::E ? SH::RB_E : SH::RB_H));
 }
 
 // tile ti of a CU's run-time row range [row0, row0+n) of a K = E matrix: RPT consecutive (= contiguous) rows
@@ -363,9 +500,10 @@ __device__ __forceinline__ TkTile tk_row_tile(const void* mat, long long row0, i
     const bool live = ti * SH::RPT < n;
     t.ncol = live ? SH::LPR_E : 0;
     t.p = live ? tk_rowp<SH, SH::E>(mat, row0 + ti * SH::RPT) : zp;
-    t.rstride = SH::LPR_E * WAVE;
+    t.rstride = SH::RB_E / 16;
     t.pidx = live ? ti * SH::RPT : SH::MAXP;
     t.pstep = live ? 1 : 0;
+    t.soff = SH::E / 2;
     return t;
 }
 
@@ -395,12 +533,14 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
             // partials are laid out (gate, up) per hidden unit
             const int ti = (K - SC::KA) * TK_NS + sw, m = ti >> 1, gu = ti & 1;
             const bool live = ti < SH::NT_A;
+            const long long row = (long long)l * 2 * SH::H + gu * SH::H + c * (SH::R_A / 2) + m * SH::RPT;
             TkTile t;
             t.ncol = live ? SH::LPR_E : 0;
-            t.p = live ? tk_rowp<SH, SH::E>(a.w13, (long long)l * 2 * SH::H + gu * SH::H + c * (SH::R_A / 2) + m * SH::RPT) : a.zeros;
-            t.rstride = SH::LPR_E * WAVE;
+            t.p = live ? tk_rowp<SH, SH::E>(a.w13, row) : a.zeros;
+            t.rstride = SH::RB_E / 16;
             t.pidx = live ? 2 * m * SH::RPT + gu : SH::MAXP;
             t.pstep = live ? 2 : 0;
+            t.soff = SH::E / 2;
             return t;
         } else if constexpr (K < SC::KP) {
             // w2: RPT rows x column part `part` (LPT segments; the last part is ragged)
@@ -408,12 +548,14 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
             const int part = sw % P, nw = (TK_NS - part + P - 1) / P;      // waves that share this column part
             const int rg = (K - SC::KD) * nw + sw / P;                     // group of RPT rows
             const bool live = rg < SH::R_D / SH::RPT;
+            const long long row = (long long)l * SH::E + c * SH::R_D + rg * SH::RPT;
             TkTile t;
             t.ncol = live ? min(SH::LPT, SH::LPR_H - part * SH::LPT) : 0;
-            t.p = live ? tk_rowp<SH, SH::H>(a.w2, (long long)l * SH::E + c * SH::R_D + rg * SH::RPT) + part * SH::LPT * WAVE : a.zeros;
-            t.rstride = SH::LPR_H * WAVE;
+            t.p = live ? tk_rowp<SH, SH::H>(a.w2, row) + part * SH::LPT * WAVE : a.zeros;
+            t.rstride = SH::RB_H / 16;
             t.pidx = live ? rg * SH::RPT * P + part : SH::MAXP;
             t.pstep = live ? P : 0;
+            t.soff = SH::H / 2 - part * SH::LPT * WAVE * 14;   // p is part * LPT segments (1 KB each) into the row; its scales 128 B each
             return t;
         } else {
             return tk_null<SH>(a.zeros);
@@ -456,12 +598,20 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0x118, 0xf, true>(0.f, v);
     return v;
 }
+// sum over the LPT = HS/4 lanes that share a timestep: one DPP row (head size 64) or two (head size 128: row_bcast:15
+// adds the even row's total into the odd row); valid in the LAST lane of the group
+template <int LPT>
+__device__ __forceinline__ float tstep_sum(float v) {
+    v = row16_sum(v);
+    if constexpr (LPT == 32) v += dpp_mov<0x142, 0xa, true>(0.f, v);
+    return v;
+}
 
 template <class SH>
 __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int l, int h, int pos, int tid, TkAtt<SH>& pa,
                                              unsigned long long* dbg = nullptr) {
     constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = TkAtt<SH>::U, TILE = TPB * U;
-    static_assert(LPT == 16, "one timestep per DPP row");
+    static_assert(LPT == 16 || LPT == 32, "a timestep is one or two DPP rows");
     float4 (&kv)[U] = pa.kv;
     float4 (&vv)[U] = pa.vv;
     const int lane = tid & 63, wid = tid >> 6;
@@ -483,7 +633,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     const int tmax = max(npast - 1, 0);
 
     float* ex = att + a.S;                                                      // exp(score - max), written per wave
-    float* pw = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_P) + wid * 32;    // this wave's 32 weights of a batch
+    float* pw = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_P) + wid * 32;    // this wave's U*TPW (<= 32) weights of a batch
     for (int base = 0; base < pos; base += TILE) {
         if (base > 0) {
 #pragma unroll
@@ -494,13 +644,13 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
             if (base + u * TPB < pos) {   // block-uniform: short contexts skip the empty batches
                 const int t = base + u * TPB + tb;
                 // rows >= pos-1 read a clamped (wrong) row: t = pos-1 is redone from LDS below, later ones are never used
-                const float d = row16_sum(dot4(qv, kv[u], 0.f));
+                const float d = tstep_sum<LPT>(dot4(qv, kv[u], 0.f));
                 if (sub == LPT - 1 && t < npast) att[t] = d / scale;               // :582
             }
         }
     }
     {   // this token's own key never went through the cache
-        const float d = row16_sum(dot4(qv, kcur[sub], 0.f));
+        const float d = tstep_sum<LPT>(dot4(qv, kcur[sub], 0.f));
         if (wid == 0 && lane == LPT - 1) att[npast] = d / scale;
     }
     if (TK_DEBUG && dbg) dbg[0] = wall_clock64();
@@ -527,8 +677,8 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
 #pragma unroll
             for (int u = 0; u < U; ++u) vv[u] = tk_ldkv(rv, min(base + u * TPB + tb, tmax) * rowb + col);
         }
-        // xi/sum(xi) (:476) once per timestep: lane i < 32 owns timestep (u = i / TPW, tl = i % TPW) of this wave
-        if (lane < 32) {
+        // xi/sum(xi) (:476) once per timestep: lane i < U*TPW owns timestep (u = i / TPW, tl = i % TPW) of this wave
+        if (lane < U * TPW) {
             const int t = base + (lane / TPW) * TPB + wid * TPW + (lane % TPW);
             pw[lane] = (t < pos) ? ex[t] / s : 0.f;
         }
@@ -559,6 +709,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
     float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
     const float* part = reinterpret_cast<const float*>(lds + LD::PART);
+    // q4_0: the streaming input is staged transposed (TkLds); 0 = natural order
+    constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
     const int L = a.L;
     const int tok = a.tokpos ? a.tokpos[0] : a.tok_imm, pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
@@ -595,7 +747,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
             }
             TK_STAMP(1);
-            xn_att = nrm.apply(xraw, xs, lane);
+            xn_att = nrm.template apply<TR_E>(xraw, xs, lane);
         }
         tk_barrier();
         TK_STAMP(2);
@@ -628,13 +780,17 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             TkAtt<SH> pa;
             pa.prefetch(a, l, my_head, pos, tid);   // K/V rows cross the memory system while q is awaited
             for (unsigned spin = 0;; ++spin) {
-                const unsigned long long xq = __hip_atomic_load(a.g_qkv + my_head * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long xk = __hip_atomic_load(a.g_qkv + SH::E + g * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long xv = __hip_atomic_load(a.g_qkv + SH::E + SH::KV + g * SH::HS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool good = (unsigned)(xq >> 32) == e_q && (unsigned)(xk >> 32) == e_q && (unsigned)(xv >> 32) == e_q;
-                qs[lane] = __uint_as_float((unsigned)xq);
-                qs[SH::HS + lane] = __uint_as_float((unsigned)xk);
-                qs[2 * SH::HS + lane] = __uint_as_float((unsigned)xv);
+                bool good = true;
+#pragma unroll
+                for (int d0 = 0; d0 < SH::HS; d0 += WAVE) {   // HS granules each of q_h, k, v: one (head size 64) or two per lane
+                    const unsigned long long xq = __hip_atomic_load(a.g_qkv + my_head * SH::HS + d0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long xk = __hip_atomic_load(a.g_qkv + SH::E + g * SH::HS + d0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long xv = __hip_atomic_load(a.g_qkv + SH::E + SH::KV + g * SH::HS + d0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    good = good && (unsigned)(xq >> 32) == e_q && (unsigned)(xk >> 32) == e_q && (unsigned)(xv >> 32) == e_q;
+                    qs[d0 + lane] = __uint_as_float((unsigned)xq);
+                    qs[SH::HS + d0 + lane] = __uint_as_float((unsigned)xk);
+                    qs[2 * SH::HS + d0 + lane] = __uint_as_float((unsigned)xv);
+                }
                 if (__all(good) || nosync) break;
                 if ((spin & 63) == 63) {
                     if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
@@ -652,19 +808,22 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             TK_STAMP(6);
             // fold the waves*TPW partial output vectors: lane = output dim, one conflict-free ds_read_b32 per partial
             const float* redf = reinterpret_cast<const float*>(lds + LD::ATT_RED);
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
-            for (int w = 0; w < TK_WAVES * (256 / SH::HS); w += 4) {
-                o0 += redf[(w + 0) * SH::HS + lane];
-                o1 += redf[(w + 1) * SH::HS + lane];
-                o2 += redf[(w + 2) * SH::HS + lane];
-                o3 += redf[(w + 3) * SH::HS + lane];
+            for (int d0 = 0; d0 < SH::HS; d0 += WAVE) {
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+                for (int w = 0; w < TK_WAVES * (256 / SH::HS); w += 4) {
+                    o0 += redf[(w + 0) * SH::HS + d0 + lane];
+                    o1 += redf[(w + 1) * SH::HS + d0 + lane];
+                    o2 += redf[(w + 2) * SH::HS + d0 + lane];
+                    o3 += redf[(w + 3) * SH::HS + d0 + lane];
+                }
+                const float o = (o0 + o1) + (o2 + o3);
+                tk_publish(a.g_xb + my_head * SH::HS + d0 + lane, e_att, o);
             }
-            const float o = (o0 + o1) + (o2 + o3);
-            tk_publish(a.g_xb + my_head * SH::HS + lane, e_att, o);
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        if (!att_cu) ok = tk_gather<SH::E>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        if (!att_cu) ok = tk_gather<SH::E, TR_E>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         TK_STAMP(7);
         tk_barrier();
         tk_barrier();
@@ -678,7 +837,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
         ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
         TK_STAMP(9);
-        const float xn_ffn = nrm.apply(xraw, xs, lane);
+        const float xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane);
         tk_barrier();
         TK_STAMP(10);
         tk_barrier();
@@ -691,7 +850,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        ok = tk_gather<SH::H>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        ok = tk_gather<SH::H, TR_H>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -711,7 +870,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     TkNorm<SH::E> nrmf;
     nrmf.prefetch(a.rms_final, lane);
     ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
-    const float xn_fin = nrmf.apply(xraw, xs, lane);
+    const float xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane);
     tk_barrier();
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
@@ -723,22 +882,23 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 }
 
 // ------------------------------------------------------------------------------------------------
-// STREAMING wave: a static list of 8 KB row tiles, always TK_NB requested ahead (register ring),
+// STREAMING wave: a static list of 8 KB row tiles, always NB requested ahead (register ring),
 // consumed between the phase's two barriers.  Nothing here depends on another CU.
 // ------------------------------------------------------------------------------------------------
+template <class SH>
 struct TkRing {
-    float4 b[TK_NB][TK_TCOLS];
-    TkTile t[TK_NB];
+    TkSlot<SH> b[SH::NB];
+    TkTile t[SH::NB];
 };
 
 // slots K .. K+N-1 (compile-time) of layer l: consume ring entry K % NB, refill it with slot K + NB
 template <class SH, int K, int N, bool CLS>
-__device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
+__device__ __forceinline__ void tk_run(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
     if constexpr (N > 0) {
-        constexpr int R = K % TK_NB;
+        constexpr int R = K % SH::NB;
         tk_consume<SH>(r.b[R], r.t[R], x, part, lane);
-        if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
-        else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
+        if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + SH::NB>(a, c, sw);
+        else r.t[R] = tk_at<SH, K + SH::NB>(a, l, c, sw);
         tk_issue<SH>(r.b[R], r.t[R], a.zeros, lane);
         tk_run<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, x, part, lane);
     }
@@ -750,11 +910,11 @@ __device__ __forceinline__ void tk_run(TkRing& r, const TokenArgs& a, int l, int
 // N tiles at once: all per-lane dots first, then the N wave reductions (independent DPP chains the
 // scheduler can interleave), then ONE lane-0 block of LDS writes
 template <class SH, int K, int N>
-__device__ __forceinline__ void tk_eat(const TkRing& r, const TkX<SH>& x, float* part, int lane) {
+__device__ __forceinline__ void tk_eat(const TkRing<SH>& r, const TkX<SH>& x, float* part, int lane) {
     if constexpr (N > 0) {
         float v[N][SH::RPT];
 #pragma unroll
-        for (int i = 0; i < N; ++i) tk_dot<SH>(r.b[(K + i) % TK_NB], x, v[i]);
+        for (int i = 0; i < N; ++i) tk_dot<SH>(r.b[(K + i) % SH::NB], x, v[i]);
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -763,16 +923,16 @@ __device__ __forceinline__ void tk_eat(const TkRing& r, const TkX<SH>& x, float*
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
-                for (int s = 0; s < SH::RPT; ++s) part[r.t[(K + i) % TK_NB].pidx + s * r.t[(K + i) % TK_NB].pstep] = v[i][s];
+                for (int s = 0; s < SH::RPT; ++s) part[r.t[(K + i) % SH::NB].pidx + s * r.t[(K + i) % SH::NB].pstep] = v[i][s];
         }
     }
 }
 template <class SH, int K, int N, bool CLS>
-__device__ __forceinline__ void tk_refill(TkRing& r, const TokenArgs& a, int l, int c, int sw, int lane) {
+__device__ __forceinline__ void tk_refill(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, int lane) {
     if constexpr (N > 0) {
-        constexpr int R = K % TK_NB;
-        if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + TK_NB>(a, c, sw);
-        else r.t[R] = tk_at<SH, K + TK_NB>(a, l, c, sw);
+        constexpr int R = K % SH::NB;
+        if constexpr (CLS) r.t[R] = tk_cls_at<SH, K + SH::NB>(a, c, sw);
+        else r.t[R] = tk_at<SH, K + SH::NB>(a, l, c, sw);
         tk_issue<SH>(r.b[R], r.t[R], a.zeros, lane);
         tk_refill<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, lane);
     }
@@ -780,13 +940,18 @@ __device__ __forceinline__ void tk_refill(TkRing& r, const TokenArgs& a, int l, 
 // one phase of S slots starting at slot K0: [barrier A] early slots (consume+refill), late slots
 // (consume), [barrier B], late refills
 template <class SH, int K0, int S, bool CLS, bool WIDE = false>
-__device__ __forceinline__ void tk_phase(TkRing& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
+__device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
                                          float* part, int lane) {
-    constexpr int LATE = S < TK_NB ? S : TK_NB, EARLY = S - LATE;
+    constexpr int LATE = S < SH::NB ? S : SH::NB, EARLY = S - LATE;
     tk_barrier();
     TkX<SH> x;
-    if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
-    else x.load(xs4, 0, SH::LPR_E, lane);
+    if constexpr (SH::Q4) {
+        if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
+        else x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
+    } else {
+        if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
+        else x.load(xs4, 0, SH::LPR_E, lane);
+    }
     tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
     tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
     tk_barrier();
@@ -794,8 +959,8 @@ __device__ __forceinline__ void tk_phase(TkRing& r, const TokenArgs& a, int l, i
 }
 
 template <class SH, int K>
-__device__ __forceinline__ void tk_prime(TkRing& r, const TokenArgs& a, int c, int sw, int lane) {
-    if constexpr (K < TK_NB) {
+__device__ __forceinline__ void tk_prime(TkRing<SH>& r, const TokenArgs& a, int c, int sw, int lane) {
+    if constexpr (K < SH::NB) {
         r.t[K] = tk_at<SH, K>(a, 0, c, sw);
         tk_issue<SH>(r.b[K], r.t[K], a.zeros, lane);
         tk_prime<SH, K + 1>(r, a, c, sw, lane);
@@ -816,16 +981,17 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
 
-    TkRing r;
+    TkRing<SH> r;
     tk_prime<SH, 0>(r, a, c, sw, lane);
 
     for (int l = 0; l < L; ++l) {
         {   // QKV phase; on the attention CUs the refills wait until attention has issued ITS loads,
             // which would otherwise queue behind 100+ KB of prefetch in this CU's memory pipeline
-            constexpr int LATE = SH::SL_Q < TK_NB ? SH::SL_Q : TK_NB, EARLY = SH::SL_Q - LATE;
+            constexpr int LATE = SH::SL_Q < SH::NB ? SH::SL_Q : SH::NB, EARLY = SH::SL_Q - LATE;
             tk_barrier();
             TkX<SH> x;
-            x.load(xs4, 0, SH::LPR_E, lane);
+            if constexpr (SH::Q4) x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
+            else x.load(xs4, 0, SH::LPR_E, lane);
             tk_run<SH, SC::KQ, EARLY, false>(r, a, l, c, sw, x, part, lane);
             tk_eat<SH, SC::KQ + EARLY, LATE>(r, x, part, lane);
             tk_barrier();
@@ -842,7 +1008,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
         tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
         tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
     }
-    // classifier: the ring index is 0 again (SLP is a multiple of TK_NB); refills run off the stream's end
+    // classifier: the ring index is 0 again (SLP is a multiple of NB); refills run off the stream's end
     tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
@@ -874,5 +1040,6 @@ typedef TkShape<2048, 5632, 32, 4, 32000> TkTinyLlama;   // /root/reference/llam
 typedef TkShape<256, 768, 4, 2, 1024> TkSmall;           // tests/golden/tk-small*.npz: pinned to the real reference
 typedef TkShape<2048, 5632, 32, 4, 32000, WT_F16> TkTinyLlamaF16;   // BASELINE.json configs[2]: the same model, f16 matrices
 typedef TkShape<512, 1536, 8, 2, 1024, WT_F16> TkSmallF16;          // parity shape for the f16 tiles (tests: tk-small16)
+typedef TkShape<4096, 11008, 32, 32, 32000, WT_Q4_0> TkLlama7BQ4;   // BASELINE.json configs[3]: Llama-2-7B, q4_0 matrices, head size 128
 
 }  // namespace llmk

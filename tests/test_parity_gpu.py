@@ -301,6 +301,9 @@ def test_llama2_7b_column_geometry_q4_0_matches_oracle(gguf):
     safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
     for flags in (0, llmk.FLAG_MULTI_KERNEL):
         m = llmk.Llmk(fw, flags=flags)
+        if flags == 0:
+            assert m.time_kernel(6, 1)[0] > 0      # the persistent kernel's q4_0 / head-size-128 instantiation is what runs
+            m.reset()
         _, l = m.generate(n, prompt=ot.tolist())
         m.close()
         err = rel_err(l, ol)
@@ -317,6 +320,8 @@ def test_llama2_7b_full_shape_q4_0_properties():
     from llm_f90_amd.tools import gguf
     s = gguf.SHAPES["llama2-7b"]
     m = bench.build_streamed(s, 2, None, 0, 0, 0, 1, None)
+    assert m.time_kernel(6, 1)[0] > 0              # default path = the persistent whole-token kernel
+    m.reset()
     n = 24
     t1, l1 = m.generate(n)
     t2, l2 = m.generate(n)
