@@ -227,26 +227,28 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
         __builtin_amdgcn_s_sleep(1);
     }
 }
-template <int N, int NBP = 0>
+template <int N, int NBP = 0, int MAXNL = 24>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
                                           int lane, bool nowait = false, unsigned long long* dbg = nullptr) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
-    if constexpr (NL <= 24) {
+    // all of a piece's loads are in flight at once (a pass is latency-bound: ~1.4 us per 16 loads per lane under load), so
+    // pieces are as large as the service wave's registers allow at the call site: MAXNL loads = 4 MAXNL VGPRs (32 where no
+    // rmsnorm gains are held across the gather)
+    if constexpr (NL <= MAXNL) {
         return tk_gather_part<NL, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
-    } else if constexpr (NL <= 48) {      // long vectors in register-sized pieces
+    } else if constexpr (NL <= 2 * MAXNL) {      // long vectors in register-sized pieces
         constexpr int H0 = NL / 2, H1 = NL - H0;
         const bool a = tk_gather_part<H0, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
         const bool b = tk_gather_part<H1, NBP>(rs, H0 * WAVE, epoch, dst, err, lane, nowait, dbg ? dbg + 2 : nullptr);
         return a && b;
     } else {
-        constexpr int Q0 = NL / 4, Q3 = NL - 3 * Q0;
+        constexpr int Q0 = NL / 3, Q2 = NL - 2 * Q0;
         const bool a = tk_gather_part<Q0, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
         const bool b = tk_gather_part<Q0, NBP>(rs, Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
-        const bool c = tk_gather_part<Q0, NBP>(rs, 2 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
-        const bool d = tk_gather_part<Q3, NBP>(rs, 3 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
-        return a && b && c && d;
+        const bool c = tk_gather_part<Q2, NBP>(rs, 2 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
+        return a && b && c;
     }
 }
 
@@ -384,6 +386,9 @@ __device__ __forceinline__ float4 tk_h2f_hi(const float4& w) {   // halves 4..7
 // (kernels.h); written out so that exactly four temporaries are live -- left to itself the scheduler hoists the 64
 // conversions of a tile ahead of their FMAs and the kernel spills (the ring and the x fragment already hold 190 VGPRs).
 // The low and high chains alternate, so dependent FMAs are four issue slots apart.
+// Measured (probes/q4_alu_probe.hip, 2 waves per SIMD): 50 cycles per dword per SIMD -- v_cvt_f32_ubyteN issues at half
+// rate (3.6 cycles), and so does v_cvt_pk_f32_fp8 (a byte 0x0n read as OCP e4m3 is exactly n * 2^-9: two nibbles per
+// instruction, but 4.4 cycles each plus a use stall: 57 cycles per dword, slower in the kernel too).
 __device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
     unsigned l, h;
     float t0, t1;
@@ -823,7 +828,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        if (!att_cu) ok = tk_gather<SH::E, TR_E>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        if (!att_cu) ok = tk_gather<SH::E, TR_E, 32>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         TK_STAMP(7);
         tk_barrier();
         tk_barrier();
@@ -850,7 +855,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        ok = tk_gather<SH::H, TR_H>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        ok = tk_gather<SH::H, TR_H, 32>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
