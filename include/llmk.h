@@ -103,6 +103,18 @@ int llmk_create_tp(const llmk_config *cfg, int tp_rank, int tp_size, llmk_ctx **
 int llmk_tp_unique_id(char id_out[128]);
 int llmk_tp_init_comm(llmk_ctx *ctx, const char id[128]);
 
+/* The same three collectives as ONE-SHOT exchanges over peer memory (xGMI is a full mesh: every rank writes its partial
+ * E-vector straight into every peer's inbox and adds the P partials in rank order -- one hop instead of a ring's
+ * 2(P-1); csrc/tp_p2p.h).  Each rank exports its inbox with llmk_tp_p2p_handle (64 bytes, a hipIpcMemHandle_t), the host
+ * ships the P handles to every rank (any side channel: files, MPI, torch.distributed) and each rank calls
+ * llmk_tp_p2p_connect with all of them, `handles` = tp_size * 64 bytes in rank order (its own entry is ignored).  Ranks
+ * that live in ONE process (one host thread per GPU) connect with llmk_tp_p2p_connect_local instead: `ranks[r]` = rank r's
+ * ctx.  After either call llmk_forward / llmk_forward_greedy run the token pass with these collectives (the RCCL
+ * communicator, if any, is then unused).  All ranks must call llmk_forward for the same token and position. */
+int llmk_tp_p2p_handle(llmk_ctx *ctx, char handle_out[64]);
+int llmk_tp_p2p_connect(llmk_ctx *ctx, const char *handles);
+int llmk_tp_p2p_connect_local(llmk_ctx *ctx, llmk_ctx *const *ranks);
+
 /* Single-process stepping of a tensor-parallel ctx, for verification on one GPU (no communicator): the
  * caller plays the collective.  llmk_tp_begin sets token/pos; llmk_tp_segment runs
  *   seg 0 (layer l):  [l>0: x += exchanged]  rmsnorm+qkv, attention, wo   -> partial E-vector
@@ -128,6 +140,14 @@ int llmk_upload(llmk_ctx *ctx, int tensor_id, const void *host, size_t nbytes, i
  * without materialising the fused array on the host). */
 int llmk_upload_rows(llmk_ctx *ctx, int tensor_id, int layer, int row_offset, int rows, const void *host,
                      size_t nbytes, int ggml_type);
+
+/* Extensions beyond the reference's behaviour, both OPT-IN (the defaults reproduce llama2.f90):
+ *  - llmk_set_tensor_type: give LLMK_WCLS its own ggml type (f32 / f16 / q4_0) before it is uploaded -- stock llama.cpp
+ *    q4_0 files keep output.weight in q6_K, which the host loader dequantises (read_ggml.f90:682-684 stops on it);
+ *  - llmk_set_rms_eps: rmsnorm epsilon other than the reference's hard-coded 1e-5 (llama2.f90:454), for a host that
+ *    honours llama.attention.layer_norm_rms_epsilon. */
+int llmk_set_tensor_type(llmk_ctx *ctx, int tensor_id, int ggml_type);
+int llmk_set_rms_eps(llmk_ctx *ctx, float eps);
 
 /* RoPE frequency table, n = head_size/2 floats: freqs[j] = 1/10000**((2j+1)/head_size), computed
  * by the HOST with the reference's own expression (llama2.f90:544-545) so the device angle

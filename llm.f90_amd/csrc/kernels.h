@@ -41,6 +41,7 @@ struct GemvArgs {
     int E, KV, hs;
     // SWIGLU
     int H;
+    float eps;            // rmsnorm epsilon (1e-5 unless the host opted into the file's, llmk_set_rms_eps)
     // q4_0 only (device layout of llmk_upload): a row is its K/2 nibble bytes followed by its K/32 f16 block scales,
     // rows are row_stride bytes apart (16-byte aligned)
     int row_stride;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
             if (lane == 0) red[wid] = ss;
             __syncthreads();
             ss = red[0] + red[1] + red[2] + red[3];
-            const float xn = sqrtf(ss / (float)K + 1e-5f);
+            const float xn = sqrtf(ss / (float)K + a.eps);
             const float4* wg = reinterpret_cast<const float4*>(a.norm_w);
             for (int i = tid; i < nx4; i += GEMV_THREADS) {
                 const int li = (WT == WT_Q4_0) ? ((i & 7) * nvec + (i >> 3)) : i;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
             ss = red[0] + red[1] + red[2] + red[3];
             // rmsnorm (llama2.f90:450-457): x*w is staged, the division by sqrt(mean(x^2)+eps) is linear in the dot
             // product and is applied ONCE to each finished row sum instead of K times per block
-            xn = sqrtf(ss / (float)K + 1e-5f);
+            xn = sqrtf(ss / (float)K + a.eps);
             const float4* wg = reinterpret_cast<const float4*>(a.norm_w);
             for (int i = tid; i < nx4; i += GEMV_THREADS) {
                 const int li = (i & 7) * xp + (i >> 3);

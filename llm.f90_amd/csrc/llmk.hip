@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "token_kernel.h"
 #include "prefill.h"
+#include "tp_p2p.h"
 
 #include <rccl/rccl.h>
 
@@ -63,6 +64,11 @@ struct llmk_ctx {
     int tp_rank = 0, tp_size = 1;
     int Eq, KVl, Hl, Vl, nhl;
     ncclComm_t comm = nullptr;
+    // one-shot peer-memory collectives (tp_p2p.h): this rank's inbox (fine-grained HBM) and the peers' as mapped here
+    unsigned long long* d_inbox = nullptr;
+    TpPeers peers = {};
+    void* ipc_mapped[TP_MAX_RANKS] = {};
+    bool p2p = false;
     float* d_part = nullptr;       // [E] partial sums of the row-parallel GEMVs (wo, w2) before the all-reduce
     TensorDesc gdesc[LLMK_N_TENSORS];  // the full (unsharded) tensors, what llmk_upload is handed
     TensorDesc desc[LLMK_N_TENSORS];
@@ -80,6 +86,7 @@ struct llmk_ctx {
     hipEvent_t ev[8] = {};
     float times[5] = {0, 0, 0, 0, 0};
     int n_cu = 256;
+    float eps = 1e-5f;     // rmsnorm epsilon: the reference's constant (llama2.f90:454) unless llmk_set_rms_eps
     // persistent whole-token kernel (token_kernel.h)
     bool use_tk = false;
     bool tk_short_grid = false;   // libllmk_debug.so only (LLMK_TK_INJECT_TIMEOUT)
@@ -204,6 +211,7 @@ GemvArgs base_args(llmk_ctx* c, int tid, int l, const float* x, const float* nor
     const size_t lrows = d.layered ? (size_t)l * d.rows : 0;
     a.W = (const char*)t.data + lrows * t.row_bytes;
     a.row_stride = (int)t.row_bytes;
+    a.eps = c->eps;
     a.x = x;
     a.norm_w = norm_w;
     a.y = y;
@@ -227,7 +235,7 @@ hipError_t launch_qkv(llmk_ctx* c, int l) {
 // Row-parallel GEMVs (wo, w2): with tp_size > 1 each rank contracts over ITS slice of the input and
 // writes a PARTIAL x-increment to d_part; the all-reduce + `x += part` follow (tp_reduce_add).
 hipError_t launch_wo(llmk_ctx* c, int l) {
-    if (c->tp_size > 1 || c->comm) {
+    if (c->tp_size > 1 || c->comm || c->p2p) {
         GemvArgs a = base_args(c, LLMK_WO, l, c->d_xb, nullptr, c->d_part);
         return launch_gemv_t<EPI_STORE, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
     }
@@ -239,7 +247,7 @@ hipError_t launch_w13(llmk_ctx* c, int l) {
     return launch_gemv_t<EPI_SWIGLU, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
 }
 hipError_t launch_w2(llmk_ctx* c, int l) {
-    if (c->tp_size > 1 || c->comm) {
+    if (c->tp_size > 1 || c->comm || c->p2p) {
         GemvArgs a = base_args(c, LLMK_W2, l, c->d_hb, nullptr, c->d_part);
         return launch_gemv_t<EPI_STORE, false>(c->cfg.weight_type, c->stream, a, c->n_cu);
     }
@@ -250,7 +258,7 @@ hipError_t launch_cls(llmk_ctx* c) {
     // vocab-parallel: this rank's V/P rows land in its slice of the full logits vector
     GemvArgs a = base_args(c, LLMK_WCLS, 0, c->d_x, (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data,
                            c->d_logits + (size_t)c->tp_rank * c->Vl);
-    return launch_gemv_t<EPI_STORE, true>(c->cfg.weight_type, c->stream, a, c->n_cu);
+    return launch_gemv_t<EPI_STORE, true>(c->t[LLMK_WCLS].type, c->stream, a, c->n_cu);   // the classifier may have its own type
 }
 hipError_t launch_embed(llmk_ctx* c) {
     hipLaunchKernelGGL(embed_kernel, dim3((c->E + 255) / 256), dim3(256), 0, c->stream,
@@ -297,6 +305,7 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     a.trace = c->d_trace;
     a.L = c->L;
     a.S = c->S;
+    a.eps = c->eps;
     a.nosync = (TK_DEBUG && getenv("LLMK_TK_NOSYNC")) ? 1 : 0;   // libllmk_debug.so only
     hipLaunchKernelGGL((token_kernel<TK>), dim3((TK_DEBUG && c->tk_short_grid) ? TK_NCU - 1 : TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
     return hipGetLastError();
@@ -388,8 +397,31 @@ int enqueue_token_tp(llmk_ctx* c) {
 }
 
 // Enqueue one token pass on c->stream.  timed: bracket the reference's five sections with events.
+hipError_t launch_tp_allreduce_add(llmk_ctx* c, int call) {   // x += sum over ranks of d_part   (:603-605, :618-620)
+    hipLaunchKernelGGL(tp_allreduce_add_kernel, dim3((c->E + 255) / 256), dim3(256), 0, c->stream, c->peers, c->d_part, c->d_x,
+                       c->d_tokpos, call, 2 * c->L, c->tp_rank, c->tp_size, c->E, reinterpret_cast<unsigned*>(c->d_logits + c->V));
+    return hipGetLastError();
+}
+
 hipError_t enqueue_token(llmk_ctx* c, bool greedy, bool timed) {
     HIPRET(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    if (c->p2p) {   // tensor-parallel over peer memory: the whole token is stream work (replayable from a hipGraph)
+        HIPRET(launch_embed(c));
+        for (int l = 0; l < c->L; ++l) {
+            HIPRET(launch_qkv(c, l));
+            HIPRET(launch_attn(c, l));
+            HIPRET(launch_wo(c, l));
+            HIPRET(launch_tp_allreduce_add(c, 2 * l));
+            HIPRET(launch_w13(c, l));
+            HIPRET(launch_w2(c, l));
+            HIPRET(launch_tp_allreduce_add(c, 2 * l + 1));
+        }
+        HIPRET(launch_cls(c));
+        hipLaunchKernelGGL(tp_allgather_kernel, dim3((c->V + 255) / 256), dim3(256), 0, c->stream, c->peers, c->d_logits, c->d_tokpos,
+                           2 * c->L, c->tp_rank, c->tp_size, c->E, c->V, reinterpret_cast<unsigned*>(c->d_logits + c->V));
+        HIPRET(hipGetLastError());
+        return enqueue_tail(c, greedy);
+    }
     if (c->use_tk) {
         HIPRET(launch_token_kernel(c));
         return enqueue_tail(c, greedy);
@@ -476,7 +508,7 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
         c->h_tokpos[2] += 1;  // token serial: makes every exchange epoch of this pass unique
         // debug library only: launch the token kernel one workgroup short at this position, so its peers really time out
         c->tk_short_grid = TK_DEBUG && c->use_tk && getenv("LLMK_TK_INJECT_TIMEOUT") && atoi(getenv("LLMK_TK_INJECT_TIMEOUT")) == pos;
-        if (c->tp_size > 1 || c->comm) {   // tensor-parallel: eager launches with the collectives in between
+        if ((c->tp_size > 1 || c->comm) && !c->p2p) {   // tensor-parallel over RCCL: eager launches with the collectives in between
             rc = enqueue_token_tp(c);
             if (rc) return rc;
             HIPCHK(enqueue_tail(c, greedy));
@@ -494,6 +526,10 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
             HIPCHK(hipGraphLaunch(*g, c->stream));
         }
         HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->p2p) {   // a peer never delivered its granules: the sticky word says so (cleared by llmk_reset)
+            const unsigned perr = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
+            return perr ? LLMK_E_TIMEOUT : LLMK_OK;
+        }
         if (!c->use_tk) return LLMK_OK;
         const unsigned err = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
         if (err == 0) return LLMK_OK;
@@ -608,7 +644,7 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
         float* vc = c->d_vc + (size_t)l * c->S * KV;
         // rmsnorm + QKV + RoPE + KV write                                                 llama2.f90:527-565
         hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
-                           (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E);
+                           (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E, c->eps);
         HIPRET(hipGetLastError());
         HIPRET(gemm(LLMK_WQKV, QKV, c->pf_Xs, E, &e.KS));
         e.rows = QKV; e.out = c->pf_Q; e.kc = kc; e.vc = vc;
@@ -635,7 +671,7 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
         HIPRET(hipGetLastError());
         // rmsnorm + w1|w3 + SwiGLU                                                        :608-616
         hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
-                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E);
+                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E, c->eps);
         HIPRET(hipGetLastError());
         HIPRET(gemm(LLMK_W13, 2 * H, c->pf_Xs, E, &e.KS));
         e.rows = 2 * H; e.out = c->pf_HB;
@@ -911,6 +947,53 @@ int llmk_upload(llmk_ctx* c, int tid, const void* host, size_t nbytes, int ggml_
     return LLMK_OK;
 }
 
+// The classifier's encoding may differ from the other matrices' (stock llama.cpp q4_0 files keep output.weight in
+// q6_K; the host loader hands it over dequantised): re-type the tensor BEFORE uploading it.  Such a ctx runs the
+// multi-kernel path (the persistent kernel is instantiated for one weight type).
+int llmk_set_tensor_type(llmk_ctx* c, int tid, int ggml_type) {
+    if (!c || tid != LLMK_WCLS) return LLMK_E_ARG;
+    if (ggml_type != LLMK_TYPE_F32 && ggml_type != LLMK_TYPE_F16 && ggml_type != LLMK_TYPE_Q4_0) return LLMK_E_TYPE;
+    DevTensor& t = c->t[tid];
+    if (t.type == ggml_type) return LLMK_OK;
+    const TensorDesc& d = c->desc[tid];
+    const int kalign = ggml_type == LLMK_TYPE_Q4_0 ? 32 : ggml_type == LLMK_TYPE_F16 ? 8 : 4;
+    if (d.K % kalign) return LLMK_E_SHAPE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (t.data) HIPCHK(hipFree(t.data));
+    t.data = nullptr;
+    t.type = ggml_type;
+    t.uploaded = false;
+    t.rows_uploaded = 0;
+    const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1);
+    t.row_bytes = ggml_type == LLMK_TYPE_Q4_0 ? q4_row_stride(d.K) : row_bytes_for(ggml_type, d.K);
+    HIPCHK(hipMalloc(&t.data, rows * t.row_bytes + TENSOR_SLACK));
+    HIPCHK(hipMemset(t.data, 0, rows * t.row_bytes + TENSOR_SLACK));
+    if (c->use_tk) {
+        c->use_tk = false;
+        if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }
+        if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
+    }
+    g_prepare = true;                      // the classifier GEMV may need a larger dynamic-LDS limit in its new type
+    const hipError_t pe = launch_cls(c);
+    g_prepare = false;
+    if (pe == hipErrorInvalidValue) return LLMK_E_SHAPE;
+    HIPCHK(pe);
+    return LLMK_OK;
+}
+
+// rmsnorm epsilon.  The reference hard-codes 1e-5 (llama2.f90:454) and ignores the file's
+// llama.attention.layer_norm_rms_epsilon; a host that opts into the file's value (llm --gguf-eps) sets it here.
+int llmk_set_rms_eps(llmk_ctx* c, float eps) {
+    if (!c || !(eps > 0.f) || !(eps < 1.f)) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->eps = eps;
+    if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }   // kernel arguments are baked in
+    if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
+    return LLMK_OK;
+}
+
 int llmk_set_rope_freqs(llmk_ctx* c, const float* freqs, int n) {
     if (!c || !freqs || n != c->hs / 2) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -1104,6 +1187,70 @@ int llmk_tp_init_comm(llmk_ctx* c, const char id_in[128]) {
     return LLMK_OK;
 }
 
+// ---- one-shot peer-memory collectives (tp_p2p.h) ----------------------------------------------------------------------
+static int tp_inbox_alloc(llmk_ctx* c) {
+    if (c->d_inbox) return LLMK_OK;
+    if (c->tp_size < 2 || c->tp_size > TP_MAX_RANKS) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t bytes = tp_inbox_granules(c->tp_size, c->E, c->V) * sizeof(unsigned long long);
+    // fine-grained: peers' stores over xGMI and this device's system-scope polls meet in memory, not in a stale L2 line
+    HIPCHK(hipExtMallocWithFlags((void**)&c->d_inbox, bytes, hipDeviceMallocFinegrained));
+    HIPCHK(hipMemset(c->d_inbox, 0, bytes));      // tag 0 is never a valid epoch
+    HIPCHK(hipDeviceSynchronize());
+    c->peers.inbox[c->tp_rank] = c->d_inbox;
+    return LLMK_OK;
+}
+
+int llmk_tp_p2p_handle(llmk_ctx* c, char handle_out[64]) {
+    if (!c || !handle_out) return LLMK_E_ARG;
+    int rc = tp_inbox_alloc(c);
+    if (rc) return rc;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    hipIpcMemHandle_t h;
+    HIPCHK(hipIpcGetMemHandle(&h, c->d_inbox));
+    memcpy(handle_out, &h, sizeof(h));
+    return LLMK_OK;
+}
+
+int llmk_tp_p2p_connect(llmk_ctx* c, const char* handles) {
+    if (!c || !handles || c->p2p) return LLMK_E_ARG;
+    int rc = tp_inbox_alloc(c);
+    if (rc) return rc;
+    for (int r = 0; r < c->tp_size; ++r) {
+        if (r == c->tp_rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * 64, sizeof(h));
+        void* p = nullptr;
+        HIPCHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        c->ipc_mapped[r] = p;
+        c->peers.inbox[r] = (unsigned long long*)p;
+    }
+    c->p2p = true;
+    return LLMK_OK;
+}
+
+int llmk_tp_p2p_connect_local(llmk_ctx* c, llmk_ctx* const* ranks) {
+    if (!c || !ranks || c->p2p) return LLMK_E_ARG;
+    int rc = tp_inbox_alloc(c);
+    if (rc) return rc;
+    for (int r = 0; r < c->tp_size; ++r) {
+        if (r == c->tp_rank) continue;
+        llmk_ctx* o = ranks[r];
+        if (!o || o->tp_size != c->tp_size || o->tp_rank != r || o->E != c->E || o->V != c->V) return LLMK_E_ARG;
+        rc = tp_inbox_alloc(o);
+        if (rc) return rc;
+        HIPCHK(hipSetDevice(c->cfg.device));
+        if (o->cfg.device != c->cfg.device) {
+            const hipError_t e = hipDeviceEnablePeerAccess(o->cfg.device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return LLMK_E_HIP + (int)e;
+            (void)hipGetLastError();
+        }
+        c->peers.inbox[r] = o->d_inbox;
+    }
+    c->p2p = true;
+    return LLMK_OK;
+}
+
 int llmk_tp_begin(llmk_ctx* c, int token, int pos) {
     int rc = check_ready(c);
     if (rc) return rc;
@@ -1164,6 +1311,9 @@ int llmk_destroy(llmk_ctx* c) {
     hipSetDevice(c->cfg.device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
+    for (int r = 0; r < TP_MAX_RANKS; ++r)
+        if (c->ipc_mapped[r]) hipIpcCloseMemHandle(c->ipc_mapped[r]);
+    if (c->d_inbox) hipFree(c->d_inbox);
     if (c->graph_logits) hipGraphExecDestroy(c->graph_logits);
     if (c->graph_greedy) hipGraphExecDestroy(c->graph_greedy);
     for (int i = 0; i < LLMK_N_TENSORS; ++i) {

@@ -259,7 +259,7 @@ __global__ void pf_embed_kernel(const float* __restrict__ table, const int* __re
 
 // xs[t] = x[t]*w ; xn[t] = sqrt(dot(x,x)/E + 1e-5): the division is applied to the finished row sums    :450-457
 __global__ __launch_bounds__(256) void pf_norm_kernel(const float* __restrict__ X, const float* __restrict__ w,
-                                                      float* __restrict__ Xs, float* __restrict__ xn, int E) {
+                                                      float* __restrict__ Xs, float* __restrict__ xn, int E, float eps) {
     __shared__ float red[4];
     const int t = blockIdx.x, tid = threadIdx.x;
     const float* x = X + (size_t)t * E;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void pf_norm_kernel(const float* __restrict__ 
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    if (tid == 0) xn[t] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)E + 1e-5f);
+    if (tid == 0) xn[t] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)E + eps);
 }
 
 struct PfEpiArgs {

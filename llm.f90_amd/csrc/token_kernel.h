@@ -75,6 +75,7 @@ struct TokenArgs {
     const float4* zeros;     // [NCU*TK_WAVES] 1 KB blocks of zeros: what empty ring slots / ragged row ends read
     unsigned long long* trace;  // debug build only: [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave
     int L, S;
+    float eps;               // rmsnorm epsilon
     int nosync;              // debug build only: do not wait for exchange tags (wrong results; measures the pure streaming rate)
     // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
     int q0, qn, o0, on;
@@ -267,7 +268,7 @@ struct TkNorm {
     // product, so it is applied ONCE to each finished row sum (W.(x*w))/xn by the epilogue instead
     // of 2048 times here -- the service wave is the serial section of every phase.
     template <int NBP = 0>   // NBP > 0: xs is the transposed q4_0 image
-    __device__ __forceinline__ float apply(const float* xraw, float* xs, int lane) const {
+    __device__ __forceinline__ float apply(const float* xraw, float* xs, int lane, float eps) const {
         float ss = 0.f;
         const int xs0 = tk_xoff<NBP>(4 * lane);     // float4 lane + 64 k: 8 blocks further per k in the transposed image
 #pragma unroll
@@ -282,7 +283,7 @@ struct TkNorm {
             *reinterpret_cast<float4*>(xs + xs0 + k * (NBP > 0 ? 32 : 4 * WAVE)) = o;
         }
         ss = wave_sum(ss);
-        return sqrtf(ss / (float)E + 1e-5f);
+        return sqrtf(ss / (float)E + eps);
     }
 };
 
@@ -752,7 +753,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
             }
             TK_STAMP(1);
-            xn_att = nrm.template apply<TR_E>(xraw, xs, lane);
+            xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
         }
         tk_barrier();
         TK_STAMP(2);
@@ -842,7 +843,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
         ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
         TK_STAMP(9);
-        const float xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane);
+        const float xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
         tk_barrier();
         TK_STAMP(10);
         tk_barrier();
@@ -875,7 +876,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     TkNorm<SH::E> nrmf;
     nrmf.prefetch(a.rms_final, lane);
     ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
-    const float xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane);
+    const float xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane, a.eps);
     tk_barrier();
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;

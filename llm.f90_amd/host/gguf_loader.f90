@@ -21,7 +21,8 @@ module read_ggml
 
   integer(4), parameter :: GGUF_MAGIC = 1179993927     ! "GGUF", read_ggml.f90:122
   integer, parameter :: NAME_LEN = 64                  ! reference truncates names/tokens to 64 chars
-  integer, parameter :: GT_F32 = 0, GT_F16 = 1, GT_Q4_0 = 2
+  integer, parameter :: GT_F32 = 0, GT_F16 = 1, GT_Q4_0 = 2, GT_Q6_K = 14
+  real(8) :: last_real = 0        ! value of the last float-typed scalar read_scalar saw (it returns integers)
 
   type :: tensor_entry
      character(len=NAME_LEN) :: name = ""
@@ -115,6 +116,9 @@ contains
           case ("llama.attention.head_count_kv");    n_kv_heads = int(ival, 4); have_kv_heads = .true.
           case ("llama.context_length");             ctx_len = int(ival, 4)
           case ("llama.feed_forward_length");        ffn = int(ival, 4)
+          ! kept for hosts that opt in (llm --gguf-eps / --gguf-rope-base); the reference ignores both (llama2.f90:454,545)
+          case ("llama.attention.layer_norm_rms_epsilon"); c%rms_eps = real(last_real, wp)
+          case ("llama.rope.freq_base");                   c%rope_freq_base = real(last_real, wp)
           end select
        end select
     end do
@@ -172,6 +176,7 @@ contains
        stop 1
     end if
     w%wtype = mt
+    w%wcls_type = mt
 
     allocate(w%token_embedding_table(E, vocab_size))
     call read_matrix_as_f32("token_embd.weight", w%token_embedding_table, E, vocab_size)
@@ -211,7 +216,16 @@ contains
           call read_raw(layer_name(l, "ffn_up.weight"), w%w13_raw, mt, E, H, int(l-1, 8) * 2*H + H)
           call read_raw(layer_name(l, "ffn_down.weight"), w%w2_raw, mt, H, E, int(l-1, 8) * E)
        end do
-       call read_raw("output.weight", w%wcls_raw, mt, E, vocab_size, 0_8)
+       ! stock llama.cpp q4_0 files keep output.weight in q6_K (the reference stops on any type >= 2,
+       ! read_ggml.f90:633-635): it is dequantised here exactly as ggml does and handed over as f32
+       if (dir(find("output.weight"))%ttype == mt) then
+          call read_raw("output.weight", w%wcls_raw, mt, E, vocab_size, 0_8)
+       else
+          deallocate(w%wcls_raw)
+          allocate(w%wcls(E, vocab_size))
+          call read_matrix_as_f32("output.weight", w%wcls, E, vocab_size)
+          w%wcls_type = GT_F32
+       end if
     end if
     if (v) print *, "loaded matmul weights, ggml type", mt
 
@@ -288,11 +302,11 @@ contains
     case (4, 5)                    ! uint32, int32
        read(u) i4; val = int(i4, 8)
     case (6)
-       read(u) r4; val = int(r4, 8)
+       read(u) r4; val = int(r4, 8); last_real = real(r4, 8)
     case (10, 11)
        read(u) i8; val = i8
     case (12)
-       read(u) r8; val = int(r8, 8)
+       read(u) r8; val = int(r8, 8); last_real = r8
     case default
        print *, "Not implemented", vtype          ! the reference's message, read_ggml.f90:683
        stop
@@ -414,7 +428,7 @@ contains
     character(len=*), intent(in) :: name
     integer, intent(in) :: cols, rows
     real(kind=wp), intent(out) :: dst(cols, rows)
-    integer :: idx, r, b, k
+    integer :: idx, r, b, k, sc
     integer(2), allocatable :: hrow(:)
     integer(1), allocatable :: qrow(:)
     real(kind=wp) :: d
@@ -447,10 +461,43 @@ contains
              end do
           end do
        end do
+    case (GT_Q6_K)
+       ! ggml block_q6_K, 256 weights in 210 bytes: ql[128] low 4 bits, qh[64] high 2 bits, 16 int8 sub-block scales,
+       ! f16 d; weight = d * scale * (q - 32)  (public ggml format, dequantize_row_q6_K; third-party knowledge, not
+       ! citable in /root/reference)
+       allocate(qrow(cols / 256 * 210))
+       read(u, pos=data_pos + dir(idx)%offset)
+       do r = 1, rows
+          read(u) qrow
+          do b = 0, cols / 256 - 1
+             d = half_bits_to_real(transfer(qrow(b*210 + 209:b*210 + 210), 0_2))
+             do k = 0, 255
+                call q6k_weight(qrow(b*210 + 1:b*210 + 208), k, q, sc)
+                dst(b*256 + k + 1, r) = d * real(sc, wp) * real(q, wp)
+             end do
+          end do
+       end do
     case default
        print *, "Type not supported", dir(idx)%ttype
        stop 1
     end select
+  end subroutine
+
+  ! element k (0..255) of a q6_K block: its 6-bit value minus 32 and its sub-block scale
+  pure subroutine q6k_weight(blk, k, q, sc)
+    integer(1), intent(in) :: blk(208)       ! ql[128] | qh[64] | scales[16]
+    integer, intent(in) :: k
+    integer, intent(out) :: q, sc
+    integer :: half, l, grp, lo, hi
+    half = k / 128                            ! two halves of 128 weights: 64 ql bytes, 32 qh bytes, 8 scales each
+    l = mod(k, 32)
+    grp = mod(k, 128) / 32                    ! 0..3: which of the four 32-weight quarters
+    lo = iand(int(blk(half*64 + mod(grp, 2)*32 + l + 1)), 255)
+    if (grp >= 2) lo = ishft(lo, -4)
+    lo = iand(lo, 15)
+    hi = iand(ishft(iand(int(blk(128 + half*32 + l + 1)), 255), -2*grp), 3)
+    q = ior(lo, ishft(hi, 4)) - 32
+    sc = int(blk(192 + half*8 + l/16 + 2*grp + 1))      ! int8, signed
   end subroutine
 
   ! IEEE binary16 bit pattern -> f32 (exact)

@@ -6,7 +6,13 @@
 ! llama2.f90:102-108).  There is no CPU forward pass in this program.
 !
 !   ./llm -m model.gguf [-p prompt] [-n tokens] [-t temperature] [-s tokenizer.bin] [-v]
-!         [--ak] [-d device] [--device-argmax] [--prefill] [--timings]
+!         [--ak] [-d device] [--device-argmax] [--prefill] [--timings] [--seed N]
+!         [--ngpu N [--tp-rccl]] [--gguf-eps] [--gguf-rope-base]
+!
+! --ngpu N (the 70B configuration, SURVEY.md section 8e): this process becomes rank 0 of N, starts N-1 copies of itself
+! (one process per GPU, devices d..d+N-1), every rank loads the file and keeps its shard, the ranks meet through a
+! scratch directory (64-byte inbox handles for the one-shot peer-memory collectives, or the RCCL unique id with
+! --tp-rccl) and run the same generation loop in lock step; only rank 0 prints.
 module arg_parse
   implicit none
 
@@ -21,6 +27,13 @@ module arg_parse
      logical :: device_argmax     ! extension: greedy pick on the GPU (SURVEY.md 8f rank 1)
      logical :: prefill           ! extension: the prompt goes through the model as ONE batched pass (llmk_prefill)
      logical :: timings           ! extension: fill the five "Timings" lines from hipEvent section timers (slow path)
+     integer :: seed              ! extension: >= 0 seeds the sampler (the reference's is unseeded, llama2.f90:433)
+     integer :: ngpu              ! extension: tensor-parallel ranks, one process per GPU
+     integer :: tp_rank           ! (internal) rank of a worker started by `--ngpu`
+     character(:), allocatable :: tp_dir   ! (internal) rendezvous directory
+     logical :: tp_rccl           ! extension: RCCL ring collectives instead of the one-shot peer-memory ones
+     logical :: gguf_eps, gguf_rope_base   ! extension: honour the file's rms epsilon / RoPE base (the reference hard-codes
+                                           ! 1e-5 and 10000, llama2.f90:454,545)
   end type args
 
 contains
@@ -41,6 +54,13 @@ contains
     a%device_argmax = .false.
     a%prefill = .false.
     a%timings = .false.
+    a%seed = -1
+    a%ngpu = 1
+    a%tp_rank = 0
+    a%tp_dir = ""
+    a%tp_rccl = .false.
+    a%gguf_eps = .false.
+    a%gguf_rope_base = .false.
 
     nargs = command_argument_count()
     i = 1
@@ -60,6 +80,13 @@ contains
        case ("--device-argmax");     a%device_argmax = .true.; i = i + 1
        case ("--prefill");           a%prefill = .true.;       i = i + 1
        case ("--timings");           a%timings = .true.;       i = i + 1
+       case ("--seed");              read (val, *) a%seed;        i = i + 2
+       case ("--ngpu");              read (val, *) a%ngpu;        i = i + 2
+       case ("--tp-rank");           read (val, *) a%tp_rank;     i = i + 2
+       case ("--tp-dir");            a%tp_dir = trim(val);     i = i + 2
+       case ("--tp-rccl");           a%tp_rccl = .true.;       i = i + 1
+       case ("--gguf-eps");          a%gguf_eps = .true.;      i = i + 1
+       case ("--gguf-rope-base");    a%gguf_rope_base = .true.; i = i + 1
        case default
           print *, "Unrecognized option:", trim(opt)
           stop
@@ -97,8 +124,14 @@ program llm
   integer(c_int) :: flags, rc
   real(kind=wp) :: t_start, t_end
   real(c_float) :: ktimes(5)
+  logical :: lead                                   ! this rank prints (rank 0, or the only process)
+  integer, allocatable :: hash_tab(:)               ! open-addressing index over vocab (lookup)
+  integer :: hash_mask
+  real(kind=wp) :: rope_base
 
   call parse_args(opts)
+  lead = opts%tp_rank == 0
+  if (opts%ngpu > 1) call tp_launch_workers()
   if (opts%ak) then
      ! llama2.c flat format: no tokenizer inside, `-s tokenizer.bin` is required (llama2.f90:160-356)
      call load_ak(opts%model_file, weights, conf, opts%verbose)
@@ -107,11 +140,13 @@ program llm
         stop 1
      end if
   else
-     call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose)
+     call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose .and. lead)
   end if
-  if (opts%verbose) print *, "Loaded weights"
+  if (opts%verbose .and. lead) print *, "Loaded weights"
   if (opts%tokenizer /= "") call read_tokenizer_bin(opts%tokenizer)
   max_len = maxval(vocab_len)
+  call build_lookup()
+  if (opts%seed >= 0) call seed_sampler(opts%seed)
 
   ! ---- device context + one-time weight upload (the host arrays are not needed afterwards) -----
   ! The reference's five section timers (llama2.f90:538-638) need an event pair and a sync per section, which rules out
@@ -120,16 +155,26 @@ program llm
   flags = 0
   if (opts%timings) flags = LLMK_FLAG_TIMINGS
   kcfg = llmk_config(conf%emb_dim, conf%hidden_dim, conf%n_layers, conf%n_heads, conf%n_kv_heads, &
-                     conf%vocab_size, conf%seq_len, weights%wtype, opts%device, flags)
-  call llmk_check(llmk_create(kcfg, ctx), "llmk_create")
+                     conf%vocab_size, conf%seq_len, weights%wtype, tp_device(), flags)
+  if (opts%ngpu > 1) then
+     call llmk_check(llmk_create_tp(kcfg, int(opts%tp_rank, c_int), int(opts%ngpu, c_int), ctx), "llmk_create_tp")
+  else
+     call llmk_check(llmk_create(kcfg, ctx), "llmk_create")
+  end if
+  if (weights%wcls_type /= weights%wtype) &
+       call llmk_check(llmk_set_tensor_type(ctx, LLMK_WCLS, int(weights%wcls_type, c_int)), "llmk_set_tensor_type")
   call upload_weights()
+  if (opts%ngpu > 1) call tp_connect()
+  if (opts%gguf_eps .and. conf%rms_eps > 0) call llmk_check(llmk_set_rms_eps(ctx, conf%rms_eps), "llmk_set_rms_eps")
 
   ! RoPE frequencies with the reference's own expression (llama2.f90:544-545): for 1-based odd i,
   ! head_dim = mod(i,head_size) = 1,3,5,...; freq = 1/10000**(head_dim/head_size)
   hs = conf%emb_dim / conf%n_heads
   allocate(freqs(hs / 2))
+  rope_base = 10000.0
+  if (opts%gguf_rope_base .and. conf%rope_freq_base > 0) rope_base = conf%rope_freq_base
   do j = 1, hs / 2
-     freqs(j) = 1.0 / (10000.0 ** (real(2*j - 1, kind=wp) / hs))
+     freqs(j) = 1.0 / (rope_base ** (real(2*j - 1, kind=wp) / hs))
   end do
   call llmk_check(llmk_set_rope_freqs(ctx, freqs, int(hs / 2, c_int)), "llmk_set_rope_freqs")
 
@@ -139,7 +184,7 @@ program llm
   seq_len = conf%seq_len
   if (opts%n <= seq_len) then                        ! llama2.f90:363-368
      seq_len = opts%n
-  else
+  else if (lead) then
      print *, opts%n, "greater than maxinum squence length"
      print *, "set to", seq_len
   end if
@@ -159,16 +204,18 @@ program llm
      batch(2:) = int(prompt_tokens, c_int)
      t_start = time_ms()       ! the clock covers the prompt pass: tokens/second counts those positions too (llama2.f90:405)
      call llmk_check(llmk_prefill(ctx, batch, int(k + 1, c_int), 1_c_int, logits), "llmk_prefill")
-     do pos = 1, k
-        write (*, fmt="(A)", advance="no") vocab(prompt_tokens(pos))(1:vocab_len(prompt_tokens(pos)))
-     end do
+     if (lead) then
+        do pos = 1, k
+           write (*, fmt="(A)", advance="no") vocab(prompt_tokens(pos))(1:vocab_len(prompt_tokens(pos)))
+        end do
+     end if
      if (opts%temperature == 0) then
         token = maxloc(logits, dim=1)
      else
         probs = softmax_t(logits / opts%temperature)
         token = sample(probs)
      end if
-     write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
+     if (lead) write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
      pos0 = k + 2
   end if
   do pos = pos0, seq_len
@@ -187,20 +234,23 @@ program llm
         end if
      end if
      token = next_tok
-     write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
+     if (lead) write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
      if (t_start == 0) t_start = time_ms()           ! clock starts after the first token
   end do
   t_end = time_ms()
 
   call llmk_check(llmk_timings(ctx, ktimes), "llmk_timings")
   s%times = ktimes
-  print *, ""
-  print *, "Inference time: ", (t_end - t_start) / 1000, " seconds"
-  print *, 1000 * (seq_len - 1) / (t_end - t_start), "tokens/second"
-  print *, "Timings"
-  do l = 1, 5
-     print *, l, s%times(l) / seq_len
-  end do
+  if (lead) then
+     print *, ""
+     print *, "Inference time: ", (t_end - t_start) / 1000, " seconds"
+     print *, 1000 * (seq_len - 1) / (t_end - t_start), "tokens/second"
+     print *, "Timings"
+     do l = 1, 5
+        print *, l, s%times(l) / seq_len
+     end do
+  end if
+  if (opts%ngpu > 1) call tp_finish()
   rc = llmk_destroy(ctx)
 
 contains
@@ -237,9 +287,16 @@ contains
             int(weights%wtype, c_int)), "upload w13")
        call llmk_check(llmk_upload(ctx, LLMK_W2, c_loc(weights%w2_raw), size(weights%w2_raw, kind=c_size_t), &
             int(weights%wtype, c_int)), "upload w2")
-       call llmk_check(llmk_upload(ctx, LLMK_WCLS, c_loc(weights%wcls_raw), size(weights%wcls_raw, kind=c_size_t), &
-            int(weights%wtype, c_int)), "upload wcls")
-       deallocate(weights%wqkv_raw, weights%wo_raw, weights%w13_raw, weights%w2_raw, weights%wcls_raw)
+       if (weights%wcls_type == LLMK_TYPE_F32) then      ! classifier dequantised by the loader (q6_K output.weight)
+          call llmk_check(llmk_upload(ctx, LLMK_WCLS, c_loc(weights%wcls), f4 * size(weights%wcls, kind=c_size_t), &
+               LLMK_TYPE_F32), "upload wcls")
+          deallocate(weights%wcls)
+       else
+          call llmk_check(llmk_upload(ctx, LLMK_WCLS, c_loc(weights%wcls_raw), size(weights%wcls_raw, kind=c_size_t), &
+               int(weights%wcls_type, c_int)), "upload wcls")
+          deallocate(weights%wcls_raw)
+       end if
+       deallocate(weights%wqkv_raw, weights%wo_raw, weights%w13_raw, weights%w2_raw)
     end if
     deallocate(weights%token_embedding_table)
   end subroutine upload_weights
@@ -276,18 +333,77 @@ contains
     close(tu)
   end subroutine read_tokenizer_bin
 
-  ! exact-match vocabulary lookup honouring the true token length (trailing blanks are data)
+  ! ---- vocabulary index: exact-match lookup honouring the true token length (trailing blanks are data).  The reference
+  ! scans all V strings per lookup (llama2.f90:643-655), O(V) per candidate pair of every merge round; this is an
+  ! open-addressing hash (FNV-1a over the bytes) built once.  Same answer: the FIRST index holding the string.
+  function hash_bytes(str, n) result(h)
+    character(len=*), intent(in) :: str
+    integer, intent(in) :: n
+    integer :: h, i
+    integer(8) :: acc
+    acc = 2166136261_8
+    do i = 1, n
+       acc = iand(ieor(acc, int(ichar(str(i:i)), 8)) * 16777619_8, 4294967295_8)
+    end do
+    h = int(iand(acc, int(hash_mask, 8)))
+  end function hash_bytes
+
+  subroutine build_lookup()
+    integer :: i, h, cap
+    cap = 1
+    do while (cap < 2 * size(vocab) + 2)
+       cap = cap * 2
+    end do
+    hash_mask = cap - 1
+    if (allocated(hash_tab)) deallocate(hash_tab)
+    allocate(hash_tab(0:cap - 1))
+    hash_tab = 0
+    do i = 1, size(vocab)
+       h = hash_bytes(vocab(i), int(vocab_len(i)))
+       do
+          if (hash_tab(h) == 0) then
+             hash_tab(h) = i
+             exit
+          end if
+          if (vocab_len(hash_tab(h)) == vocab_len(i)) then
+             if (vocab(hash_tab(h))(1:vocab_len(i)) == vocab(i)(1:vocab_len(i))) exit    ! duplicate: the first index wins
+          end if
+          h = iand(h + 1, hash_mask)
+       end do
+    end do
+  end subroutine build_lookup
+
   function lookup(str, n) result(idx)
     character(len=*), intent(in) :: str
     integer, intent(in) :: n
-    integer :: idx
-    do idx = 1, size(vocab)
+    integer :: idx, h
+    h = hash_bytes(str, n)
+    do
+       idx = hash_tab(h)
+       if (idx == 0) exit
        if (vocab_len(idx) == n) then
           if (vocab(idx)(1:n) == str(1:n)) return
        end if
+       h = iand(h + 1, hash_mask)
     end do
     idx = -1
   end function lookup
+
+  ! a byte with no single-character token: llama's byte-fallback token "<0xXX>", else <unk> (the reference indexes
+  ! vocab_len(-1) here, llama2.f90:666-668 + :683)
+  function byte_token(ch) result(idx)
+    character(len=1), intent(in) :: ch
+    integer :: idx
+    character(len=6) :: name
+    character(len=16), parameter :: hex = "0123456789ABCDEF"
+    integer :: b
+    idx = lookup(ch, 1)
+    if (idx > 0) return
+    b = ichar(ch)
+    name = "<0x" // hex(b / 16 + 1:b / 16 + 1) // hex(mod(b, 16) + 1:mod(b, 16) + 1) // ">"
+    idx = lookup(name, 6)
+    if (idx < 0) idx = 1                                   ! <unk>
+  end function byte_token
 
   ! llama2.c-style BPE (behaviour of llama2.f90:658-724): start from one token per byte, then
   ! repeatedly fuse the adjacent pair whose concatenation is the best-scoring vocabulary entry.
@@ -301,14 +417,13 @@ contains
     n = len(text)
     allocate(tokens(n))
     do i = 1, n
-       tokens(i) = lookup(text(i:i), 1)
+       tokens(i) = byte_token(text(i:i))
     end do
     do
        best_score = -1e10
        best_i = -1
        best_tok = -1
        do i = 1, n - 1
-          if (tokens(i) < 1 .or. tokens(i + 1) < 1) cycle
           la = vocab_len(tokens(i))
           lb = vocab_len(tokens(i + 1))
           pair = vocab(tokens(i))(1:la) // vocab(tokens(i + 1))(1:lb)
@@ -350,5 +465,149 @@ contains
     end do
     idx = size(p)
   end function sample
+
+  ! `--seed N`: a reproducible sampler (and identical draws on every tensor-parallel rank)
+  subroutine seed_sampler(seed)
+    integer, intent(in) :: seed
+    integer :: n, i
+    integer, allocatable :: put(:)
+    call random_seed(size=n)
+    allocate(put(n))
+    do i = 1, n
+       put(i) = ieor(seed * 1664525 + 1013904223, i * 668265263)
+    end do
+    call random_seed(put=put)
+  end subroutine seed_sampler
+
+  ! ---- `--ngpu N`: one process per GPU ------------------------------------------------------------------------------
+  integer(c_int) function tp_device()
+    character(len=8) :: env
+    integer :: st
+    tp_device = int(opts%device + opts%tp_rank, c_int)
+    call get_environment_variable("LLMK_TP_SAME_DEVICE", env, status=st)      ! test aid: all ranks on one GPU
+    if (st == 0) tp_device = int(opts%device, c_int)
+  end function tp_device
+
+  function shell_quote(a) result(q)
+    character(len=*), intent(in) :: a
+    character(len=:), allocatable :: q
+    integer :: i
+    q = "'"
+    do i = 1, len(a)
+       if (a(i:i) == "'") then
+          q = q // "'\''"
+       else
+          q = q // a(i:i)
+       end if
+    end do
+    q = q // "'"
+  end function shell_quote
+
+  ! rank 0: make the rendezvous directory and start ranks 1..N-1 as copies of this command line
+  subroutine tp_launch_workers()
+    character(len=4096) :: arg
+    character(len=:), allocatable :: cmd, base
+    character(len=32) :: num
+    integer :: i, r, seed, ticks
+    if (opts%tp_rank > 0) return                       ! a worker: everything was handed down
+    write (num, "(I0)") c_getpid()
+    opts%tp_dir = "/tmp/llmk_tp_" // trim(num)
+    call execute_command_line("mkdir -p " // opts%tp_dir)
+    call get_command_argument(0, arg)
+    base = shell_quote(trim(arg))
+    do i = 1, command_argument_count()
+       call get_command_argument(i, arg)
+       base = base // " " // shell_quote(trim(arg))
+    end do
+    if (opts%temperature /= 0 .and. opts%seed < 0) then   ! sampling: every rank must draw the same numbers
+       call system_clock(ticks)
+       seed = iand(ticks, 1073741823)
+       opts%seed = seed
+       write (num, "(I0)") seed
+       base = base // " --seed " // trim(num)
+    end if
+    do r = 1, opts%ngpu - 1
+       write (num, "(I0)") r
+       cmd = base // " --tp-rank " // trim(num) // " --tp-dir " // opts%tp_dir // " > /dev/null 2> " // opts%tp_dir // &
+             "/rank" // trim(num) // ".err &"
+       call execute_command_line(cmd, wait=.false.)
+    end do
+  end subroutine tp_launch_workers
+
+  subroutine tp_put(name, bytes)
+    character(len=*), intent(in) :: name
+    character(kind=c_char), intent(in) :: bytes(:)
+    integer :: fu
+    open(newunit=fu, file=opts%tp_dir // "/" // name // ".tmp", form="unformatted", access="stream", status="replace")
+    write (fu) bytes
+    close(fu)
+    call execute_command_line("mv " // opts%tp_dir // "/" // name // ".tmp " // opts%tp_dir // "/" // name)   ! atomic
+  end subroutine tp_put
+
+  subroutine tp_get(name, bytes)
+    character(len=*), intent(in) :: name
+    character(kind=c_char), intent(out) :: bytes(:)
+    integer :: fu, waited
+    logical :: there
+    waited = 0
+    do
+       inquire(file=opts%tp_dir // "/" // name, exist=there)
+       if (there) exit
+       rc = c_usleep(20000_c_int)
+       waited = waited + 1
+       if (waited > 15000) then                        ! 5 minutes: a peer died while loading
+          print *, "tensor-parallel rendezvous timed out waiting for ", name
+          stop 1
+       end if
+    end do
+    open(newunit=fu, file=opts%tp_dir // "/" // name, form="unformatted", access="stream", status="old", action="read")
+    read (fu) bytes
+    close(fu)
+  end subroutine tp_get
+
+  ! exchange the inbox handles (or the RCCL id) through the rendezvous directory
+  subroutine tp_connect()
+    character(kind=c_char) :: h(64), uid(128)
+    character(kind=c_char), allocatable :: all(:)
+    character(len=32) :: num
+    integer :: r
+    if (opts%tp_rccl) then
+       if (opts%tp_rank == 0) then
+          call llmk_check(llmk_tp_unique_id(uid), "llmk_tp_unique_id")
+          call tp_put("uid", uid)
+       else
+          call tp_get("uid", uid)
+       end if
+       call llmk_check(llmk_tp_init_comm(ctx, uid), "llmk_tp_init_comm")
+       return
+    end if
+    call llmk_check(llmk_tp_p2p_handle(ctx, h), "llmk_tp_p2p_handle")
+    write (num, "(I0)") opts%tp_rank
+    call tp_put("inbox" // trim(num), h)
+    allocate(all(64 * opts%ngpu))
+    do r = 0, opts%ngpu - 1
+       write (num, "(I0)") r
+       call tp_get("inbox" // trim(num), all(64 * r + 1:64 * r + 64))
+    end do
+    call llmk_check(llmk_tp_p2p_connect(ctx, all), "llmk_tp_p2p_connect")
+  end subroutine tp_connect
+
+  ! rank 0 leaves last and removes the directory
+  subroutine tp_finish()
+    character(kind=c_char) :: one(1)
+    character(len=32) :: num
+    integer :: r
+    one(1) = "x"
+    write (num, "(I0)") opts%tp_rank
+    if (opts%tp_rank > 0) then
+       call tp_put("done" // trim(num), one)
+       return
+    end if
+    do r = 1, opts%ngpu - 1
+       write (num, "(I0)") r
+       call tp_get("done" // trim(num), one)
+    end do
+    call execute_command_line("rm -rf " // opts%tp_dir)
+  end subroutine tp_finish
 
 end program llm

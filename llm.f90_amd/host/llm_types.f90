@@ -34,12 +34,15 @@ module weight_module
      real(kind=wp), allocatable :: wcls(:,:)                    ! (emb, vocab)
      ! f16 / q4_0 path: ggml type of the five matrices and their bytes in the same fused order
      integer :: wtype = 0
+     integer :: wcls_type = 0      ! ggml type the classifier is handed over in (f32 when the loader dequantised a q6_K output.weight)
      integer(c_int8_t), allocatable :: wqkv_raw(:), wo_raw(:), w13_raw(:), w2_raw(:), wcls_raw(:)
   end type TransformerWeights
 
   type Config
      integer :: emb_dim, hidden_dim, n_layers, n_heads, n_kv_heads, vocab_size, seq_len
      integer :: kv_head_size
+     ! read from the file, used only on request (llm --gguf-eps / --gguf-rope-base); 0 = key absent
+     real(kind=wp) :: rms_eps = 0, rope_freq_base = 0
   end type Config
 
   ! The KV cache and attention scratch live on the device inside the llmk context; the host

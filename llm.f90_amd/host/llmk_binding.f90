@@ -22,6 +22,32 @@ module llmk_binding
        type(llmk_config), intent(in) :: cfg
        type(c_ptr), intent(out) :: ctx
      end function
+     ! tensor-parallel shard `tp_rank` of `tp_size` (the 70B configuration): llmk_upload is still handed the FULL arrays
+     integer(c_int) function llmk_create_tp(cfg, tp_rank, tp_size, ctx) bind(C, name="llmk_create_tp")
+       import :: c_int, c_ptr, llmk_config
+       type(llmk_config), intent(in) :: cfg
+       integer(c_int), value :: tp_rank, tp_size
+       type(c_ptr), intent(out) :: ctx
+     end function
+     integer(c_int) function llmk_tp_unique_id(id_out) bind(C, name="llmk_tp_unique_id")
+       import :: c_int, c_char
+       character(kind=c_char), intent(out) :: id_out(128)
+     end function
+     integer(c_int) function llmk_tp_init_comm(ctx, id) bind(C, name="llmk_tp_init_comm")
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: id(128)
+     end function
+     integer(c_int) function llmk_tp_p2p_handle(ctx, handle_out) bind(C, name="llmk_tp_p2p_handle")
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(out) :: handle_out(64)
+     end function
+     integer(c_int) function llmk_tp_p2p_connect(ctx, handles) bind(C, name="llmk_tp_p2p_connect")
+       import :: c_int, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: handles(*)     ! tp_size * 64 bytes, rank order
+     end function
      integer(c_int) function llmk_upload(ctx, tensor_id, host, nbytes, ggml_type) bind(C, name="llmk_upload")
        import :: c_int, c_ptr, c_size_t
        type(c_ptr), value :: ctx
@@ -38,6 +64,16 @@ module llmk_binding
        type(c_ptr), value :: host
        integer(c_size_t), value :: nbytes
        integer(c_int), value :: ggml_type
+     end function
+     integer(c_int) function llmk_set_tensor_type(ctx, tensor_id, ggml_type) bind(C, name="llmk_set_tensor_type")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: tensor_id, ggml_type
+     end function
+     integer(c_int) function llmk_set_rms_eps(ctx, eps) bind(C, name="llmk_set_rms_eps")
+       import :: c_int, c_ptr, c_float
+       type(c_ptr), value :: ctx
+       real(c_float), value :: eps
      end function
      integer(c_int) function llmk_set_rope_freqs(ctx, freqs, n) bind(C, name="llmk_set_rope_freqs")
        import :: c_int, c_ptr, c_float
@@ -83,6 +119,14 @@ module llmk_binding
      end function
      integer(c_int) function llmk_version() bind(C, name="llmk_version")
        import :: c_int
+     end function
+     ! libc, for the multi-process rendezvous of `llm --ngpu N`
+     integer(c_int) function c_getpid() bind(C, name="getpid")
+       import :: c_int
+     end function
+     integer(c_int) function c_usleep(us) bind(C, name="usleep")
+       import :: c_int
+       integer(c_int), value :: us
      end function
   end interface
 

@@ -21,9 +21,10 @@ TENSOR_IDS = {
 }
 FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 # every symbol include/llmk.h declares
-SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_begin", "llmk_tp_segment",
+SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_p2p_handle", "llmk_tp_p2p_connect",
+           "llmk_tp_p2p_connect_local", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
-           "llmk_set_rope_freqs", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_reset", "llmk_timings",
+           "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_reset", "llmk_timings",
            "llmk_time_kernel", "llmk_peek", "llmk_destroy", "llmk_strerror", "llmk_version"]
 
 
@@ -58,6 +59,9 @@ def lib():
         L.llmk_create_tp.argtypes = [C.POINTER(Config), ci, ci, C.POINTER(vp)]
         L.llmk_tp_unique_id.argtypes = [C.c_char_p]
         L.llmk_tp_init_comm.argtypes = [vp, C.c_char_p]
+        L.llmk_tp_p2p_handle.argtypes = [vp, C.c_char_p]
+        L.llmk_tp_p2p_connect.argtypes = [vp, C.c_char_p]
+        L.llmk_tp_p2p_connect_local.argtypes = [vp, C.POINTER(vp)]
         L.llmk_tp_begin.argtypes = [vp, ci, ci]
         L.llmk_tp_segment.argtypes = [vp, ci, ci]
         L.llmk_tp_read_partial.argtypes = [vp, cf]
@@ -66,6 +70,8 @@ def lib():
         L.llmk_upload.argtypes = [vp, ci, vp, C.c_size_t, ci]
         L.llmk_upload_rows.argtypes = [vp, ci, ci, ci, ci, vp, C.c_size_t, ci]
         L.llmk_set_rope_freqs.argtypes = [vp, cf, ci]
+        L.llmk_set_tensor_type.argtypes = [vp, ci, ci]
+        L.llmk_set_rms_eps.argtypes = [vp, C.c_float]
         L.llmk_forward.argtypes = [vp, ci, ci, cf]
         L.llmk_prefill.argtypes = [vp, C.POINTER(ci), ci, ci, cf]
         L.llmk_forward_greedy.argtypes = [vp, ci, ci, C.POINTER(ci)]
@@ -102,10 +108,14 @@ class Llmk:
                      seq_len or s.seq_len, fw.ggml_type, device, flags)
         self._h = C.c_void_p()
         _ck(lib().llmk_create_tp(C.byref(cfg), tp_rank, tp_size, C.byref(self._h)))
+        cls_type = getattr(fw, "cls_type", fw.ggml_type)
+        if cls_type != fw.ggml_type:      # e.g. a q6_K output.weight dequantised by the loader
+            _ck(lib().llmk_set_tensor_type(self._h, TENSOR_IDS["wcls"], cls_type))
         for name, tid in TENSOR_IDS.items():
             a = np.ascontiguousarray(getattr(fw, name))
             is_mat = name in ("wqkv", "wo", "w13", "w2", "wcls")
-            _ck(lib().llmk_upload(self._h, tid, a.ctypes.data, a.nbytes, fw.ggml_type if is_mat else 0))
+            _ck(lib().llmk_upload(self._h, tid, a.ctypes.data, a.nbytes,
+                                  (cls_type if name == "wcls" else fw.ggml_type) if is_mat else 0))
         # the reference's own f32 expression for the RoPE frequencies (llama2.f90:544-545)
         hs = s.head_size
         fr = np.float32(1.0) / np.power(np.float32(10000.0), (np.arange(1, hs, 2, dtype=np.float32) / np.float32(hs)),
@@ -116,6 +126,9 @@ class Llmk:
     def set_rope_freqs(self, fr):
         fr = np.ascontiguousarray(fr, np.float32)
         _ck(lib().llmk_set_rope_freqs(self._h, fr.ctypes.data_as(C.POINTER(C.c_float)), len(fr)))
+
+    def set_rms_eps(self, eps: float):
+        _ck(lib().llmk_set_rms_eps(self._h, eps))
 
     def forward(self, token: int, pos: int) -> np.ndarray:
         """1-based token and pos, as `transformer(token,pos,s,weights)` (llama2.f90:380)."""
@@ -166,6 +179,22 @@ class Llmk:
 
     def tp_init_comm(self, uid: bytes):
         _ck(lib().llmk_tp_init_comm(self._h, C.create_string_buffer(uid, 128)))
+
+    def tp_p2p_handle(self) -> bytes:
+        buf = C.create_string_buffer(64)
+        _ck(lib().llmk_tp_p2p_handle(self._h, buf))
+        return buf.raw
+
+    def tp_p2p_connect(self, handles):
+        """handles: the tp_size 64-byte inbox handles in rank order (other PROCESSES' ranks)"""
+        _ck(lib().llmk_tp_p2p_connect(self._h, C.create_string_buffer(b"".join(handles), 64 * len(handles))))
+
+    @staticmethod
+    def tp_p2p_connect_local(ranks):
+        """ranks: the tp_size Llmk objects of ONE process, in rank order"""
+        arr = (C.c_void_p * len(ranks))(*[m._h for m in ranks])
+        for m in ranks:
+            _ck(lib().llmk_tp_p2p_connect_local(m._h, arr))
 
     def tp_begin(self, token: int, pos: int):
         _ck(lib().llmk_tp_begin(self._h, token, pos))

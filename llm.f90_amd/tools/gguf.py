@@ -26,8 +26,11 @@ import numpy as np
 
 GGUF_MAGIC = 0x46554747  # "GGUF" little endian == 1179993927 (read_ggml.f90:122)
 GGML_F32, GGML_F16, GGML_Q4_0 = 0, 1, 2
+GGML_Q6_K = 14
 QK4_0 = 32
 Q4_0_BLOCK_BYTES = 18
+QK_K = 256
+Q6_K_BLOCK_BYTES = 210
 
 # GGUF metadata value types
 T_U8, T_I8, T_U16, T_I16, T_U32, T_I32, T_F32, T_BOOL, T_STR, T_ARR, T_U64, T_I64, T_F64 = range(13)
@@ -183,6 +186,51 @@ def dequantize_q4_0(raw: np.ndarray, cols: int) -> np.ndarray:
     return vals.reshape(*raw.shape[:-1], cols)
 
 
+def quantize_q6_K(w: np.ndarray) -> np.ndarray:
+    """A valid ggml block_q6_K encoding of w (256 weights -> ql[128] | qh[64] | int8 scales[16] | f16 d): per 16-weight
+    sub-block a scale s = max|x|/31, d = max s / 127, 6-bit q = round(x / (d*sc)) + 32.  (Not ggml's search-based
+    quantiser -- any encoding is a legitimate file; what the loaders must agree on is the DEcoding.)  uint8 [..., K/256*210]."""
+    assert w.shape[-1] % QK_K == 0
+    x = w.reshape(-1, 16, 16).astype(np.float32)                  # [block][sub-block][16]
+    s = np.abs(x).max(axis=2) / np.float32(31.0)                  # [block][16]
+    d = (s.max(axis=1) / np.float32(127.0)).astype(np.float16)    # [block]
+    df = d.astype(np.float32)
+    sc = np.where(df[:, None] > 0, np.clip(np.rint(s / np.where(df[:, None] > 0, df[:, None], 1)), 1, 127), 1).astype(np.int8)
+    step = df[:, None, None] * sc[:, :, None].astype(np.float32)
+    q = np.clip(np.rint(np.where(step > 0, x / np.where(step > 0, step, 1), 0)), -32, 31).astype(np.int32) + 32   # 0..63
+    q = q.reshape(-1, 2, 4, 32)                                   # [block][half][quarter][l]
+    ql = np.empty((q.shape[0], 2, 64), np.uint8)
+    ql[:, :, 0:32] = (q[:, :, 0] & 15) | ((q[:, :, 2] & 15) << 4)
+    ql[:, :, 32:64] = (q[:, :, 1] & 15) | ((q[:, :, 3] & 15) << 4)
+    qh = ((q[:, :, 0] >> 4) | ((q[:, :, 1] >> 4) << 2) | ((q[:, :, 2] >> 4) << 4) | ((q[:, :, 3] >> 4) << 6)).astype(np.uint8)
+    out = np.empty((q.shape[0], Q6_K_BLOCK_BYTES), np.uint8)
+    out[:, 0:128] = ql.reshape(-1, 128)
+    out[:, 128:192] = qh.reshape(-1, 64)
+    out[:, 192:208] = sc.view(np.uint8)
+    out[:, 208:210] = d.view(np.uint8).reshape(-1, 2)
+    return out.reshape(*w.shape[:-1], w.shape[-1] // QK_K * Q6_K_BLOCK_BYTES)
+
+
+def dequantize_q6_K(raw: np.ndarray, cols: int) -> np.ndarray:
+    """ggml dequantize_row_q6_K: y = d * scale * (q - 32), evaluated left to right in f32.  uint8 [..., cols/256*210] -> f32."""
+    b = raw.reshape(-1, Q6_K_BLOCK_BYTES)
+    ql = b[:, 0:128].reshape(-1, 2, 64).astype(np.int32)
+    qh = b[:, 128:192].reshape(-1, 2, 32).astype(np.int32)
+    sc = b[:, 192:208].copy().view(np.int8).reshape(-1, 2, 8).astype(np.float32)
+    d = b[:, 208:210].copy().view(np.float16).astype(np.float32).reshape(-1, 1, 1)
+    q = np.empty((b.shape[0], 2, 4, 32), np.int32)
+    q[:, :, 0] = (ql[:, :, 0:32] & 15) | (((qh >> 0) & 3) << 4)
+    q[:, :, 1] = (ql[:, :, 32:64] & 15) | (((qh >> 2) & 3) << 4)
+    q[:, :, 2] = (ql[:, :, 0:32] >> 4) | (((qh >> 4) & 3) << 4)
+    q[:, :, 3] = (ql[:, :, 32:64] >> 4) | (((qh >> 6) & 3) << 4)
+    q -= 32
+    # sub-block scale of element (quarter g, l): scales[l // 16 + 2 g]
+    idx = (np.arange(32) // 16)[None, :] + 2 * np.arange(4)[:, None]            # [4][32]
+    scq = sc[:, :, idx]                                                          # [block][half][4][32]
+    y = (d[..., None] * scq) * q.astype(np.float32)
+    return y.reshape(*raw.shape[:-1], cols)
+
+
 def encode(w: np.ndarray, ggml_type: int) -> np.ndarray:
     if ggml_type == GGML_F32:
         return np.ascontiguousarray(w, dtype="<f4")
@@ -190,6 +238,8 @@ def encode(w: np.ndarray, ggml_type: int) -> np.ndarray:
         return np.ascontiguousarray(w.astype("<f2"))
     if ggml_type == GGML_Q4_0:
         return quantize_q4_0(w)
+    if ggml_type == GGML_Q6_K:
+        return quantize_q6_K(w)
     raise ValueError(ggml_type)
 
 
@@ -201,6 +251,8 @@ def decode(raw: np.ndarray, ggml_type: int, cols: int) -> np.ndarray:
         return raw.view("<f2").astype(np.float32) if raw.dtype != np.float16 else raw.astype(np.float32)
     if ggml_type == GGML_Q4_0:
         return dequantize_q4_0(raw, cols)
+    if ggml_type == GGML_Q6_K:
+        return dequantize_q6_K(raw, cols)
     raise ValueError(ggml_type)
 
 
@@ -245,6 +297,11 @@ class FusedWeights:
     w13: np.ndarray = None                    # [L][2H][E*]  rows 0..H-1 gate, H.. up (read_ggml.f90:347,376)
     w2: np.ndarray = None                     # [L][E][H*]
     wcls: np.ndarray = None                   # [V][E*]
+    wcls_type: int = None                     # the classifier's own ggml type when it differs (q6_K output.weight -> f32)
+
+    @property
+    def cls_type(self) -> int:
+        return self.ggml_type if self.wcls_type is None else self.wcls_type
 
     def as_f32(self) -> "FusedWeights":
         """Same weights with every matrix decoded to f32 (what an f32 reference run consumes)."""
@@ -252,7 +309,7 @@ class FusedWeights:
         return FusedWeights(s, GGML_F32, self.token_embedding_table, self.rms_att_weight, self.rms_ffn_weight,
                             self.rms_final_weight, decode(self.wqkv, t, s.emb_dim), decode(self.wo, t, s.emb_dim),
                             decode(self.w13, t, s.emb_dim), decode(self.w2, t, s.hidden_dim),
-                            decode(self.wcls, t, s.emb_dim))
+                            decode(self.wcls, self.cls_type, s.emb_dim))
 
 
 def synth_fused(shape: LlamaShape, seed: int, ggml_type: int = GGML_F32) -> FusedWeights:
@@ -347,9 +404,12 @@ def _tensor_source(fw: "FusedWeights", name: str) -> np.ndarray:
     }[rest]()
 
 
-def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int = 3) -> None:
-    """Write fused weights as a Llama GGUF. With f32 matrices the reference loader reads it as is."""
+def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int = 3, rms_eps: float = 1e-5,
+               rope_freq_base: float = None, output_q6k: bool = False) -> None:
+    """Write fused weights as a Llama GGUF. With f32 matrices the reference loader reads it as is.
+    output_q6k: store output.weight as q6_K (what stock llama.cpp q4_0 files do), quantised from the decoded wcls."""
     shape, ggml_type = fw.shape, fw.ggml_type
+    out_raw = quantize_q6_K(decode(fw.wcls, fw.cls_type, shape.emb_dim)) if output_q6k else None
     names = tensor_names(shape)
     vocab = vocab_strings(shape.vocab_size)
     kvs = [
@@ -361,10 +421,13 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
         ("llama.feed_forward_length", T_U32, shape.hidden_dim),
         ("llama.attention.head_count", T_U32, shape.n_heads),
         ("llama.attention.head_count_kv", T_U32, shape.n_kv_heads),
-        ("llama.attention.layer_norm_rms_epsilon", T_F32, 1e-5),
+        ("llama.attention.layer_norm_rms_epsilon", T_F32, rms_eps),
         ("general.alignment", T_U32, alignment),
         ("tokenizer.ggml.model", T_STR, b"llama"),
     ]
+    if rope_freq_base is not None:
+        kvs.append(("llama.rope.freq_base", T_F32, rope_freq_base))
+    src = lambda name: out_raw if (output_q6k and name == "output.weight") else _tensor_source(fw, name)
     with open(path, "wb") as f:
         f.write(struct.pack("<IIqq", GGUF_MAGIC, version, len(names), len(kvs) + 2))
         for k, t, v in kvs:
@@ -385,7 +448,9 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
         infos = []
         for name, dims, kind in names:
             tt = ggml_type if kind == "mat" else GGML_F32
-            nbytes = _tensor_source(fw, name).nbytes
+            if name == "output.weight":
+                tt = GGML_Q6_K if output_q6k else fw.cls_type
+            nbytes = src(name).nbytes
             infos.append((tt, offset, nbytes))
             _w_str(f, name.encode())
             f.write(struct.pack("<I", len(dims)))
@@ -397,7 +462,7 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
         data_start = f.tell()
         for (name, dims, kind), (tt, off, nbytes) in zip(names, infos):
             assert f.tell() == data_start + off
-            f.write(np.ascontiguousarray(_tensor_source(fw, name)).data)
+            f.write(np.ascontiguousarray(src(name)).data)
             f.write(b"\0" * ((-nbytes) % alignment))
 
 
@@ -456,11 +521,11 @@ class GGUFFile:
         dims, tt, off = self.tensors[name]
         cols = dims[0]
         rows = int(np.prod(dims[1:])) if len(dims) > 1 else 1
-        row_bytes = {GGML_F32: 4 * cols, GGML_F16: 2 * cols, GGML_Q4_0: cols // 32 * 18}[tt]
+        row_bytes = {GGML_F32: 4 * cols, GGML_F16: 2 * cols, GGML_Q4_0: cols // 32 * 18, GGML_Q6_K: cols // 256 * 210}[tt]
         with open(self.path, "rb") as f:
             f.seek(self.data_start + off)
             raw = np.frombuffer(f.read(rows * row_bytes), dtype=np.uint8)
-        dt = {GGML_F32: "<f4", GGML_F16: "<f2", GGML_Q4_0: np.uint8}[tt]
+        dt = {GGML_F32: "<f4", GGML_F16: "<f2", GGML_Q4_0: np.uint8, GGML_Q6_K: np.uint8}[tt]
         arr = raw.view(dt)
         return (arr.reshape(rows, -1) if len(dims) > 1 else arr), tt
 
@@ -519,7 +584,10 @@ def load_fused(path: str) -> FusedWeights:
     emb, et = g.read_tensor("token_embd.weight")
     fw.token_embedding_table = decode(emb, et, E)
     fw.rms_final_weight = g.read_tensor("output_norm.weight")[0].astype(np.float32)
-    fw.wcls = g.read_tensor("output.weight")[0]
+    fw.wcls, ct = g.read_tensor("output.weight")
+    if ct != mt:   # mixed file: the classifier is handed over dequantised, as the Fortran loader does (q6_K output.weight)
+        fw.wcls = decode(fw.wcls, ct, E)
+        fw.wcls_type = GGML_F32
     cat = lambda parts: np.ascontiguousarray(np.concatenate(parts, axis=0))
     fw.rms_att_weight = np.stack([g.read_tensor(f"blk.{i}.attn_norm.weight")[0] for i in range(L)]).astype(np.float32)
     fw.rms_ffn_weight = np.stack([g.read_tensor(f"blk.{i}.ffn_norm.weight")[0] for i in range(L)]).astype(np.float32)

@@ -53,8 +53,13 @@ static float dotf(const float *a, const float *b, int n) {
 }
 
 /* llama2.f90:450-457 */
+/* The reference's constant (llama2.f90:454).  oracle_set_eps exists ONLY to check the product's opt-in extension
+ * (llmk_set_rms_eps, llm --gguf-eps); every parity test runs with the default. */
+static float g_eps = 1e-5f;
+void oracle_set_eps(float eps) { g_eps = eps; }
+
 static void rmsnorm(float *out, const float *x, const float *w, int n) {
-    float xn = sqrtf(dotf(x, x, n) / (float)n + 1e-5f);
+    float xn = sqrtf(dotf(x, x, n) / (float)n + g_eps);
     for (int i = 0; i < n; ++i) out[i] = x[i] * w[i] / xn;
 }
 

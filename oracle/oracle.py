@@ -40,6 +40,8 @@ def _lib(flavour: str):
     lib.oracle_forward.restype = C.c_int
     lib.oracle_generate.argtypes = [C.POINTER(_Model), C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int), _F]
     lib.oracle_generate.restype = C.c_int
+    lib.oracle_set_eps.argtypes = [C.c_float]
+    lib.oracle_set_eps.restype = None
     return lib
 
 
@@ -63,6 +65,10 @@ class Oracle:
         m.key_cache = self.key_cache.ctypes.data_as(_F)
         m.value_cache = self.value_cache.ctypes.data_as(_F)
         self.m = m
+
+    def set_eps(self, eps: float):
+        """rmsnorm epsilon other than the reference's 1e-5 (process-wide; only for the opt-in extension's test)"""
+        self.lib.oracle_set_eps(eps)
 
     def reset(self):
         self.key_cache[:] = 0

@@ -19,7 +19,8 @@ program loader_dump
   call load_ggml(trim(inpath), w, c, vocab, scores, tl, .false.)
   open(newunit=u, file=trim(outpath), form="unformatted", access="stream", status="replace")
   write(u) c%emb_dim, c%hidden_dim, c%n_layers, c%n_heads, c%n_kv_heads, c%vocab_size, c%seq_len, c%kv_head_size
-  write(u) w%wtype, int(len(vocab(1)), 4)
+  write(u) w%wtype, int(len(vocab(1)), 4), w%wcls_type
+  write(u) c%rms_eps, c%rope_freq_base
   write(u) tl
   write(u) scores
   do i = 1, size(vocab)
@@ -40,7 +41,11 @@ program loader_dump
      write(u) w%wo_raw
      write(u) w%w13_raw
      write(u) w%w2_raw
-     write(u) w%wcls_raw
+     if (w%wcls_type == 0) then
+        write(u) w%wcls            ! dequantised by the loader (q6_K output.weight)
+     else
+        write(u) w%wcls_raw
+     end if
   end if
   close(u)
 end program loader_dump

@@ -96,3 +96,70 @@ def test_cli_prefill_flag_prints_the_reference_transcript(tag, gguf, tmp_path):
     ref = bytes(g["stdout"]).split(b"\n")
     k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
     assert out[:k] == ref[:k]
+
+
+def test_cli_loads_a_stock_layout_q4_0_file_with_q6k_output_weight(gguf, tmp_path):
+    from llm_f90_amd import llmk
+    s = gguf.LlamaShape(256, 512, 2, 4, 2, 320, 48)
+    path = str(tmp_path / "q6k.gguf")
+    gguf.write_gguf(path, gguf.synth_fused(s, 5, 2), output_q6k=True)
+    out = _run(["-m", path, "-n", "14"], str(tmp_path)).split(b"\n")
+    m = llmk.Llmk(gguf.load_fused(path))
+    toks, _ = m.generate(14)
+    m.close()
+    vocab = gguf.vocab_strings(s.vocab_size)
+    assert out[1].rstrip(b" ") == b"".join(vocab[t - 1] for t in toks).rstrip(b" ")
+
+
+def test_cli_opt_in_gguf_epsilon_and_rope_base(gguf, tmp_path):
+    """--gguf-eps / --gguf-rope-base honour the file's values; without the flags the reference behaviour (1e-5, 10000) stays"""
+    from llm_f90_amd import llmk
+    g = load_golden("tiny-hs64")
+    s = gguf.SHAPES["tiny-hs64"]
+    fw = gguf.synth_fused(s, int(g["seed"]))
+    path = str(tmp_path / "m.gguf")
+    gguf.write_gguf(path, fw, rms_eps=0.05, rope_freq_base=500.0)
+    ref = bytes(g["stdout"]).split(b"\n")
+    n = int(g["n"])
+    assert _run(["-m", path, "-n", str(n)], str(tmp_path)).split(b"\n")[1] == ref[1]        # flags absent: the reference's output
+    out = _run(["-m", path, "-n", str(n), "--gguf-eps", "--gguf-rope-base"], str(tmp_path)).split(b"\n")
+    m = llmk.Llmk(fw)
+    m.set_rms_eps(0.05)
+    hs = s.head_size
+    m.set_rope_freqs(np.float32(1.0) / np.power(np.float32(500.0), np.arange(1, hs, 2, dtype=np.float32) / np.float32(hs), dtype=np.float32))
+    toks, _ = m.generate(n)
+    m.close()
+    vocab = gguf.vocab_strings(s.vocab_size)
+    assert out[1].rstrip(b" ") == b"".join(vocab[t - 1] for t in toks).rstrip(b" ")
+    assert out[1] != ref[1]
+
+
+def test_cli_byte_fallback_and_seeded_sampler(gguf, tmp_path):
+    """A prompt byte with no single-character token must not crash (the reference indexes vocab_len(-1)): it becomes
+    <0xXX> when the vocabulary has byte tokens, else <unk>.  --seed makes temperature sampling reproducible."""
+    s = gguf.SHAPES["tiny-hs64"]
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, s, 20260928)
+    out = _run(["-m", path, "-n", "8", "-p", "a\tb"], str(tmp_path)).split(b"\n")      # TAB is not in the synthetic vocabulary
+    assert out[1].startswith(b"a<unk>b")
+    a = _run(["-m", path, "-n", "24", "-t", "0.9", "--seed", "7"], str(tmp_path)).split(b"\n")[1]
+    b = _run(["-m", path, "-n", "24", "-t", "0.9", "--seed", "7"], str(tmp_path)).split(b"\n")[1]
+    c = _run(["-m", path, "-n", "24", "-t", "0.9", "--seed", "8"], str(tmp_path)).split(b"\n")[1]
+    assert a == b and a != c
+
+
+def test_cli_ngpu_two_ranks_over_peer_memory_on_one_gpu(gguf, tmp_path):
+    """`llm --ngpu 2`: rank 0 starts a second process, both load the file and keep their shard, meet through the
+    rendezvous directory (64-byte inbox handles over hipIpc) and decode in lock step with the one-shot peer-memory
+    collectives.  LLMK_TP_SAME_DEVICE puts both ranks on this box's single GPU: two real processes, real IPC mappings,
+    real cross-process granule traffic; only the link is HBM instead of xGMI.  Transcript = the real reference's."""
+    g = load_golden("tiny-gqa")
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, gguf.SHAPES["tiny-gqa"], int(g["seed"]))
+    env = dict(os.environ, LLMK_TP_SAME_DEVICE="1")
+    r = subprocess.run([LLM, "-m", path, "-n", str(int(g["n"])), "-t", "0", "--ngpu", "2"], capture_output=True, cwd=str(tmp_path),
+                       timeout=180, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.split(b"\n")
+    ref = bytes(g["stdout"]).split(b"\n")
+    assert out[0] == ref[0] and out[1] == ref[1]

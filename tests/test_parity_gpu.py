@@ -337,3 +337,46 @@ def test_llama2_7b_full_shape_q4_0_properties():
     _, lr = ref.generate(n, prompt=t1.tolist())
     ref.close()
     assert rel_err(l1, lr).max() <= 2e-5
+
+
+def test_opt_in_rms_epsilon_matches_the_oracle_with_the_same_epsilon(gguf):
+    """llmk_set_rms_eps (extension; the reference hard-codes 1e-5, llama2.f90:454): default == explicit 1e-5 bit for
+    bit, and another epsilon follows the oracle run with that epsilon -- on both the persistent and the multi-kernel path."""
+    s = gguf.SHAPES["tk-small"]
+    fw = gguf.synth_fused(s, 123)
+    n = 10
+    for flags in (0, llmk.FLAG_MULTI_KERNEL):
+        m = llmk.Llmk(fw, flags=flags)
+        t0, l0 = m.generate(n)
+        m.set_rms_eps(1e-5)
+        t1, l1 = m.generate(n)
+        assert np.array_equal(l0, l1)
+        m.set_rms_eps(0.05)
+        _, l2 = m.generate(n, prompt=t0.tolist())
+        m.close()
+        o = Oracle(fw, "strict")
+        try:
+            o.set_eps(0.05)
+            _, ol = o.generate(n, prompt=t0.tolist())
+        finally:
+            o.set_eps(1e-5)
+        assert rel_err(l2, ol).max() <= REL_TOL
+        assert rel_err(l2, l0).max() > 100 * REL_TOL      # the epsilon really took effect
+
+
+def test_classifier_with_its_own_type_q6k_output_weight(gguf, tmp_path):
+    """A q4_0 file whose output.weight is q6_K (stock llama.cpp layout): the loader dequantises the classifier, the ctx
+    re-types LLMK_WCLS to f32 (llmk_set_tensor_type) and runs; checked against the oracle on the fully decoded weights."""
+    s = gguf.LlamaShape(256, 512, 2, 4, 2, 320, 48)
+    path = str(tmp_path / "q6k.gguf")
+    gguf.write_gguf(path, gguf.synth_fused(s, 5, 2), output_q6k=True)
+    fw = gguf.load_fused(path)
+    assert fw.ggml_type == 2 and fw.cls_type == 0
+    n = 16
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    m = llmk.Llmk(fw)
+    _, l = m.generate(n, prompt=ot.tolist())
+    assert rel_err(l, ol).max() <= REL_TOL
+    lg = m.prefill([2] + ot[:n - 1].tolist(), 1)
+    assert rel_err(lg[None], ol[n - 1][None]).max() <= REL_TOL
+    m.close()
