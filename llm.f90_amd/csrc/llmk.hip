@@ -528,6 +528,8 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->p2p) {   // a peer never delivered its granules: the sticky word says so (cleared by llmk_reset)
             const unsigned perr = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
+            if (perr) fprintf(stderr, "llmk: rank %d of %d: a peer's granules never arrived (code 0x%x, position %d, serial %d)\n",
+                              c->tp_rank, c->tp_size, perr, pos, c->h_tokpos[2]);
             return perr ? LLMK_E_TIMEOUT : LLMK_OK;
         }
         if (!c->use_tk) return LLMK_OK;

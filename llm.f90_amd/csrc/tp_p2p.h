@@ -82,18 +82,22 @@ __global__ __launch_bounds__(256) void tp_allreduce_add_kernel(TpPeers peers, co
 }
 
 // logits[0..V) = concatenation of the ranks' Vl-row slices                     (classifier, llama2.f90:634-636)
-__global__ __launch_bounds__(256) void tp_allgather_kernel(TpPeers peers, float* __restrict__ logits, const int* __restrict__ tokpos,
+__global__ __launch_bounds__(256) void tp_allgather_kernel(TpPeers peers, float* logits, const int* __restrict__ tokpos,
                                                            int ncalls, int me, int P, int E, int V, unsigned* err) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= V) return;
-    const int Vl = V / P, owner = j / Vl;
+    const int Vl = V / P, owner = j < V ? j / Vl : -1;
     const unsigned serial = (unsigned)tokpos[2];
     const unsigned epoch = serial * (unsigned)(ncalls + 1) + (unsigned)ncalls + 1u;
     const size_t base = (size_t)2 * P * E + (size_t)(serial & 1) * V;
+    // Two separate statements, NOT if/else: a wave can hold owners and receivers side by side, and with an if/else the
+    // hardware may run the spinning side first -- the owners' stores then never issue, and the peer's mirror-image wave
+    // waits for them while this one waits for the peer's (observed on MI355X: the first rank to arrive hung).  Every
+    // lane's sends are issued before any lane starts to wait.
     if (owner == me) {
         const float v = logits[j];
         for (int r = 1; r < P; ++r) tp_send(peers.inbox[(me + r) % P] + base + j, epoch, v);
-    } else {
+    }
+    if (owner >= 0 && owner != me) {
         float v;
         if (tp_recv(peers.inbox[me] + base + j, epoch, &v, err)) logits[j] = v;
     }

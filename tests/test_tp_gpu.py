@@ -132,11 +132,13 @@ def _in_threads(ranks, fn):
     return out
 
 
-@pytest.mark.parametrize("shape,P", [("tiny-gqa", 2), ("tiny-mha", 4), ("tk-small", 2)])
+@pytest.mark.parametrize("shape,P", [("tiny-gqa", 2), ("tiny-mha", 2), ("tk-small", 2)])
 def test_one_shot_peer_memory_collectives_virtual_ranks(shape, P, gguf):
     """csrc/tp_p2p.h on hardware: P contexts on this GPU, each with its own stream and inbox, connected with
     llmk_tp_p2p_connect_local; every rank runs llmk_forward in its own host thread and the all-reduce / all-gather
-    kernels exchange granules for real (through HBM instead of xGMI).  Reference goldens; all ranks bit-identical."""
+    kernels exchange granules for real (through HBM instead of xGMI).  Reference goldens; all ranks bit-identical.
+    (Two ranks per process: the ranks' kernels wait for each other, so each needs its own hardware queue, and one process
+    gets four.  More ranks on one GPU run as separate processes, below -- the deployment shape anyway.)"""
     g = load_golden(shape)
     s = gguf.SHAPES[shape]
     fw = gguf.synth_fused(s, int(g["seed"]))
@@ -185,30 +187,39 @@ def _ipc_rank(rank, P, shape_name, seed, n, conn, device):
     m.close()
 
 
-@pytest.mark.parametrize("same_device", [True, False], ids=["one-gpu", "two-gpus"])
-def test_two_processes_exchange_over_ipc_mapped_inboxes(same_device, gguf):
+@pytest.mark.parametrize("P,same_device,tag", [(2, True, "tiny-gqa"), (4, True, "tiny-mha"), (2, False, "tiny-gqa"), (4, False, "tiny-mha")],
+                         ids=["2-ranks-one-gpu", "4-ranks-one-gpu", "2-gpus", "4-gpus"])
+def test_rank_processes_exchange_over_ipc_mapped_inboxes(P, same_device, tag, gguf):
     """The deployment shape: one PROCESS per rank, inboxes exported with hipIpcGetMemHandle and mapped by the peers.
-    one-gpu: both ranks on device 0 (what this box has); two-gpus: devices 0 and 1 over xGMI (skipped without a second GPU)."""
+    one-gpu: all ranks on device 0 (what this box has); N-gpus: devices 0..N-1 over xGMI (skipped without them)."""
     import multiprocessing as mp
     import torch
-    if not same_device and torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
-    g = load_golden("tiny-gqa")
-    n, P = int(g["n"]), 2
+    if not same_device and torch.cuda.device_count() < P:
+        pytest.skip(f"needs {P} GPUs")
+    g = load_golden(tag)
+    n = int(g["n"])
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(P)]
-    procs = [ctx.Process(target=_ipc_rank, args=(r, P, "tiny-gqa", int(g["seed"]), n, pipes[r][1], 0 if same_device else r))
+    procs = [ctx.Process(target=_ipc_rank, args=(r, P, tag, int(g["seed"]), n, pipes[r][1], 0 if same_device else r))
              for r in range(P)]
     for p in procs:
         p.start()
-    handles = [pipes[r][0].recv() for r in range(P)]
+
+    def get(r, what):
+        if not pipes[r][0].poll(120):                 # a hung or dead rank must fail the test, not stall it
+            for p in procs:
+                p.terminate()
+            pytest.fail(f"rank {r} never delivered its {what}")
+        return pipes[r][0].recv()
+    handles = [get(r, "inbox handle") for r in range(P)]
     for r in range(P):
         pipes[r][0].send(handles)
-    res = [pipes[r][0].recv() for r in range(P)]
+    res = [get(r, "result") for r in range(P)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     for toks, logits in res:
         assert rel_err(logits, g["logits"]).max() <= REL_TOL
         assert np.array_equal(toks, g["tokens"])
-    assert np.array_equal(res[0][1], res[1][1])
+    for r in range(1, P):
+        assert np.array_equal(res[0][1], res[r][1])
