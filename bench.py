@@ -132,10 +132,12 @@ class _ShapeOnly:
         self.shape, self.ggml_type = shape, wtype
 
 
-def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep):
+def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, collective="p2p"):
     """Create the ctx first, then upload layer by layer (llmk_upload_rows hands over FULL layers; a
     tensor-parallel ctx keeps only its shard).  q4_0 weights of the big shapes are generated directly in
-    block format.  With tp_size > 1 rank 0's RCCL unique id is broadcast over torch.distributed."""
+    block format.  With tp_size > 1 the ranks meet over torch.distributed (a side channel only): the 64-byte inbox
+    handles of the one-shot peer-memory collectives are all-gathered (collective "p2p"), or rank 0's RCCL unique id is
+    broadcast (collective "rccl", the library baseline)."""
     import ctypes as C
     s = shape
     E, H, L, KV, V = s.emb_dim, s.hidden_dim, s.n_layers, s.kv_dim, s.vocab_size
@@ -145,7 +147,11 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep):
     m._h = C.c_void_p()
     llmk._ck(llmk.lib().llmk_create_tp(C.byref(cfg), tp_rank, tp_size, C.byref(m._h)))
     m._logits = np.empty(V, np.float32)
-    if tp_size > 1 or rep is not None:
+    if (tp_size > 1 or rep is not None) and collective == "p2p" and tp_size > 1:
+        handles = [None] * tp_size
+        rep.dist.all_gather_object(handles, m.tp_p2p_handle())
+        m.tp_p2p_connect(handles)
+    elif tp_size > 1 or rep is not None:
         uid = llmk.Llmk.tp_unique_id() if tp_rank == 0 else bytes(128)
         if rep is not None and rep.dist is not None:
             import torch
@@ -240,6 +246,8 @@ def main():
     ap.add_argument("--tp", action="store_true",
                     help="tensor-parallel: ONE model sharded over the N ranks (RCCL all-reduce), the 70B configuration; "
                          "default for N>1 is N independent replicas")
+    ap.add_argument("--tp-collective", default="p2p", choices=["p2p", "rccl"],
+                    help="--tp: one-shot all-reduce over peer memory (csrc/tp_p2p.h, default) or ncclAllReduce (library baseline)")
     ap.add_argument("--greedy-on-device", action="store_true", help="time llmk_forward_greedy instead")
     ap.add_argument("--prefill", type=int, default=0, metavar="N",
                     help="auxiliary line (not the headline metric): time llmk_prefill on an N-token prompt (SURVEY.md 8f rank 1)")
@@ -273,7 +281,8 @@ def main():
     fw = None if big else gguf.synth_fused(shape, SEED, wtype)
     t_gen = time.perf_counter() - t0
     if a.tp or big:
-        m = build_streamed(shape, wtype, fw, local, flags, rank if a.tp else 0, world if a.tp else 1, rep if a.tp else None)
+        m = build_streamed(shape, wtype, fw, local, flags, rank if a.tp else 0, world if a.tp else 1, rep if a.tp else None,
+                           a.tp_collective)
     else:
         m = llmk.Llmk(fw, device=local, flags=flags)
     t_up = time.perf_counter() - t0 - t_gen
@@ -321,7 +330,9 @@ def main():
         "dtype": a.type, "data": "synthetic",
         "config": {"workload": f"{a.shape} {a.type} decode, greedy, positions {W + 1}..{W + K} (./llm -n {W + K} -t 0)",
                    "consumer": "device argmax (llmk_forward_greedy)" if step else "logits to host + host argmax (llmk_forward)",
-                   "parallelism": (f"tp{world} (row-parallel GEMVs, RCCL all-reduce)" if a.tp else "replicas" if world > 1 else "single GPU"), "seed": SEED,
+                   "parallelism": ((f"tp{world} (row-parallel GEMVs, " + ("one-shot peer-memory all-reduce" if a.tp_collective == "p2p" else "RCCL all-reduce")
+                                    + (", ALL RANKS SHARING ONE GPU: protocol check, not a scaling number" if os.environ.get("LLMK_SHARE_GPU") else "") + ")")
+                                   if a.tp else "replicas" if world > 1 else "single GPU"), "seed": SEED,
                    "path": "multi-kernel (5 launches/layer)" if a.multi_kernel else "default (persistent token kernel where instantiated)"},
     }
     if rank == 0:

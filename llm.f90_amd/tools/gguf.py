@@ -405,13 +405,14 @@ def _tensor_source(fw: "FusedWeights", name: str) -> np.ndarray:
 
 
 def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int = 3, rms_eps: float = 1e-5,
-               rope_freq_base: float = None, output_q6k: bool = False) -> None:
+               rope_freq_base: float = None, output_q6k: bool = False, vocab: List[bytes] = None, scores=None) -> None:
     """Write fused weights as a Llama GGUF. With f32 matrices the reference loader reads it as is.
     output_q6k: store output.weight as q6_K (what stock llama.cpp q4_0 files do), quantised from the decoded wcls."""
     shape, ggml_type = fw.shape, fw.ggml_type
     out_raw = quantize_q6_K(decode(fw.wcls, fw.cls_type, shape.emb_dim)) if output_q6k else None
     names = tensor_names(shape)
-    vocab = vocab_strings(shape.vocab_size)
+    vocab = vocab_strings(shape.vocab_size) if vocab is None else vocab
+    scores = -np.arange(len(vocab), dtype="<f4") if scores is None else np.asarray(scores, "<f4")
     kvs = [
         ("general.architecture", T_STR, b"llama"),
         ("general.name", T_STR, b"synthetic"),
@@ -443,7 +444,7 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
             _w_str(f, s)
         _w_str(f, b"tokenizer.ggml.scores")
         f.write(struct.pack("<IIQ", T_ARR, T_F32, len(vocab)))
-        f.write((-np.arange(len(vocab), dtype="<f4")).tobytes())
+        f.write(scores.tobytes())
         offset = 0
         infos = []
         for name, dims, kind in names:

@@ -181,3 +181,30 @@ def test_ak_requires_tokenizer_and_rejects_garbage(tools, gguf):
     open(bad, "wb").write(struct.pack("<7i", 0, 0, 0, 0, 0, 0, 0))
     r = subprocess.run([tools["llm"], "--ak", "-m", bad, "-s", ak], capture_output=True)
     assert r.returncode != 0 and b"not an ak checkpoint" in r.stdout
+
+
+def test_converter_cli_replaces_load_f90(tools, gguf, tmp_path):
+    """llm.f90_amd/tools/convert.py: GGUF -> "ak" + tokenizer.bin (what the reference's broken load.f90 was for) and
+    GGUF -> q4_0 / f16 GGUF; byte-exact against the library writers, and the q4_0 file loads through the Fortran loader."""
+    import sys
+    s = gguf.SHAPES["tiny-hs64"]
+    src = str(tmp_path / "src.gguf")
+    gguf.write_synth_gguf(src, s, 42)
+    conv = os.path.join(PKG, "tools", "convert.py")
+    ak, tok, q4 = str(tmp_path / "m.ak"), str(tmp_path / "tok.bin"), str(tmp_path / "q4.gguf")
+    r = subprocess.run([sys.executable, conv, src, "--ak", ak, "--tokenizer", tok, "--gguf", q4, "--type", "q4_0"], capture_output=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref_ak, ref_tok = str(tmp_path / "ref.ak"), str(tmp_path / "ref_tok.bin")
+    fw = gguf.synth_fused(s, 42)
+    gguf.write_ak(ref_ak, fw)
+    gguf.write_tokenizer_bin(ref_tok, gguf.vocab_strings(s.vocab_size), -np.arange(s.vocab_size, dtype=np.float32))   # the file's scores
+    assert open(ak, "rb").read() == open(ref_ak, "rb").read()
+    assert open(tok, "rb").read() == open(ref_tok, "rb").read()
+    got = gguf.load_fused(q4)
+    assert got.ggml_type == 2 and np.array_equal(got.w13, gguf.synth_fused(s, 42, 2).w13)
+    out = str(tmp_path / "dump_q4.bin")
+    subprocess.run([tools["dump"], q4, out], capture_output=True, check=True)
+    d = _read_dump(out, gguf)
+    assert d["wtype"] == 2 and np.array_equal(d["wo"].reshape(-1), got.wo.view(np.uint8).reshape(-1))
+    r = subprocess.run([sys.executable, conv, src], capture_output=True)
+    assert r.returncode != 0 and b"nothing to do" in r.stderr
