@@ -6,6 +6,13 @@
 //   2  v_and x2 + 4 v_cvt_pk_f32_fp8 + 4 v_pk_fma_f32
 //   3  3 v_lshrrev + 4 v_and_or (0x4300 | n = bf16 128+n) + 1 v_mfma_f32_16x16x32_bf16
 //   4  8 v_fmac_f32 only      5  8 v_cvt_f32_ubyte only      6  4 v_cvt_pk_f32_fp8 only
+//   7  the MFMA recipe as it would run in the kernel: per 16-byte load (4 dwords) 3 shifts + 4 v_and_or (0x6400 | n =
+//      f16 1024+n) + 4 v_pk_add_f16 (-1032 -> n-8, exact) per dword, 4 chained v_mfma_f32_16x16x32_f16 into one of 8
+//      independent accumulators, then 4 v_fma_mix_f32 (block scales)
+//   8  integer recipe: x held as six signed 4-bit digits per element (block fixed point), weights as signed nibbles
+//      (n ^ 8 = n - 8 in two's complement): per dword 1 v_xor + 6 v_dot8c_i32_i4, per block (4 dwords) 4 v_lshl_add +
+//      2 v_cvt_f32_i32 + 3 f32 ops.  No per-weight conversion at all.
+//   9  6 v_dot8c_i32_i4 only
 // Prints cycles (s_memtime) per dword per wave for 1 and 2 waves per SIMD.
 //   hipcc --offload-arch=gfx950 -O3 q4_alu_probe.hip -o q4_alu_probe && ./q4_alu_probe
 #include <hip/hip_runtime.h>
@@ -15,6 +22,8 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef short bf8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int ITERS = 2000;
 
@@ -31,8 +40,65 @@ __global__ __launch_bounds__(512) void probe(const unsigned* __restrict__ qin, c
     f4 acc = {0.f, 0.f, 0.f, 0.f};
     bf8 bx;
     for (int i = 0; i < 8; ++i) bx[i] = (short)(__float_as_uint(x[i]) >> 16);
+    h8 hx;
+    for (int i = 0; i < 8; ++i) hx[i] = (_Float16)x[i];
+    f4 accs[8];
+    for (int i = 0; i < 8; ++i) accs[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    f4 outv = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
+    if constexpr (V == 8 || V == 9) {
+        int xd[4][6];
+        for (int i = 0; i < 4; ++i) for (int p = 0; p < 6; ++p) xd[i][p] = (int)q[(i + p) & 3] * (p + 3) + i;
+        float facc = 0.f;
+#pragma unroll 1
+        for (int it = 0; it < ITERS; ++it) {
+            int I[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int dw = 0; dw < 4; ++dw) {
+                const int qq = (int)((q[dw] + it) ^ (V == 8 ? 0x88888888u : 0u));
+#pragma unroll
+                for (int p = 0; p < 6; ++p) I[p] = __builtin_amdgcn_sdot8(qq, xd[dw][p], I[p], false);
+            }
+            if constexpr (V == 8) {
+                const int lo_ = I[0] + (I[1] << 4) + (I[2] << 8), hi_ = I[3] + (I[4] << 4) + (I[5] << 8);
+                const float f = fmaf((float)hi_, 4096.0f, (float)lo_);
+                facc = fmaf(f, x[0] * x[1], facc);
+            } else {
+                facc += (float)(I[0] ^ I[1] ^ I[2] ^ I[3] ^ I[4] ^ I[5]);
+            }
+        }
+        acc[0] = facc;
+    } else if constexpr (V == 7) {
+#pragma unroll 1
+        for (int it = 0; it < ITERS / 2; ++it) {
+#pragma unroll
+            for (int ld = 0; ld < 8; ++ld) {           // 8 lane-loads of a tile: 8 independent accumulators
+                f4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dw = 0; dw < 4; ++dw) {
+                    const unsigned qq = q[dw] + it + ld;
+                    unsigned w[4];
+                    w[0] = (qq & 0x000f000fu) | 0x64006400u;
+                    w[1] = ((qq >> 4) & 0x000f000fu) | 0x64006400u;
+                    w[2] = ((qq >> 8) & 0x000f000fu) | 0x64006400u;
+                    w[3] = ((qq >> 12) & 0x000f000fu) | 0x64006400u;
+                    h8 a;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        h2 p = __builtin_bit_cast(h2, w[k]);
+                        p = p - (h2){(_Float16)1032.f, (_Float16)1032.f};
+                        a[2 * k] = p[0]; a[2 * k + 1] = p[1];
+                    }
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(hx, a, d, 0, 0, 0);
+                }
+                const h2 s01 = __builtin_bit_cast(h2, q[0]), s23 = __builtin_bit_cast(h2, q[1]);
+                outv[0] = fmaf((float)s01[0], d[0], outv[0]); outv[1] = fmaf((float)s01[1], d[1], outv[1]);
+                outv[2] = fmaf((float)s23[0], d[2], outv[2]); outv[3] = fmaf((float)s23[1], d[3], outv[3]);
+            }
+        }
+        acc = outv;
+    } else
 #pragma unroll 1
     for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -105,7 +171,8 @@ void run(int threads, const unsigned* q, const float* x, float* out, unsigned lo
     double s = 0;
     for (int i = 0; i < nw; ++i) s += (double)h[i];
     // __builtin_readcyclecounter = s_memtime = shader cycles
-    printf("{\"variant\": %d, \"waves_per_simd\": %d, \"cycles_per_dword\": %.4f}\n", V, threads / 256, s / nw / (ITERS * 4.0));
+    const double ndw = V == 7 ? (ITERS / 2) * 32.0 : ITERS * 4.0;
+    printf("{\"variant\": %d, \"waves_per_simd\": %d, \"cycles_per_dword\": %.4f}\n", V, threads / 256, s / nw / ndw);
     free(h);
 }
 
@@ -115,7 +182,7 @@ int main() {
     hipMemset(q, 0x5a, 512 * 16); hipMemset(x, 0x3c, 512 * 32);
     for (int th : {256, 512}) {
         run<0>(th, q, x, out, cyc); run<1>(th, q, x, out, cyc); run<2>(th, q, x, out, cyc); run<3>(th, q, x, out, cyc);
-        run<4>(th, q, x, out, cyc); run<5>(th, q, x, out, cyc); run<6>(th, q, x, out, cyc);
+        run<4>(th, q, x, out, cyc); run<5>(th, q, x, out, cyc); run<6>(th, q, x, out, cyc); run<7>(th, q, x, out, cyc); run<8>(th, q, x, out, cyc); run<9>(th, q, x, out, cyc);
     }
     return 0;
 }
