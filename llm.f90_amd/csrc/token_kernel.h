@@ -103,6 +103,12 @@ struct TkShape {
     static constexpr int NBLK_E = E / 32, NBLK_H = H / 32;               // q4_0 blocks per row
     static constexpr int NBP_E = NBLK_E + 1, NBP_H = NBLK_H + 1;         // q4_0: pitch (in float4) of the transposed x image in LDS
     static constexpr int NB = Q4 ? 3 : 5;                                // ring depth (q4_0: 4 would spill, 237 VGPRs at 3)
+    // COOP (q4_0): all eight waves gather the phase's input vector, one eighth each, and the tiles are requested from
+    // inside the dot products (tk_step).  The dequantise-and-dot of a q4_0 tile takes 1.9 us, so the loads' issue hides
+    // behind ALU work instead of behind the exchange, and a wave that polls right after its phase has almost nothing of
+    // its own queued ahead of the poll -- the reason the f32 / f16 kernels keep a wave that never streams (section 3b of
+    // DESIGN.md) does not apply, and an 88 KB sweep by one wave was 7.3 us per layer.
+    static constexpr bool COOP = Q4;
     static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
     static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
     // rows per CU and tiles per CU for each phase
@@ -152,6 +158,7 @@ struct TkLds {
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
     static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
     static constexpr int ATT_R4 = ATT_RED + TK_WAVES * (256 / SH::HS) * SH::HS * 4;   // [waves][TPW][HS/4] float4
+    static constexpr int RED8 = ATT_R4;                                    // COOP: the eight waves' partial sums of x^2 (32 of the 64 bytes)
     static constexpr int ROPE = ATT_R4 + 64;                               // cos[HS/2] | sin[HS/2] of pos*freq
     static constexpr int ATT_P = ROPE + SH::HS * 4;                        // [waves][32] softmax weights of the wave's own timesteps
     static constexpr int ATT_S = ATT_P + TK_WAVES * 32 * 4;                // scores [S], then exp(score - max) [S]
@@ -251,6 +258,82 @@ __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned 
         const bool c = tk_gather_part<Q2, NBP>(rs, 2 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
         return a && b && c;
     }
+}
+
+// ---- cooperative gather (TkShape::COOP): wave w of 8 takes a contiguous eighth of the vector's 16-byte loads ----------
+// NLW loads per lane, all in flight per pass.  Values reach LDS only once the whole slice carries the epoch: a slice that
+// holds this CU's OWN rows cannot complete before the service wave has published them, i.e. after its epilogue has read
+// xraw -- so a wave may start on the next vector while the epilogue of the previous phase still runs.
+//   xraw (optional) <- x;  xs <- x * gains (NORM) or x;  *ss += sum x^2 (NORM)
+template <int NLW, int NBP, bool NORM>
+__device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
+                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait) {
+    if constexpr (NLW == 0) return true;
+    else {
+        float2 gn[NORM ? NLW : 1];
+        if constexpr (NORM) {
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) gn[k] = *reinterpret_cast<const float2*>(gains + 2 * (first_pair + lane + k * WAVE));
+        }
+        const int e0 = 2 * (first_pair + lane);
+        const int d0 = tk_xoff<NBP>(e0);
+        for (unsigned spin = 0;; ++spin) {
+            tk_v4u r[NLW];
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
+            if (__all(ok) || nowait) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NLW; ++k) {
+                    const float x0 = __uint_as_float(r[k].x), x1 = __uint_as_float(r[k].z);
+                    if (xraw) *reinterpret_cast<float2*>(xraw + e0 + k * 2 * WAVE) = make_float2(x0, x1);
+                    if constexpr (NORM) {
+                        acc = fmaf(x0, x0, acc);
+                        acc = fmaf(x1, x1, acc);
+                        *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0 * gn[k].x, x1 * gn[k].y);
+                    } else {
+                        *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0, x1);
+                    }
+                }
+                if constexpr (NORM) *ss += acc;
+                return true;
+            }
+            if ((spin & 63) == 63) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+                if (spin > TK_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(err, 0x400u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return false;
+                }
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+// wave w (0..7) of the workgroup; red8[w] receives the slice's sum of squares when NORM
+template <int N, int NBP, bool NORM>
+__device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsigned epoch, float* xraw, float* xs, const float* gains,
+                                               float* red8, unsigned* err, int w, int lane, bool nowait) {
+    static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
+    constexpr int NL = N / 128, B = NL / TK_WAVES, X = NL % TK_WAVES;      // waves < X take B + 1 loads per lane, the others B
+    const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
+    float ss = 0.f;
+    bool ok;
+    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
+    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
+    if constexpr (NORM) {
+        ss = wave_sum(ss);
+        if (lane == 0) red8[w] = ss;
+    }
+    return ok;
+}
+// the eight partial sums -> sqrt(mean(x^2) + eps)                                                    llama2.f90:454
+template <int E>
+__device__ __forceinline__ float tk_coop_xn(const float* red8, float eps) {
+    const float ss = ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
+    return sqrtf(ss / (float)E + eps);
 }
 
 // rmsnorm on one wave, lane <-> 4 consecutive elements per 256: the gains are requested (plain
@@ -717,6 +800,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     const float* part = reinterpret_cast<const float*>(lds + LD::PART);
     // q4_0: the streaming input is staged transposed (TkLds); 0 = natural order
     constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
+    float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
     const int L = a.L;
     const int tok = a.tokpos ? a.tokpos[0] : a.tok_imm, pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
@@ -743,19 +827,23 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
         TkNorm<SH::E> nrm;
-        if (!att_cu) nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
+        const bool coop0 = SH::COOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
+        if (!att_cu && !coop0) nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
         float xn_att = 1.f;
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
-            if (l == 0) {
+            if (coop0) {
+                ok = tk_coop_gather<SH::E, TR_E, true>(a.g_x, e_q - 1, xraw, xs, a.rms_att + (size_t)l * SH::E, red8, a.err, TK_NS, lane, nosync) && ok;
+            } else if (l == 0) {
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
             } else {
                 ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
             }
             TK_STAMP(1);
-            xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
+            if (!coop0) xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
         }
         tk_barrier();
+        if (coop0 && !att_cu) xn_att = tk_coop_xn<SH::E>(red8, a.eps);
         TK_STAMP(2);
         tk_barrier();
         TK_STAMP(3);
@@ -829,7 +917,11 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        if (!att_cu) ok = tk_gather<SH::E, TR_E, 32>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        if constexpr (SH::COOP) {
+            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(a.g_xb, e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+        } else {
+            if (!att_cu) ok = tk_gather<SH::E, TR_E, 32>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+        }
         TK_STAMP(7);
         tk_barrier();
         tk_barrier();
@@ -840,11 +932,19 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_xa + r, e_o, xraw[r] + v);
         }
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
-        nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
-        ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
-        TK_STAMP(9);
-        const float xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
-        tk_barrier();
+        float xn_ffn;
+        if constexpr (SH::COOP) {
+            ok = tk_coop_gather<SH::E, TR_E, true>(a.g_xa, e_o, xraw, xs, a.rms_ffn + (size_t)l * SH::E, red8, a.err, TK_NS, lane, nosync) && ok;
+            TK_STAMP(9);
+            tk_barrier();
+            xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
+        } else {
+            nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
+            ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+            TK_STAMP(9);
+            xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
+            tk_barrier();
+        }
         TK_STAMP(10);
         tk_barrier();
         TK_STAMP(11);
@@ -856,7 +956,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        ok = tk_gather<SH::H, TR_H, 32>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        if constexpr (SH::COOP) ok = tk_coop_gather<SH::H, TR_H, false>(a.g_hb, e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+        else ok = tk_gather<SH::H, TR_H, 32>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -873,11 +974,18 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     }
 #undef TK_STAMP
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
-    TkNorm<SH::E> nrmf;
-    nrmf.prefetch(a.rms_final, lane);
-    ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
-    const float xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane, a.eps);
-    tk_barrier();
+    float xn_fin;
+    if constexpr (SH::COOP) {
+        ok = tk_coop_gather<SH::E, TR_E, true>(a.g_x, ebase + 5u * L, xraw, xs, a.rms_final, red8, a.err, TK_NS, lane, nosync) && ok;
+        tk_barrier();
+        xn_fin = tk_coop_xn<SH::E>(red8, a.eps);
+    } else {
+        TkNorm<SH::E> nrmf;
+        nrmf.prefetch(a.rms_final, lane);
+        ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
+        xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane, a.eps);
+        tk_barrier();
+    }
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
     for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = part[j] / xn_fin;
@@ -964,6 +1072,96 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
     tk_refill<SH, K0 + EARLY, LATE, CLS>(r, a, l, c, sw, lane);
 }
 
+// COOP: "lagged refill".  Slot K consumes ring entry K % NB and, INSIDE its ALU work, requests tile K + NB - 1 into the
+// entry slot K - 1 has just freed: one half of the loads after the first two rows' dots, the other half after the last
+// two.  Issuing a load blocks while the CU's memory pipeline is full; spread through 1.9 us of dequantise-and-dot it never
+// does, there is no refill burst anywhere (the f32 / f16 kernels place theirs behind the exchange instead, section 3b), and
+// a wave that polls after its phase has at most one tile of its own in flight.  Prefetch distance NB - 1 = 2 tiles.
+template <class SH, int K, bool CLS>
+__device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
+    static_assert(SH::Q4 && SH::RPT == 4 && SH::LPT == 2, "written for the q4_0 tile (4 rows x 2 segments)");
+    constexpr int R = K % SH::NB, RN = (K + SH::NB - 1) % SH::NB;
+    const TkSlot<SH>& e = r.b[R];
+    TkTile tn;
+    if constexpr (CLS) tn = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
+    else tn = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
+    TkSlot<SH>& n = r.b[RN];
+    float v[4];
+    auto row = [&](int s_) {
+        float acc = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const float4& w = e.b[s_ * 2 + jj];
+            const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+            float tl = 0.f, th = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
+            const float t = fmaf(th, 0.0625f, tl);
+            const unsigned short hs = e.sc[s_ * 2 + jj];
+            const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
+            acc = fmaf(d, t - x.xs8[jj], acc);
+        }
+        return acc;
+    };
+    v[0] = row(0);
+    v[1] = row(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TK_TCOLS; ++j) {          // the tile's 8 nibble vectors
+        const int s_ = j / SH::LPT, jj = j % SH::LPT;
+        const bool real = jj < tn.ncol;
+        const float4* pj = real ? tn.p + s_ * tn.rstride + jj * WAVE : a.zeros;
+        n.b[j] = ldg_nt(pj + (real ? lane : 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    v[2] = row(2);
+    v[3] = row(3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < TK_TCOLS; ++j) {          // ... and its 8 block scales
+        const int s_ = j / SH::LPT, jj = j % SH::LPT;
+        const bool real = jj < tn.ncol;
+        const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(tn.p + s_ * tn.rstride) + tn.soff) + jj * WAVE
+                                        : reinterpret_cast<const unsigned short*>(a.zeros);
+        n.sc[j] = __builtin_nontemporal_load(pj + (real ? lane : 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) v[s_] = wave_sum(v[s_]);
+    const TkTile& t = r.t[R];
+    if (lane == 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) part[t.pidx + s_ * t.pstep] = v[s_];
+    }
+    r.t[RN] = tn;
+}
+template <class SH, int K, int N, bool CLS>
+__device__ __forceinline__ void tk_steps(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
+    if constexpr (N > 0) {
+        tk_step<SH, K, CLS>(r, a, l, c, sw, x, part, lane);
+        tk_steps<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, x, part, lane);
+    }
+}
+template <class SH, int K0, int S, bool CLS, bool WIDE = false>
+__device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
+                                              float* part, int lane) {
+    tk_barrier();
+    TkX<SH> x;
+    if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
+    else x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
+    tk_steps<SH, K0, S, CLS>(r, a, l, c, sw, x, part, lane);
+    tk_barrier();
+}
+// the ring starts with tiles 0 .. NB-2 requested; slot 0 requests tile NB-1
+template <class SH, int K>
+__device__ __forceinline__ void tk_prime_coop(TkRing<SH>& r, const TokenArgs& a, int c, int sw, int lane) {
+    if constexpr (K < SH::NB - 1) {
+        r.t[K] = tk_at<SH, K>(a, 0, c, sw);
+        tk_issue<SH>(r.b[K], r.t[K], a.zeros, lane);
+        tk_prime_coop<SH, K + 1>(r, a, c, sw, lane);
+    }
+}
+
 template <class SH, int K>
 __device__ __forceinline__ void tk_prime(TkRing<SH>& r, const TokenArgs& a, int c, int sw, int lane) {
     if constexpr (K < SH::NB) {
@@ -1018,6 +1216,56 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
+// STREAMING wave of a COOP shape (q4_0): the same static tile list with lagged refills (tk_step), and this wave (sw = 0..6;
+// the service wave is slice 7) gathers its eighth of each phase's input vector right after the phase before it.  Vector and
+// epoch of every gather mirror tk_service.
+template <class SH>
+__device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, int c, int sw, int lane, int tid) {
+    typedef TkLds<SH> LD;
+    typedef TkSched<SH> SC;
+    float* xs = reinterpret_cast<float*>(lds + LD::XS);
+    float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
+    const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
+    float* part = reinterpret_cast<float*>(lds + LD::PART);
+    float* red8 = reinterpret_cast<float*>(lds + LD::RED8);
+    constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
+    const int L = a.L;
+    const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
+    const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
+    const bool nosync = TK_DEBUG && a.nosync != 0;
+    constexpr int HPC = TK_NCU / SH::NH;
+    const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
+    const int my_head = c / HPC;
+
+    TkRing<SH> r;
+    tk_prime_coop<SH, 0>(r, a, c, sw, lane);
+
+    for (int l = 0; l < L; ++l) {
+        const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
+        // QKV phase (its input was gathered at the end of the previous layer; layer 0: the service wave stages the embedding row)
+        tk_phase_body<SH, SC::KQ, SH::SL_Q, false>(r, a, l, c, sw, xs4, part, lane);
+        if (att_cu) {
+            TkAtt<SH> pa;
+            pa.prefetch(a, l, my_head, pos, tid);
+            tk_barrier();
+            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
+            tk_barrier();
+        }
+        if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(a.g_xb, e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        tk_phase_body<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
+        tk_coop_gather<SH::E, TR_E, true>(a.g_xa, e_o, xraw, xs, a.rms_ffn + (size_t)l * SH::E, red8, a.err, sw, lane, nosync);
+        tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
+        tk_coop_gather<SH::H, TR_H, false>(a.g_hb, e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);
+        if (l + 1 < L) {
+            if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(a.g_x, e_d, xraw, xs, a.rms_att + (size_t)(l + 1) * SH::E, red8, a.err, sw, lane, nosync);
+        } else {
+            tk_coop_gather<SH::E, TR_E, true>(a.g_x, e_d, xraw, xs, a.rms_final, red8, a.err, sw, lane, nosync);
+        }
+    }
+    tk_phase_body<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
+}
+
 template <class SH>
 __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1039,6 +1287,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         a.c0 = SH::RPT * (c * SH::CB + min(c, SH::CX));
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH>(a, lds, c, lane, tid); }
+    else if constexpr (SH::COOP) tk_stream_coop<SH>(a, lds, c, wid, lane, tid);
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }
 
