@@ -195,8 +195,9 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
 
 def prefill_line(a):
     """`--prefill N`: prompt tokens/s of llmk_prefill (batched MFMA GEMMs) next to the token-by-token loop it replaces.
-    Roofline of its dominant kernel, the w1|w3 GEMM at 64 positions: f32 matrix-core peak (157.3 TFLOP/s,
-    MI355X_MICROARCH.md) -- at 64 positions per pass the GEMM is MFMA-bound (2*64 flop per 4-byte weight = 32 flop/B)."""
+    Roofline of its dominant kernel, the w1|w3 GEMM at 128 positions: f32 matrix-core peak (157.3 TFLOP/s,
+    MI355X_MICROARCH.md) -- at 128 positions per pass the GEMM is MFMA-bound (2*128 flop per 4-byte weight = 64 flop/B:
+    the matrix rate needs 2.5 TB/s of weights)."""
     shape = gguf.SHAPES[a.shape]
     n = a.prefill
     if a.type != "f32" or n < 1 or n + 1 > shape.seq_len:
@@ -218,13 +219,13 @@ def prefill_line(a):
         m.forward(prompt[pos - 1], pos)
     dt_seq = (time.perf_counter() - t0) / nseq
     ms, wbytes = m.time_kernel(7, 66)
-    flop = 2.0 * 64 * wbytes / 4.0
+    flop = 2.0 * 128 * wbytes / 4.0
     out = {"metric": f"prompt tokens/sec {a.shape} prefill", "value": n / dt, "unit": "tokens/s", "n_gpus": 1,
            "steps": reps, "warmup": max(1, a.warmup // 4), "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"{a.shape} f32 prefill of a {n}-token prompt (llmk_prefill, 64 positions per pass)",
+           "config": {"workload": f"{a.shape} f32 prefill of a {n}-token prompt (llmk_prefill, 128 positions per pass)",
                       "token_by_token_tok_s": 1.0 / dt_seq, "speedup": (n / dt) * dt_seq, "seed": SEED},
-           "roofline": {"bound": "mfma", "kernel": "pf_gemm_kernel<4> (w1|w3, 64 positions, v_mfma_f32_16x16x4_f32)",
+           "roofline": {"bound": "mfma", "kernel": "pf_gemm_kernel<8> (w1|w3, 128 positions, v_mfma_f32_16x16x4_f32)",
                         "achieved": flop / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "us_per_launch": ms * 1000.0,
                         "flop_per_launch": flop, "weight_bytes_per_launch": wbytes,

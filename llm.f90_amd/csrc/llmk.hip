@@ -20,6 +20,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <vector>
 
 #include <math.h>
 #include <stdio.h>
@@ -542,16 +543,30 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
 }
 
 // ---- batched prefill (prefill.h) ------------------------------------------------------------------------
-// K slices of a GEMM: enough (64-row strip x slice) blocks for >= 2 per CU, slices whole multiples of PF_KSTEP columns
+// q4_0 GEMM: K slices -- enough (64-row strip x slice) blocks for >= 2 per CU, slices whole multiples of the step
 void pf_split(const llmk_ctx* c, int rows, int K, int* ks_out, int* kslice_out) {
     const int strips = (rows + 63) / 64;
-    const int step = c->cfg.weight_type == LLMK_TYPE_Q4_0 ? PF_KSTEP_Q4 : PF_KSTEP;
+    const int step = PF_KSTEP_Q4;
     int ks = (2 * c->n_cu + strips - 1) / strips;
     int kslice = ((K + ks - 1) / ks + step - 1) / step * step;
     if (kslice < 2 * step) kslice = 2 * step;
     *kslice_out = kslice;
     *ks_out = (K + kslice - 1) / kslice;
 }
+// f32 / f16 GEMM: units per block and workgroups per CU (prefill.h PfGemmArgs).  Two workgroups per CU overlap one's
+// barrier with the other's MFMAs; one per CU is taken when it divides the units much more evenly.
+struct PfPlan { int nk, total, U, grid, per_cu; };
+PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
+    PfPlan p;
+    p.nk = K / PF_KSTEP;
+    p.total = (rows + 63) / 64 * p.nk;
+    auto eff = [&](int nb) { const int U = (p.total + nb - 1) / nb; return (double)p.total / ((double)U * nb); };
+    p.per_cu = eff(c->n_cu) > eff(2 * c->n_cu) + 0.08 ? 1 : 2;
+    p.U = (p.total + p.per_cu * c->n_cu - 1) / (p.per_cu * c->n_cu);
+    p.grid = (p.total + p.U - 1) / p.U;
+    return p;
+}
+int pf_max_slots(const PfPlan& p) { return (p.nk - 1) / p.U + 2; }
 int pf_setup(llmk_ctx* c) {
     if (c->pf_X) return LLMK_OK;
     const size_t T = PF_TMAX;
@@ -559,9 +574,13 @@ int pf_setup(llmk_ctx* c) {
     size_t pcap = 0;
     const int Ks[4] = {c->E, c->E, c->E, c->H};
     for (int i = 0; i < 4; ++i) {
-        int ks, kslice;
-        pf_split(c, rows[i], Ks[i], &ks, &kslice);
-        pcap = std::max(pcap, (size_t)ks * T * rows[i]);
+        if (c->cfg.weight_type == LLMK_TYPE_Q4_0) {
+            int ks, kslice;
+            pf_split(c, rows[i], Ks[i], &ks, &kslice);
+            pcap = std::max(pcap, (size_t)ks * T * rows[i]);
+        } else {
+            pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
+        }
     }
     HIPCHK(hipMalloc(&c->pf_X, T * c->E * sizeof(float)));
     HIPCHK(hipMalloc(&c->pf_Xs, T * c->E * sizeof(float)));
@@ -570,64 +589,79 @@ int pf_setup(llmk_ctx* c) {
     HIPCHK(hipMalloc(&c->pf_HB, T * c->H * sizeof(float)));
     HIPCHK(hipMalloc(&c->pf_P, pcap * sizeof(float)));
     HIPCHK(hipMalloc(&c->pf_xn, T * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_tok, T * sizeof(int)));
+    HIPCHK(hipMalloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
     return LLMK_OK;
 }
-// P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; returns KS through *ks_out
-// q4_0: W = nibble plane of the layer, Wsc = its scale plane
-hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, int* ks_out) {
-    PfGemmQ4Args a;
-    a.W = (const char*)W; a.RS = row_stride; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
+// P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; the epilogue's partial count goes to e->KS
+// q4_0: rows of nibbles + scales (row_stride bytes apart); a pass of more than 64 positions is two launches
+hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
     int ks, kslice;
     pf_split(c, rows, K, &ks, &kslice);
-    a.kslice = kslice;
-    *ks_out = ks;
-    const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
-    const int NG = (T + 15) / 16;
-    const size_t smem = (size_t)2 * NG * 16 * PF_LDW_Q4 * sizeof(float);
+    e->KS = ks; e->U = 0; e->nk = 0;
+    const int Tp = (T + 15) / 16 * 16;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        PfGemmQ4Args a;
+        a.W = (const char*)W; a.RS = row_stride; a.X = X + (size_t)t0 * K; a.P = c->pf_P + (size_t)t0 * rows;
+        a.rows = rows; a.K = K; a.T = std::min(64, T - t0); a.Tp = Tp; a.kslice = kslice;
+        const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
+        const int NG = (a.T + 15) / 16;
+        const size_t smem = (size_t)2 * NG * 16 * PF_LDW_Q4 * sizeof(float);
 #define PFQ(NG_)                                                                                                              \
     do {                                                                                                                      \
         HIPRET(hipFuncSetAttribute((const void*)pf_gemm_q4_kernel<NG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(pf_gemm_q4_kernel<NG_>, grid, block, smem, c->stream, a);                                          \
     } while (0)
-    switch (NG) {
-        case 1: PFQ(1); break;
-        case 2: PFQ(2); break;
-        case 3: PFQ(3); break;
-        default: PFQ(4); break;
-    }
+        switch (NG) {
+            case 1: PFQ(1); break;
+            case 2: PFQ(2); break;
+            case 3: PFQ(3); break;
+            default: PFQ(4); break;
+        }
 #undef PFQ
+        HIPRET(hipGetLastError());
+    }
+    return hipSuccess;
+}
+template <int NG>
+hipError_t pf_gemm_launch(llmk_ctx* c, const PfGemmArgs& a, const PfPlan& p) {
+    // the LDS request pins the workgroups per CU (160 KB per CU): every CU gets the same number of equal blocks
+    const size_t need = (size_t)2 * NG * 16 * PF_LDW * sizeof(float);
+    const size_t smem = std::max(need, p.per_cu == 1 ? (size_t)84 * 1024 : (size_t)56 * 1024);
+    const dim3 grid(p.grid), block(PF_WAVES * WAVE);
+    if (c->cfg.weight_type == LLMK_TYPE_F16) {
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16>), grid, block, smem, c->stream, a);
+    } else {
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32>), grid, block, smem, c->stream, a);
+    }
     return hipGetLastError();
 }
-hipError_t pf_gemm(llmk_ctx* c, const void* W, const float* X, int rows, int K, int T, int* ks_out) {
+hipError_t pf_gemm(llmk_ctx* c, const void* W, const float* X, int rows, int K, int T, PfEpiArgs* e) {
+    const PfPlan p = pf_plan(c, rows, K);
     PfGemmArgs a;
     a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
-    int ks, kslice;
-    pf_split(c, rows, K, &ks, &kslice);
-    a.kslice = kslice;
-    *ks_out = ks;
-    const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
-#define PF_LAUNCH(NG_)                                                                                     \
-    do {                                                                                                   \
-        if (c->cfg.weight_type == LLMK_TYPE_F16)                                                           \
-            hipLaunchKernelGGL((pf_gemm_kernel<NG_, WT_F16>), grid, block, 0, c->stream, a);                \
-        else                                                                                               \
-            hipLaunchKernelGGL((pf_gemm_kernel<NG_, WT_F32>), grid, block, 0, c->stream, a);                \
-    } while (0)
+    a.nk = p.nk; a.U = p.U; a.total = p.total;
+#ifdef LLMK_PF_TRACE
+    a.trace = (unsigned long long*)c->pf_HB;     // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
+#endif
+    e->KS = 0; e->U = p.U; e->nk = p.nk;
     switch ((T + 15) / 16) {
-        case 1: PF_LAUNCH(1); break;
-        case 2: PF_LAUNCH(2); break;
-        case 3: PF_LAUNCH(3); break;
-        default: PF_LAUNCH(4); break;
+        case 1: return pf_gemm_launch<1>(c, a, p);
+        case 2: return pf_gemm_launch<2>(c, a, p);
+        case 3: return pf_gemm_launch<3>(c, a, p);
+        case 4: return pf_gemm_launch<4>(c, a, p);
+        case 5: return pf_gemm_launch<5>(c, a, p);
+        case 6: return pf_gemm_launch<6>(c, a, p);
+        case 7: return pf_gemm_launch<7>(c, a, p);
+        default: return pf_gemm_launch<8>(c, a, p);
     }
-#undef PF_LAUNCH
-    return hipGetLastError();
 }
 // one batch of T <= PF_TMAX prompt positions pos0 .. pos0+T-1 (1-based) through all layers; X[T-1] ends up in d_x
-hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
+hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
     const int E = c->E, H = c->H, KV = c->KV, QKV = E + 2 * KV, Tp = (T + 15) / 16 * 16;
     const float* emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
-    hipLaunchKernelGGL(pf_embed_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, emb, c->pf_tok, c->pf_X, E);
+    hipLaunchKernelGGL(pf_embed_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, emb, tok, c->pf_X, E);
     HIPRET(hipGetLastError());
     PfEpiArgs e;
     memset(&e, 0, sizeof(e));
@@ -635,12 +669,12 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
     e.E = E; e.KV = KV; e.hs = c->hs; e.H = H;
     for (int l = 0; l < c->L; ++l) {
         // layer l of tensor tid: data plane (and the q4_0 scale plane), rows_per_layer rows
-        auto gemm = [&](int tid, int rows_per_layer, const float* X, int K, int* ks) -> hipError_t {
+        auto gemm = [&](int tid, int rows_per_layer, const float* X, int K) -> hipError_t {
             const DevTensor& dt = c->t[tid];
             const char* w = (const char*)dt.data + (size_t)l * rows_per_layer * dt.row_bytes;
             if (c->cfg.weight_type == LLMK_TYPE_Q4_0)
-                return pf_gemm_q4(c, w, (int)dt.row_bytes, X, rows_per_layer, K, T, ks);
-            return pf_gemm(c, w, X, rows_per_layer, K, T, ks);
+                return pf_gemm_q4(c, w, (int)dt.row_bytes, X, rows_per_layer, K, T, &e);
+            return pf_gemm(c, w, X, rows_per_layer, K, T, &e);
         };
         float* kc = c->d_kc + (size_t)l * c->S * KV;
         float* vc = c->d_vc + (size_t)l * c->S * KV;
@@ -648,7 +682,7 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
         hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
                            (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E, c->eps);
         HIPRET(hipGetLastError());
-        HIPRET(gemm(LLMK_WQKV, QKV, c->pf_Xs, E, &e.KS));
+        HIPRET(gemm(LLMK_WQKV, QKV, c->pf_Xs, E));
         e.rows = QKV; e.out = c->pf_Q; e.kc = kc; e.vc = vc;
         hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
@@ -667,7 +701,7 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
 #undef ATT
         HIPRET(hipGetLastError());
         // x += wo . xb                                                                    :603-605
-        HIPRET(gemm(LLMK_WO, E, c->pf_XB, E, &e.KS));
+        HIPRET(gemm(LLMK_WO, E, c->pf_XB, E));
         e.rows = E; e.out = c->pf_X;
         hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
@@ -675,12 +709,12 @@ hipError_t pf_batch(llmk_ctx* c, int T, int pos0) {
         hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
                            (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E, c->eps);
         HIPRET(hipGetLastError());
-        HIPRET(gemm(LLMK_W13, 2 * H, c->pf_Xs, E, &e.KS));
+        HIPRET(gemm(LLMK_W13, 2 * H, c->pf_Xs, E));
         e.rows = 2 * H; e.out = c->pf_HB;
         hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
         // x += w2 . hb                                                                    :618-620
-        HIPRET(gemm(LLMK_W2, E, c->pf_HB, H, &e.KS));
+        HIPRET(gemm(LLMK_W2, E, c->pf_HB, H));
         e.rows = E; e.out = c->pf_X;
         hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
@@ -1034,14 +1068,10 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     HIPCHK(hipSetDevice(c->cfg.device));
     rc = pf_setup(c);
     if (rc) return rc;
-    int tok0[PF_TMAX];
-    for (int i = 0; i < n; i += PF_TMAX) {
-        const int T = n - i < PF_TMAX ? n - i : PF_TMAX;
-        for (int j = 0; j < T; ++j) tok0[j] = tokens[i + j] - 1;
-        HIPCHK(hipMemcpyAsync(c->pf_tok, tok0, T * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));   // tok0 is reused by the next batch
-        HIPCHK(pf_batch(c, T, pos0 + i));
-    }
+    std::vector<int> tok0(tokens, tokens + n);
+    for (int& t : tok0) --t;
+    HIPCHK(hipMemcpyAsync(c->pf_tok, tok0.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < n; i += PF_TMAX) HIPCHK(pf_batch(c, c->pf_tok + i, std::min(PF_TMAX, n - i), pos0 + i));
     HIPCHK(launch_cls(c));                          // final rmsnorm + classifier of the last position   :627-636
     HIPCHK(hipMemcpyAsync(c->h_logits, c->d_logits, (size_t)c->V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1095,14 +1125,17 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     if (c->h_tokpos[1] < 1) { c->h_tokpos[0] = 0; c->h_tokpos[1] = 1; }
     HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
     auto one = [&](int i) -> hipError_t {
-        const int l = i % c->L;
+        int l = i % c->L;
+#ifdef LLMK_PF_TRACE
+        if (getenv("LLMK_PF_ONE_LAYER")) l = 0;      // debug build: weights from the Infinity Cache instead of HBM
+#endif
         if (kernel == 6) {  // whole-token kernel: fresh exchange epochs for every launch
             hipLaunchKernelGGL(bump_serial_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tokpos);
             return launch_token_kernel(c);
         }
         if (kernel == 7) {
-            int ks;
-            return pf_gemm(c, (const char*)c->t[LLMK_W13].data + (size_t)l * 2 * c->H * c->t[LLMK_W13].row_bytes, c->pf_Xs, 2 * c->H, c->E, PF_TMAX, &ks);
+            PfEpiArgs e;
+            return pf_gemm(c, (const char*)c->t[LLMK_W13].data + (size_t)l * 2 * c->H * c->t[LLMK_W13].row_bytes, c->pf_Xs, 2 * c->H, c->E, PF_TMAX, &e);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);
@@ -1159,6 +1192,9 @@ int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
             src = (which == 4 ? c->d_kc : c->d_vc) + ((size_t)layer * c->S + (pos - 1)) * c->KVl;
             len = c->KVl;
             break;
+#ifdef LLMK_PF_TRACE
+        case 7: src = c->pf_HB; len = PF_TMAX * c->H; break;
+#endif
         case 6:  // debug: raw trace stamps reinterpret as floats (2 per stamp)
             if (!c->d_trace) return LLMK_E_ARG;
             src = (const float*)c->d_trace; len = TK_NCU * TK_TRACE_N * 2;

@@ -9,13 +9,13 @@
 // X[T][K] . W[rows][K]^T has 2*T flop per weight word.  v_mfma_f32_16x16x4_f32 keeps full f32 operands
 // (parity bar: 1e-4 relative on logits), 256 flop/clk/CU.
 //
-// pf_gemm: grid (ceil(rows/64), KS), 4 waves per block; wave w owns weight rows row0+16w .. +15 for the block's K
-// slice, all four share the slice's activations through LDS (64 tokens x 64 columns per step, double-buffered), so
-// a block reads as many activation bytes from L2 as weight bytes from HBM (one strip per block would read 4x).
+// pf_gemm: 4 waves per block; wave w owns weight rows strip*64+16w .. +15 of the block's units, all four share the
+// units' activations through LDS (up to 128 tokens x 64 columns per step, double-buffered).
 // Lane l holds W[row + l%16][k + 4*(l/16) .. +3] (16 bytes; the 4 lanes of a row cover one 64-byte line) and, per
 // 16-token group, X[t0 + l%16][same columns]: MFMA step j multiplies component j of both -- k is a summation
-// index, so any lane->k assignment is valid as long as A and B agree.  Loads run one 64-column step ahead of the MFMAs.  Each block writes ONE partial tile P[ks][t][row]; the epilogue kernel adds the KS partials in
-// order (deterministic) and applies the fused tail (RoPE + KV write / residual / SwiGLU).
+// index, so any lane->k assignment is valid as long as A and B agree.  Weight loads run two 64-column steps ahead of the
+// MFMAs.  Each block writes one partial tile P[slot][t][row] per strip it touches; the epilogue kernel adds a strip's
+// partials in slot order (deterministic) and applies the fused tail (RoPE + KV write / residual / SwiGLU).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,21 +23,45 @@
 
 namespace llmk {
 
-constexpr int PF_TMAX = 64;          // prompt positions per pass (4 MFMA token groups)
+constexpr int PF_TMAX = 128;         // prompt positions per pass (8 MFMA token groups)
 constexpr int PF_WAVES = 4;
 
 typedef float pf_v4f __attribute__((ext_vector_type(4)));
 
+// Work of one GEMM = strips (64 weight rows) x nk (64-column steps) UNITS, strip-major.  Block b owns the U consecutive
+// units [b*U, (b+1)*U): every block multiplies the same number of 64x64 weight tiles whatever rows/K are, and the grid is
+// the number of workgroups the chip holds at once (1 or 2 per CU, pinned by the LDS request) -- with a strips x slices
+// grid the 528 / 880 blocks of the w1|w3 GEMM left 16 / 112 CUs with one block more than the others and the kernel
+// waited 1.5x the median block for them (profiles/README.md, round 2).  A block whose range crosses a strip boundary
+// writes one partial tile per strip it touches: partial `slot` of strip s comes from block floor(s*nk/U) + slot.
 struct PfGemmArgs {
     const void* W;       // [rows][K]  f32 or f16 (template parameter WT)
     const float* X;      // [T][K]   (activations, L2-resident)
-    float* P;            // [KS][Tp][rows] partial sums, Tp = 16*NG
+    float* P;            // [slots][Tp][rows] partial sums, Tp = 16*NG
     int rows, K, T;
-    int kslice;          // columns per K slice (multiple of PF_KSTEP)
+    int nk;              // 64-column steps per strip = K / PF_KSTEP
+    int U;               // units per block
+    int total;           // strips * nk
+#ifdef LLMK_PF_TRACE
+    unsigned long long* trace;   // [grid][20] wall-clock stamps: entry, prologue done, end of steps 0..15, exit
+#endif
 };
 
 constexpr int PF_KSTEP = 64;                 // columns per pipeline step (4 MFMA chunks of 16)
 constexpr int PF_LDW = PF_KSTEP + 4;         // LDS row pitch in floats (+16 bytes: the 16 tokens of a read spread over banks)
+
+__host__ __device__ inline int pf_first_block(int strip, int nk, int U) { return strip * nk / U; }
+__host__ __device__ inline int pf_nslots(int strip, int nk, int U) { return ((strip + 1) * nk - 1) / U - strip * nk / U + 1; }
+
+// write the wave's partial tile (D layout of 16x16x4: lane l, register v <-> weight row 4*(l/16)+v, token l%16) and clear it
+template <int NG>
+__device__ __forceinline__ void pf_flush(pf_v4f (&acc)[NG], bool active, float* dst, int rows) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (active) *reinterpret_cast<float4*>(dst + (size_t)g * 16 * rows) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
+        acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+    }
+}
 
 // f16 weights: a lane's 16 bytes are 8 columns, so a chunk is 32 columns (8 MFMA steps after the exact half -> float
 // conversion) and a 64-column step has two chunks; the activation side is f32 either way.
@@ -48,14 +72,19 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     constexpr int CPL = 16 / BW;                          // columns per lane load: 4 / 8
     constexpr int CW = 4 * CPL;                           // columns per chunk (4 lane groups): 16 / 32
     constexpr int NJ = PF_KSTEP / CW;                     // chunks per step: 4 / 2
-    __shared__ __attribute__((aligned(16))) float xs[2][TP][PF_LDW];
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    float* xs = reinterpret_cast<float*>(pf_smem);        // [2][TP][PF_LDW]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int row0 = blockIdx.x * 64 + wid * 16, ks = blockIdx.y;
-    const int kb = ks * a.kslice, ke = min(a.K, kb + a.kslice);
-    const int nsteps = (ke - kb) / PF_KSTEP;
+    const int u0 = blockIdx.x * a.U, nsteps = min(a.U, a.total - u0);
+    if (nsteps <= 0) return;                          // whole block: no barrier is pending
     const int li = lane & 15, lk = (lane >> 4) * CPL;
-    const bool active = row0 < a.rows;                               // ragged last block: idle waves still take the barriers
-    const char* wp = static_cast<const char*>(a.W) + ((size_t)min(row0 + li, a.rows - 1) * a.K + kb + lk) * BW;
+    const size_t rowb = (size_t)a.K * BW;
+    const char* wbase = static_cast<const char*>(a.W) + (size_t)lk * BW;
+    // cursors over the block's units: weights run two steps ahead of the MFMAs, activations one
+    int cs = u0 / a.nk, ck = u0 % a.nk;                   // strip / column step being multiplied
+    int ws = cs, wk = ck, wi = 0, xk = ck, xi = 0;
+    const char* wp = wbase + (size_t)min(ws * 64 + wid * 16 + li, a.rows - 1) * rowb + (size_t)wk * (PF_KSTEP * BW);
+    bool active = cs * 64 + wid * 16 < a.rows;            // ragged last strip: idle waves still take the barriers
     // activation staging: thread -> (token, 16-byte column group) of the TP x 64 tile, TP*16/256 vectors per thread
     constexpr int XV = TP * (PF_KSTEP / 4) / (PF_WAVES * WAVE);
     const float* xg[XV];
@@ -63,7 +92,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         const int idx = tid + i * PF_WAVES * WAVE, t = idx / (PF_KSTEP / 4), c4 = idx % (PF_KSTEP / 4);
-        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + kb + c4 * 4;   // pad tokens re-read the last row
+        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + c4 * 4;        // pad tokens re-read the last row
         xo[i] = t * PF_LDW + c4 * 4;
     }
 
@@ -71,69 +100,113 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
 
-    // Weights and activations of step s+1 are requested before the MFMAs of step s (one register stage ahead).
-    // Measured alternatives on MI355X (f32 w1|w3 GEMM, 64 positions): this form 47 us; two stages ahead with the
-    // stages rotated by name (loop written out three times) 77 us -- 150 registers, 3 waves/SIMD instead of 4.
-    float4 wc[NJ], wn[NJ], xr[XV];
+    // Weights are requested TWO 64-column steps ahead of their MFMAs (a ring of three register stages, the loop written
+    // out three times so the stages have names), activations one step ahead (they are L2-resident): the loaded HBM
+    // latency is 2-3 us, one step of MFMAs 0.85 us (64 positions) to 1.7 us (128).  Every load is unconditional (the
+    // cursors stop on the block's last unit) so the compiler counts vmcnt instead of draining it.
+    float4 w0[NJ], w1[NJ], w2[NJ];
+    pf_v4f xr[XV];
+    // Straight-line steps: the cursors advance by selects, not branches, and the loop below has no conditional steps --
+    // hipcc's waitcnt pass merges the pending-load state of both arms of a branch, and with a conditional step it
+    // concluded that the stage about to be multiplied might be the newest load: s_waitcnt vmcnt(0) at the top of every
+    // step, i.e. no weights in flight across a step at all (round-2 ISA reading).
+#define PF_WLOAD(W_)                                                                                                 \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) W_[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * CW * BW)); \
+        const int adv_ = wi < nsteps - 1 ? 1 : 0;                                                                    \
+        wi += adv_;                                                                                                  \
+        wk += adv_;                                                                                                  \
+        const bool wrap_ = wk == a.nk;                                                                               \
+        wk = wrap_ ? 0 : wk;                                                                                         \
+        ws += wrap_ ? 1 : 0;                                                                                         \
+        const char* nxt_ = wbase + (size_t)min(ws * 64 + wid * 16 + li, a.rows - 1) * rowb;                          \
+        wp = wrap_ ? nxt_ : wp + adv_ * (PF_KSTEP * BW);                                                             \
+    } while (0)
+#define PF_XLOAD()                                                                                                   \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const pf_v4f*>(xg[i] + xk * PF_KSTEP); \
+        const int adv_ = xi < nsteps - 1 ? 1 : 0;                                                                    \
+        xi += adv_;                                                                                                  \
+        xk += adv_;                                                                                                  \
+        xk = xk == a.nk ? 0 : xk;                                                                                    \
+    } while (0)
+#define PF_XSTORE(BUF_)                                                                                              \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < XV; ++i) *reinterpret_cast<pf_v4f*>(xs + (BUF_) * TP * PF_LDW + xo[i]) = xr[i]; \
+    } while (0)
+    auto compute = [&](const float4 (&wc)[NJ], int buf) {
+        const float* xb = xs + buf * TP * PF_LDW;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) wc[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * CW * BW));
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-    for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
-#pragma unroll
-    for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[0][0][0] + xo[i]) = xr[i];
-    __syncthreads();
-
-    for (int s = 0; s < nsteps; ++s) {
-        const int kn = min(s + 1, nsteps - 1) * PF_KSTEP;             // clamped: the loads stay unconditional
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) wn[j] = ldg_nt(reinterpret_cast<const float4*>(wp + (kn + j * CW) * BW));
-#pragma unroll
-        for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + kn);
-        const float* xb = &xs[s & 1][0][0];
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-                for (int h = 0; h < CPL / 4; ++h) {      // 4 columns at a time: one float4 of activations per token group
-                    float4 w;
-                    if constexpr (WT == WT_F16) {
-                        const __half2 p0 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].x : &wc[j].z);
-                        const __half2 p1 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].y : &wc[j].w);
-                        w = make_float4(__low2float(p0), __high2float(p0), __low2float(p1), __high2float(p1));
-                    } else {
-                        w = wc[j];
-                    }
-                    float4 x[NG];
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * CW + lk + 4 * h);
-                    // component-major: the NG accumulators are independent chains the matrix core can interleave
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[g].x, acc[g], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[g].y, acc[g], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[g].z, acc[g], 0, 0, 0);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[g].w, acc[g], 0, 0, 0);
+            for (int h = 0; h < CPL / 4; ++h) {      // 4 columns at a time: one float4 of activations per token group
+                float4 w;
+                if constexpr (WT == WT_F16) {
+                    const __half2 p0 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].x : &wc[j].z);
+                    const __half2 p1 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].y : &wc[j].w);
+                    w = make_float4(__low2float(p0), __high2float(p0), __low2float(p1), __high2float(p1));
+                } else {
+                    w = wc[j];
                 }
+                float4 x[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * CW + lk + 4 * h);
+                // component-major: the NG accumulators are independent chains the matrix core can interleave
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[g].x, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[g].y, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[g].z, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[g].w, acc[g], 0, 0, 0);
             }
         }
-        // the other buffer was last read in step s-1, which every wave left through the barrier below
-#pragma unroll
-        for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(&xs[(s + 1) & 1][0][0] + xo[i]) = xr[i];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) wc[j] = wn[j];
-        __syncthreads();
+    };
+#ifdef LLMK_PF_TRACE
+    unsigned long long* tr = a.trace + (size_t)blockIdx.x * 20;
+    if (tid == 0) tr[0] = wall_clock64();
+#define PF_STAMP(I_) if (tid == 0 && (I_) < 19) tr[I_] = wall_clock64()
+#else
+#define PF_STAMP(I_)
+#endif
+    PF_WLOAD(w0);
+    PF_WLOAD(w1);
+    PF_XLOAD();
+    PF_XSTORE(0);
+    __syncthreads();
+    PF_STAMP(1);
+    // step s: request activations of s+1 and weights of s+2 (in this order: the activations are needed first and
+    // vmcnt retires in order), multiply step s, publish the activations of s+1; at the end of a strip (or of the block's
+    // range) write the partial tile and start the next strip.  The step count is padded to a multiple of 3; a padding
+    // step re-requests the last unit and multiplies nothing.
+#define PF_STEP(S_, CUR_, NXT2_)                                                                                     \
+    {                                                                                                                \
+        PF_XLOAD();                                                                                                  \
+        PF_WLOAD(NXT2_);                                                                                             \
+        if (active && (S_) < nsteps) compute(CUR_, (S_) & 1);                                                        \
+        PF_XSTORE(((S_) + 1) & 1);                                                                                   \
+        if ((S_) < nsteps && (++ck == a.nk || (S_) == nsteps - 1)) {                                                 \
+            const int slot = (int)blockIdx.x - pf_first_block(cs, a.nk, a.U);                                        \
+            pf_flush<NG>(acc, active, a.P + ((size_t)slot * TP + li) * a.rows + cs * 64 + wid * 16 + (lane >> 4) * 4, a.rows); \
+            ck = 0;                                                                                                  \
+            ++cs;                                                                                                    \
+            active = cs * 64 + wid * 16 < a.rows;                                                                    \
+        }                                                                                                            \
+        __syncthreads();                                                                                             \
+        PF_STAMP(2 + (S_));                                                                                          \
     }
-    if (active) {
-        // D layout of 16x16x4: lane l, register v  <->  weight row 4*(l/16)+v, token l%16
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            float* dst = a.P + ((size_t)ks * TP + g * 16 + li) * a.rows + row0 + (lane >> 4) * 4;
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
-        }
+    for (int s = 0; s < nsteps; s += 3) {
+        PF_STEP(s, w0, w2)
+        PF_STEP(s + 1, w1, w0)
+        PF_STEP(s + 2, w2, w1)
     }
+#undef PF_STEP
+#undef PF_STAMP
+#undef PF_WLOAD
+#undef PF_XLOAD
+#undef PF_XSTORE
 }
 
 // ---- q4_0 weights (device layout of llmk_upload: rows of K/2 nibble bytes + K/32 f16 scales, RS bytes apart) -----------
@@ -150,6 +223,7 @@ struct PfGemmQ4Args {
     const float* X;      // [T][K]
     float* P;            // [KS][Tp][rows]
     int rows, K, T;
+    int Tp;              // token pitch of P (a 128-position pass is two launches of 64)
     int kslice;          // columns per K slice (multiple of PF_KSTEP_Q4)
 };
 
@@ -244,7 +318,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_q4_kernel(PfGemmQ4Arg
     if (active) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            float* dst = a.P + ((size_t)ks * TP + g * 16 + li) * a.rows + row0 + (lane >> 4) * 4;
+            float* dst = a.P + ((size_t)ks * a.Tp + g * 16 + li) * a.rows + row0 + (lane >> 4) * 4;
             *reinterpret_cast<float4*>(dst) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
         }
     }
@@ -276,19 +350,21 @@ __global__ __launch_bounds__(256) void pf_norm_kernel(const float* __restrict__ 
 }
 
 struct PfEpiArgs {
-    const float* P;      // [KS][Tp][rows]
+    const float* P;      // [slots][Tp][rows]
     const float* xn;     // [T] (QKV, SWIGLU) or null
     float* out;          // QKV: Q [T][E];  RESID: X [T][rows] (+=);  SWIGLU: HB [T][H]
     float* kc;           // QKV: this layer's caches [S][KV]
     float* vc;
     const float* rope;   // [hs/2]
-    int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0
+    int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0;  KS: partials per row (uniform K slices, q4_0 GEMM)
+    int U, nk;                   // U > 0: unit-balanced GEMM (PfGemmArgs), the 64-row strip of r has pf_nslots partials
     int E, KV, hs, H;
 };
 
 __device__ __forceinline__ float pf_sum(const PfEpiArgs& a, int t, int r) {
+    const int n = a.U > 0 ? pf_nslots(r >> 6, a.nk, a.U) : a.KS;
     float s = 0.f;
-    for (int ks = 0; ks < a.KS; ++ks) s += a.P[((size_t)ks * a.Tp + t) * a.rows + r];
+    for (int ks = 0; ks < n; ++ks) s += a.P[((size_t)ks * a.Tp + t) * a.rows + r];
     return s;
 }
 
