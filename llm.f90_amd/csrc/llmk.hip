@@ -553,18 +553,37 @@ void pf_split(const llmk_ctx* c, int rows, int K, int* ks_out, int* kslice_out) 
     *kslice_out = kslice;
     *ks_out = (K + kslice - 1) / kslice;
 }
-// f32 / f16 GEMM: units per block and workgroups per CU (prefill.h PfGemmArgs).  Two workgroups per CU overlap one's
-// barrier with the other's MFMAs; one per CU is taken when it divides the units much more evenly.
-struct PfPlan { int nk, total, U, grid, per_cu; };
+// f32 / f16 GEMM: row groups per wave, units per block and workgroups per CU (prefill.h PfGemmArgs).  Every candidate
+// is priced with the measured step times (tests/host_tools/pf_trace.py, round 2): a step of NR row groups at 128
+// positions keeps a SIMD's matrix core busy for 1.7*NR us per resident wave, plus ~0.5 us of barrier / staging per step;
+// the first weights take ~4 us to arrive and every partial tile costs a write and a read in the epilogue.
+struct PfPlan { int nr, nk, total, U, grid; };
 PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
-    PfPlan p;
-    p.nk = K / PF_KSTEP;
-    p.total = (rows + 63) / 64 * p.nk;
-    auto eff = [&](int nb) { const int U = (p.total + nb - 1) / nb; return (double)p.total / ((double)U * nb); };
-    p.per_cu = eff(c->n_cu) > eff(2 * c->n_cu) + 0.08 ? 1 : 2;
-    p.U = (p.total + p.per_cu * c->n_cu - 1) / (p.per_cu * c->n_cu);
-    p.grid = (p.total + p.U - 1) / p.U;
-    return p;
+    // ONE workgroup per CU (pinned by the LDS request), one or two 16-row groups per wave.  Step times measured at 128
+    // positions (tests/host_tools/pf_trace.py, profiles/README.md round 2): 2.45 us with one row group, 4.25 us with two;
+    // ~4 us until the first weights arrive; every partial tile is written once and read once by the epilogue.  Also
+    // measured and dropped: two workgroups per CU (their waves share the SIMDs' matrix cores: same step rate per CU, but
+    // the pairs drift apart and the kernel waits for the slower one) and eight waves per workgroup (two per SIMD in step).
+    static const double step_us[2] = {2.45, 4.25};
+    PfPlan best{};
+    double best_t = 1e30;
+    for (int nr = 1; nr <= 2; ++nr) {
+        const int sr = 64 * nr;
+        if (nr == 2 && rows % sr) continue;
+#ifdef LLMK_PF_TRACE
+        if (const char* f = getenv("LLMK_PF_PLAN"))          // debug build: force the row groups per wave (when the shape allows it)
+            if (atoi(f) != nr && !(rows % 128)) continue;
+#endif
+        PfPlan p;
+        p.nr = nr;
+        p.nk = K / PF_KSTEP;
+        p.total = (rows + sr - 1) / sr * p.nk;
+        p.U = (p.total + c->n_cu - 1) / c->n_cu;
+        p.grid = (p.total + p.U - 1) / p.U;
+        const double t = 4.0 + p.U * step_us[nr - 1] + 0.15 * ((p.nk - 1) / p.U + 1);
+        if (t < best_t) { best_t = t; best = p; }
+    }
+    return best;
 }
 int pf_max_slots(const PfPlan& p) { return (p.nk - 1) / p.U + 2; }
 int pf_setup(llmk_ctx* c) {
@@ -597,7 +616,7 @@ int pf_setup(llmk_ctx* c) {
 hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
     int ks, kslice;
     pf_split(c, rows, K, &ks, &kslice);
-    e->KS = ks; e->U = 0; e->nk = 0;
+    e->KS = ks; e->U = 0; e->nk = 0; e->sh = 6;
     const int Tp = (T + 15) / 16 * 16;
     for (int t0 = 0; t0 < T; t0 += 64) {
         PfGemmQ4Args a;
@@ -622,18 +641,17 @@ hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X
     }
     return hipSuccess;
 }
-template <int NG>
+template <int NG, int NR>
 hipError_t pf_gemm_launch(llmk_ctx* c, const PfGemmArgs& a, const PfPlan& p) {
-    // the LDS request pins the workgroups per CU (160 KB per CU): every CU gets the same number of equal blocks
-    const size_t need = (size_t)2 * NG * 16 * PF_LDW * sizeof(float);
-    const size_t smem = std::max(need, p.per_cu == 1 ? (size_t)84 * 1024 : (size_t)56 * 1024);
+    // the LDS request (> half of the CU's 160 KB) pins one workgroup per CU: every CU gets one block of equal length
+    const size_t smem = std::max((size_t)2 * NG * 16 * PF_LDW * sizeof(float), (size_t)84 * 1024);
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
     if (c->cfg.weight_type == LLMK_TYPE_F16) {
-        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16>), grid, block, smem, c->stream, a);
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, c->stream, a);
     } else {
-        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32>), grid, block, smem, c->stream, a);
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F32, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32, NR>), grid, block, smem, c->stream, a);
     }
     return hipGetLastError();
 }
@@ -645,17 +663,14 @@ hipError_t pf_gemm(llmk_ctx* c, const void* W, const float* X, int rows, int K, 
 #ifdef LLMK_PF_TRACE
     a.trace = (unsigned long long*)c->pf_HB;     // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
 #endif
-    e->KS = 0; e->U = p.U; e->nk = p.nk;
+    e->KS = 0; e->U = p.U; e->nk = p.nk; e->sh = p.nr == 2 ? 7 : 6;
+#define PF_CASE(NG_)                                                                         \
+    case NG_: return p.nr == 2 ? pf_gemm_launch<NG_, 2>(c, a, p) : pf_gemm_launch<NG_, 1>(c, a, p)
     switch ((T + 15) / 16) {
-        case 1: return pf_gemm_launch<1>(c, a, p);
-        case 2: return pf_gemm_launch<2>(c, a, p);
-        case 3: return pf_gemm_launch<3>(c, a, p);
-        case 4: return pf_gemm_launch<4>(c, a, p);
-        case 5: return pf_gemm_launch<5>(c, a, p);
-        case 6: return pf_gemm_launch<6>(c, a, p);
-        case 7: return pf_gemm_launch<7>(c, a, p);
-        default: return pf_gemm_launch<8>(c, a, p);
+        PF_CASE(1); PF_CASE(2); PF_CASE(3); PF_CASE(4); PF_CASE(5); PF_CASE(6); PF_CASE(7);
+        default: return p.nr == 2 ? pf_gemm_launch<8, 2>(c, a, p) : pf_gemm_launch<8, 1>(c, a, p);
     }
+#undef PF_CASE
 }
 // one batch of T <= PF_TMAX prompt positions pos0 .. pos0+T-1 (1-based) through all layers; X[T-1] ends up in d_x
 hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
@@ -678,19 +693,24 @@ hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
         };
         float* kc = c->d_kc + (size_t)l * c->S * KV;
         float* vc = c->d_vc + (size_t)l * c->S * KV;
-        // rmsnorm + QKV + RoPE + KV write                                                 llama2.f90:527-565
-        hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
-                           (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E, c->eps);
-        HIPRET(hipGetLastError());
+        // rmsnorm (layer 0 here, later layers in the previous residual's kernel) + QKV + RoPE + KV write   llama2.f90:527-565
+        if (l == 0) {
+            hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
+                               (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data, c->pf_Xs, c->pf_xn, E, c->eps);
+            HIPRET(hipGetLastError());
+        }
         HIPRET(gemm(LLMK_WQKV, QKV, c->pf_Xs, E));
         e.rows = QKV; e.out = c->pf_Q; e.kc = kc; e.vc = vc;
         hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, c->stream, e);
         HIPRET(hipGetLastError());
         // causal attention: position pos0+t sees cache rows 0 .. pos0+t-1                 :572-598
-        const size_t smem = (516 + (size_t)c->S) * sizeof(float);
-#define ATT(HS_)                                                                                                   \
-    hipLaunchKernelGGL((attn_kernel<HS_>), dim3(c->nh, T), dim3(256), smem, c->stream, c->pf_Q, kc, vc, c->pf_XB, \
-                       c->d_tokpos, KV, c->kv_mul, pos0, E)
+#define ATT(HS_)                                                                                                         \
+    do {                                                                                                                 \
+        const size_t smem = ((size_t)PF_ATT_WAVES * 16 * (HS_) + 2 * PF_ATT_WAVES * 16) * sizeof(float);                 \
+        HIPRET(hipFuncSetAttribute((const void*)pf_attn_kernel<HS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL((pf_attn_kernel<HS_>), dim3(c->nh, (T + 15) / 16), dim3(PF_ATT_WAVES * WAVE), smem, c->stream, \
+                           c->pf_Q, kc, vc, c->pf_XB, KV, c->kv_mul, pos0, T, E);                                        \
+    } while (0)
         switch (c->hs) {
             case 16: ATT(16); break;
             case 32: ATT(32); break;
@@ -703,12 +723,10 @@ hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
         // x += wo . xb                                                                    :603-605
         HIPRET(gemm(LLMK_WO, E, c->pf_XB, E));
         e.rows = E; e.out = c->pf_X;
-        hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
+        hipLaunchKernelGGL(pf_epi_resid_norm_kernel, dim3(T), dim3(1024), 0, c->stream, e,
+                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, c->eps);
         HIPRET(hipGetLastError());
-        // rmsnorm + w1|w3 + SwiGLU                                                        :608-616
-        hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
-                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, E, c->eps);
-        HIPRET(hipGetLastError());
+        // (rmsnorm above) + w1|w3 + SwiGLU                                                :608-616
         HIPRET(gemm(LLMK_W13, 2 * H, c->pf_Xs, E));
         e.rows = 2 * H; e.out = c->pf_HB;
         hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, c->stream, e);
@@ -716,7 +734,9 @@ hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
         // x += w2 . hb                                                                    :618-620
         HIPRET(gemm(LLMK_W2, E, c->pf_HB, H));
         e.rows = E; e.out = c->pf_X;
-        hipLaunchKernelGGL(pf_epi_resid_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, e);
+        hipLaunchKernelGGL(pf_epi_resid_norm_kernel, dim3(T), dim3(1024), 0, c->stream, e,
+                           l + 1 < c->L ? (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)(l + 1) * E : nullptr, c->pf_Xs,
+                           c->pf_xn, c->eps);
         HIPRET(hipGetLastError());
     }
     return hipMemcpyAsync(c->d_x, c->pf_X + (size_t)(T - 1) * E, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
@@ -1110,10 +1130,10 @@ int llmk_timings(llmk_ctx* c, float ms[5]) {
 int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* bytes_per_launch) {
     int rc = check_ready(c);
     if (rc) return rc;
-    if (kernel < 0 || kernel > 7 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
+    if (kernel < 0 || kernel > 10 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
     if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (kernel == 7) {   // the prefill w1|w3 GEMM at PF_TMAX positions (whatever the workspaces hold: timing only)
+    if (kernel >= 7) {   // the prefill GEMMs at PF_TMAX positions: 7 w1|w3, 8 wqkv, 9 wo, 10 w2 (whatever the workspaces hold: timing only)
         if (c->cfg.weight_type == LLMK_TYPE_Q4_0 || c->tp_size != 1 || c->E % PF_KSTEP || c->H % PF_KSTEP) return LLMK_E_ARG;
         rc = pf_setup(c);
         if (rc) return rc;
@@ -1133,9 +1153,12 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
             hipLaunchKernelGGL(bump_serial_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tokpos);
             return launch_token_kernel(c);
         }
-        if (kernel == 7) {
+        if (kernel >= 7) {
             PfEpiArgs e;
-            return pf_gemm(c, (const char*)c->t[LLMK_W13].data + (size_t)l * 2 * c->H * c->t[LLMK_W13].row_bytes, c->pf_Xs, 2 * c->H, c->E, PF_TMAX, &e);
+            const int tid = kernel == 7 ? LLMK_W13 : kernel == 8 ? LLMK_WQKV : kernel == 9 ? LLMK_WO : LLMK_W2;
+            const int rows = kernel == 7 ? 2 * c->H : kernel == 8 ? c->E + 2 * c->KV : c->E;
+            return pf_gemm(c, (const char*)c->t[tid].data + (size_t)l * rows * c->t[tid].row_bytes, kernel == 10 ? c->pf_HB : c->pf_Xs,
+                           rows, kernel == 10 ? c->H : c->E, PF_TMAX, &e);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);
@@ -1157,7 +1180,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     if (kernel == 6) c->h_tokpos[2] += iters + 3;   // the device-side serial was bumped once per launch: keep the host's in step
                                                      // (exchange epochs must stay unique per serial)
     if (bytes_per_launch) {
-        const int tids[8] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS, -1, LLMK_W13};
+        const int tids[11] = {LLMK_WQKV, -1, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS, -1, LLMK_W13, LLMK_WQKV, LLMK_WO, LLMK_W2};
         double b = 0;
         if (kernel == 6) {
             double w = 0;

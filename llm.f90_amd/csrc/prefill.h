@@ -41,9 +41,9 @@ struct PfGemmArgs {
     int rows, K, T;
     int nk;              // 64-column steps per strip = K / PF_KSTEP
     int U;               // units per block
-    int total;           // strips * nk
+    int total;           // strips * nk   (strip = 64 rows, or 128 with two row groups per wave)
 #ifdef LLMK_PF_TRACE
-    unsigned long long* trace;   // [grid][20] wall-clock stamps: entry, prologue done, end of steps 0..15, exit
+    unsigned long long* trace;   // [grid][20] wall-clock stamps: entry, prologue done, end of steps 0..14; [17] exit, [18],[19] shader clock at entry / exit
 #endif
 };
 
@@ -65,13 +65,22 @@ __device__ __forceinline__ void pf_flush(pf_v4f (&acc)[NG], bool active, float* 
 
 // f16 weights: a lane's 16 bytes are 8 columns, so a chunk is 32 columns (8 MFMA steps after the exact half -> float
 // conversion) and a 64-column step has two chunks; the activation side is f32 either way.
-template <int NG, int WT>
+//
+// NR = 16-row groups per wave.  NR 1: strips of 64 rows, weights requested TWO steps ahead (ring of three register
+// stages).  NR 2: strips of 128 rows (rows % 128 == 0 required: no ragged strip), every activation fragment read from LDS
+// feeds two MFMAs -- a step is twice the matrix work for the same LDS reads, barrier and staging, so the fixed cost per
+// step weighs half; one step (>= 3.4 us of MFMAs) is enough lead for the weights, which keeps the ring at two stages and
+// the kernel at two waves per SIMD.
+template <int NG, int WT, int NR>
 __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) {
+    constexpr int NW = PF_WAVES;
     constexpr int TP = NG * 16;
     constexpr int BW = (WT == WT_F16) ? 2 : 4;          // bytes per weight
     constexpr int CPL = 16 / BW;                          // columns per lane load: 4 / 8
     constexpr int CW = 4 * CPL;                           // columns per chunk (4 lane groups): 16 / 32
     constexpr int NJ = PF_KSTEP / CW;                     // chunks per step: 4 / 2
+    constexpr int SR = 16 * NR * NW;                      // rows per strip
+    constexpr int NT = NW * WAVE;                         // threads
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     float* xs = reinterpret_cast<float*>(pf_smem);        // [2][TP][PF_LDW]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -80,132 +89,184 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     const int li = lane & 15, lk = (lane >> 4) * CPL;
     const size_t rowb = (size_t)a.K * BW;
     const char* wbase = static_cast<const char*>(a.W) + (size_t)lk * BW;
-    // cursors over the block's units: weights run two steps ahead of the MFMAs, activations one
+    // cursors over the block's units: weights run ahead of the MFMAs, activations one step
     int cs = u0 / a.nk, ck = u0 % a.nk;                   // strip / column step being multiplied
     int ws = cs, wk = ck, wi = 0, xk = ck, xi = 0;
-    const char* wp = wbase + (size_t)min(ws * 64 + wid * 16 + li, a.rows - 1) * rowb + (size_t)wk * (PF_KSTEP * BW);
-    bool active = cs * 64 + wid * 16 < a.rows;            // ragged last strip: idle waves still take the barriers
+    const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * (PF_KSTEP * BW);
+    bool active = cs * SR + wid * (16 * NR) < a.rows;     // ragged last strip (NR 1): idle waves still take the barriers
     // activation staging: thread -> (token, 16-byte column group) of the TP x 64 tile, TP*16/256 vectors per thread
-    constexpr int XV = TP * (PF_KSTEP / 4) / (PF_WAVES * WAVE);
+    constexpr int XN = TP * (PF_KSTEP / 4), XV = (XN + NT - 1) / NT;   // XN % NT = 0 or NT/2 (odd NG, 8 waves)
+    const bool xlast = (XV - 1) * NT + tid < XN;
     const float* xg[XV];
     int xo[XV];
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
-        const int idx = tid + i * PF_WAVES * WAVE, t = idx / (PF_KSTEP / 4), c4 = idx % (PF_KSTEP / 4);
+        const int idx = min(tid + i * NT, XN - 1), t = idx / (PF_KSTEP / 4), c4 = idx % (PF_KSTEP / 4);
         xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + c4 * 4;        // pad tokens re-read the last row
         xo[i] = t * PF_LDW + c4 * 4;
     }
 
-    pf_v4f acc[NG];
+    pf_v4f acc[NR][NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[r][g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
 
-    // Weights are requested TWO 64-column steps ahead of their MFMAs (a ring of three register stages, the loop written
-    // out three times so the stages have names), activations one step ahead (they are L2-resident): the loaded HBM
-    // latency is 2-3 us, one step of MFMAs 0.85 us (64 positions) to 1.7 us (128).  Every load is unconditional (the
-    // cursors stop on the block's last unit) so the compiler counts vmcnt instead of draining it.
-    float4 w0[NJ], w1[NJ], w2[NJ];
+    // The register stages have names and the loop is written out once per stage.  Every load is unconditional (the
+    // cursors stop on the block's last unit) and the cursors advance by selects, not branches: hipcc's waitcnt pass
+    // merges the pending-load state of both arms of a branch, and with conditional steps it concluded that the stage
+    // about to be multiplied might be the newest load -- s_waitcnt vmcnt(0) at the top of every step, no weights in
+    // flight across a step at all (round-2 ISA reading).
+    float4 w0[NR * NJ], w1[NR * NJ], w2[NR == 1 ? NJ : 1];
     pf_v4f xr[XV];
-    // Straight-line steps: the cursors advance by selects, not branches, and the loop below has no conditional steps --
-    // hipcc's waitcnt pass merges the pending-load state of both arms of a branch, and with a conditional step it
-    // concluded that the stage about to be multiplied might be the newest load: s_waitcnt vmcnt(0) at the top of every
-    // step, i.e. no weights in flight across a step at all (round-2 ISA reading).
-#define PF_WLOAD(W_)                                                                                                 \
+#define PF_WLOAD_PART(W_, LO_, HI_)                                                                                  \
     do {                                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) W_[j] = ldg_nt(reinterpret_cast<const float4*>(wp + j * CW * BW)); \
+        _Pragma("unroll") for (int q = (LO_); q < (HI_); ++q)                                                        \
+            W_[q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * CW * BW));  \
+    } while (0)
+#define PF_WNEXT()                                                                                                   \
+    do {                                                                                                             \
         const int adv_ = wi < nsteps - 1 ? 1 : 0;                                                                    \
         wi += adv_;                                                                                                  \
         wk += adv_;                                                                                                  \
         const bool wrap_ = wk == a.nk;                                                                               \
         wk = wrap_ ? 0 : wk;                                                                                         \
         ws += wrap_ ? 1 : 0;                                                                                         \
-        const char* nxt_ = wbase + (size_t)min(ws * 64 + wid * 16 + li, a.rows - 1) * rowb;                          \
+        const char* nxt_ = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb;                   \
         wp = wrap_ ? nxt_ : wp + adv_ * (PF_KSTEP * BW);                                                             \
     } while (0)
-#define PF_XLOAD()                                                                                                   \
+#define PF_WLOAD(W_)                                                                                                 \
     do {                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const pf_v4f*>(xg[i] + xk * PF_KSTEP); \
+        PF_WLOAD_PART(W_, 0, NR * NJ);                                                                               \
+        PF_WNEXT();                                                                                                  \
+    } while (0)
+#define PF_XLOAD_PART(LO_, HI_)                                                                                      \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = (LO_); i < (HI_); ++i) xr[i] = *reinterpret_cast<const pf_v4f*>(xg[i] + xk * PF_KSTEP); \
+    } while (0)
+#define PF_XNEXT()                                                                                                   \
+    do {                                                                                                             \
         const int adv_ = xi < nsteps - 1 ? 1 : 0;                                                                    \
         xi += adv_;                                                                                                  \
         xk += adv_;                                                                                                  \
         xk = xk == a.nk ? 0 : xk;                                                                                    \
     } while (0)
+#define PF_XLOAD()                                                                                                   \
+    do {                                                                                                             \
+        PF_XLOAD_PART(0, XV);                                                                                        \
+        PF_XNEXT();                                                                                                  \
+    } while (0)
 #define PF_XSTORE(BUF_)                                                                                              \
     do {                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < XV; ++i) *reinterpret_cast<pf_v4f*>(xs + (BUF_) * TP * PF_LDW + xo[i]) = xr[i]; \
+        _Pragma("unroll") for (int i = 0; i < XV; ++i)                                                               \
+            if (i < XV - 1 || XN % NT == 0 || xlast) *reinterpret_cast<pf_v4f*>(xs + (BUF_) * TP * PF_LDW + xo[i]) = xr[i]; \
     } while (0)
-    auto compute = [&](const float4 (&wc)[NJ], int buf) {
+    // a quarter of a step: 16 columns, one float4 of activations per token group (f16: half of a 32-column chunk)
+    auto piece = [&](const float4 (&wc)[NR * NJ], int buf, int pc) {
         const float* xb = xs + buf * TP * PF_LDW;
+        const int j = pc / (CPL / 4), h = pc % (CPL / 4);
+        float4 w[NR];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-            for (int h = 0; h < CPL / 4; ++h) {      // 4 columns at a time: one float4 of activations per token group
-                float4 w;
-                if constexpr (WT == WT_F16) {
-                    const __half2 p0 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].x : &wc[j].z);
-                    const __half2 p1 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[j].y : &wc[j].w);
-                    w = make_float4(__low2float(p0), __high2float(p0), __low2float(p1), __high2float(p1));
-                } else {
-                    w = wc[j];
-                }
-                float4 x[NG];
-#pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * CW + lk + 4 * h);
-                // component-major: the NG accumulators are independent chains the matrix core can interleave
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[g].x, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[g].y, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[g].z, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[g].w, acc[g], 0, 0, 0);
+        for (int r = 0; r < NR; ++r) {
+            if constexpr (WT == WT_F16) {
+                const __half2 p0 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[r * NJ + j].x : &wc[r * NJ + j].z);
+                const __half2 p1 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[r * NJ + j].y : &wc[r * NJ + j].w);
+                w[r] = make_float4(__low2float(p0), __high2float(p0), __low2float(p1), __high2float(p1));
+            } else {
+                w[r] = wc[r * NJ + j];
             }
         }
+        float4 x[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) x[g] = *reinterpret_cast<const float4*>(xb + (g * 16 + li) * PF_LDW + j * CW + lk + 4 * h);
+        // component-major: the NR*NG accumulators are independent chains the matrix core can interleave
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r].x, x[g].x, acc[r][g], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r].y, x[g].y, acc[r][g], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r].z, x[g].z, acc[r][g], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r].w, x[g].w, acc[r][g], 0, 0, 0);
     };
 #ifdef LLMK_PF_TRACE
     unsigned long long* tr = a.trace + (size_t)blockIdx.x * 20;
-    if (tid == 0) tr[0] = wall_clock64();
-#define PF_STAMP(I_) if (tid == 0 && (I_) < 19) tr[I_] = wall_clock64()
+    if (tid == 0) { tr[0] = wall_clock64(); tr[18] = __builtin_readcyclecounter(); }
+#define PF_STAMP(I_) if (tid == 0 && (I_) < 17) tr[I_] = wall_clock64()
 #else
 #define PF_STAMP(I_)
 #endif
     PF_WLOAD(w0);
-    PF_WLOAD(w1);
+    if constexpr (NR == 1) PF_WLOAD(w1);
     PF_XLOAD();
     PF_XSTORE(0);
+    PF_XLOAD();
     __syncthreads();
     PF_STAMP(1);
-    // step s: request activations of s+1 and weights of s+2 (in this order: the activations are needed first and
-    // vmcnt retires in order), multiply step s, publish the activations of s+1; at the end of a strip (or of the block's
-    // range) write the partial tile and start the next strip.  The step count is padded to a multiple of 3; a padding
-    // step re-requests the last unit and multiplies nothing.
-#define PF_STEP(S_, CUR_, NXT2_)                                                                                     \
+    // step s: publish the activations of s+1 (requested a whole step ago: nothing to wait for; the buffer they go to
+    // was last read in step s-1, which every wave has left), request the activations of s+2 and the weights the ring has
+    // room for (in this order: vmcnt retires in order and the activations are needed first), multiply step s; at the end
+    // of a strip (or of the block's range) write the partial tile and start the next strip.  The step count is padded to a multiple
+    // of the ring depth; a padding step re-requests the last unit and multiplies nothing.
+#define PF_STEP(S_, CUR_, NXT_)                                                                                      \
     {                                                                                                                \
-        PF_XLOAD();                                                                                                  \
-        PF_WLOAD(NXT2_);                                                                                             \
-        if (active && (S_) < nsteps) compute(CUR_, (S_) & 1);                                                        \
+        const bool mul_ = active && (S_) < nsteps;                                                                   \
         PF_XSTORE(((S_) + 1) & 1);                                                                                   \
+        if (mul_) piece(CUR_, (S_) & 1, 0);                                                                          \
+        PF_XLOAD_PART(0, XV / 2);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if (mul_) piece(CUR_, (S_) & 1, 1);                                                                          \
+        PF_XLOAD_PART(XV / 2, XV);                                                                                   \
+        PF_XNEXT();                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if (mul_) piece(CUR_, (S_) & 1, 2);                                                                          \
+        PF_WLOAD_PART(NXT_, 0, NR * NJ / 2);                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if (mul_) piece(CUR_, (S_) & 1, 3);                                                                          \
+        PF_WLOAD_PART(NXT_, NR * NJ / 2, NR * NJ);                                                                   \
+        PF_WNEXT();                                                                                                  \
         if ((S_) < nsteps && (++ck == a.nk || (S_) == nsteps - 1)) {                                                 \
             const int slot = (int)blockIdx.x - pf_first_block(cs, a.nk, a.U);                                        \
-            pf_flush<NG>(acc, active, a.P + ((size_t)slot * TP + li) * a.rows + cs * 64 + wid * 16 + (lane >> 4) * 4, a.rows); \
+            float* dst_ = a.P + ((size_t)slot * TP + li) * a.rows + cs * SR + wid * (16 * NR) + (lane >> 4) * 4;     \
+            _Pragma("unroll") for (int r = 0; r < NR; ++r) pf_flush<NG>(acc[r], active, dst_ + r * 16, a.rows);      \
             ck = 0;                                                                                                  \
             ++cs;                                                                                                    \
-            active = cs * 64 + wid * 16 < a.rows;                                                                    \
+            active = cs * SR + wid * (16 * NR) < a.rows;                                                             \
         }                                                                                                            \
         __syncthreads();                                                                                             \
         PF_STAMP(2 + (S_));                                                                                          \
     }
-    for (int s = 0; s < nsteps; s += 3) {
-        PF_STEP(s, w0, w2)
-        PF_STEP(s + 1, w1, w0)
-        PF_STEP(s + 2, w2, w1)
+    if constexpr (NR == 1) {
+        for (int s = 0; s < nsteps; s += 3) {
+            PF_STEP(s, w0, w2)
+            PF_STEP(s + 1, w1, w0)
+            PF_STEP(s + 2, w2, w1)
+        }
+    } else {
+        for (int s = 0; s < nsteps; s += 2) {
+            PF_STEP(s, w0, w1)
+            PF_STEP(s + 1, w1, w0)
+        }
     }
+#ifdef LLMK_PF_TRACE
+    if (tid == 0) { tr[17] = wall_clock64(); tr[19] = __builtin_readcyclecounter(); }     // shader clock = (19 - 18) / (17 - 0)
+#endif
 #undef PF_STEP
 #undef PF_STAMP
 #undef PF_WLOAD
+#undef PF_WLOAD_PART
+#undef PF_WNEXT
 #undef PF_XLOAD
+#undef PF_XLOAD_PART
+#undef PF_XNEXT
 #undef PF_XSTORE
 }
 
@@ -349,6 +410,143 @@ __global__ __launch_bounds__(256) void pf_norm_kernel(const float* __restrict__ 
     if (tid == 0) xn[t] = sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)E + eps);
 }
 
+// ---- batched causal attention on the matrix cores                                     llama2.f90:572-598 ------------
+// One workgroup per (query head, 16 prompt positions); its 8 waves take the 16-row tiles of the KV cache round robin, each
+// with its own running softmax (max m, sum l, unnormalised output O), and the workgroup merges the eight partial results
+// at the end:  out = sum_w O_w e^(m_w - M) / sum_w l_w e^(m_w - M).  The token-by-token kernel (kernels.h attn_kernel) is
+// launched per (head, position) and re-reads the cache for every position: 16x the L2 traffic of this one.
+//
+// Per tile and wave, with v_mfma_f32_16x16x4_f32 (D[i][j] += sum_k A[i][k] B[k][j]; lane l gives A[l%16][l/16] and
+// B[l/16][l%16], and receives D[4*(l/16)+v][l%16] in register v):
+//   S^T = K Q^T : A = K tile (i = cache row), B = Q (j = query), HS/4 steps; lane (q = l%16, g = l/16) holds head
+//         dimensions 16g' .. of both (the contraction index can be any permutation as long as A and B agree), and ends up
+//         with S[q][row 4g+v], v = 0..3 -- a query's 16 scores sit in 4 lanes x 4 registers: max and sum need two
+//         cross-lane steps (xor 16, 32);
+//   O += P V   : A = P (i = query): lane (q, g) feeds P[q][row 4g+v] in step v -- exactly the registers it holds, no
+//         transpose; B = V: lane (c = l%16, g) feeds V[row 4g+v][NT*c + t] for output tile t (NT = HS/16 adjacent floats:
+//         one vector load per row), and receives O[query 4g+r][NT*c + t] in register r.
+constexpr int PF_ATT_WAVES = 8;
+
+template <int HS>
+__global__ __launch_bounds__(PF_ATT_WAVES * WAVE) void pf_attn_kernel(const float* __restrict__ Q, const float* __restrict__ kc,
+                                                                      const float* __restrict__ vc, float* __restrict__ out,
+                                                                      int KV, int kv_mul, int pos0, int T, int E) {
+    constexpr int DG = HS / 4, NT = HS / 16, NW = PF_ATT_WAVES;
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    float* so = reinterpret_cast<float*>(pf_smem);   // [NW][16][HS]
+    float* sm = so + NW * 16 * HS;                    // [NW][16]
+    float* sl = sm + NW * 16;                         // [NW][16]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, g = lane >> 4;
+    const int h = blockIdx.x, kvh = h / kv_mul, q0 = blockIdx.y * 16;
+    const int tq = q0 + li;                           // this lane's query (token index of the batch); row r is visible iff r < pos0 + tq
+    const int nrows = pos0 + min(q0 + 15, T - 1);     // rows the tile's last query sees: 0 .. nrows-1
+    const float scale = sqrtf((float)HS);
+    float qf[DG];
+    {
+        const float* qp = Q + (size_t)min(tq, T - 1) * E + (size_t)h * HS + g * DG;
+#pragma unroll
+        for (int m = 0; m < DG; m += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + m);
+            qf[m] = v.x; qf[m + 1] = v.y; qf[m + 2] = v.z; qf[m + 3] = v.w;
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    pf_v4f O[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) O[t] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+    const float* kb = kc + (size_t)kvh * HS + g * DG;
+    const float* vb = vc + (size_t)kvh * HS + NT * li;
+    const int ntile = (nrows + 15) >> 4;
+    for (int kt = wid; kt < ntile; kt += NW) {
+        const int r0 = kt << 4;
+        float kf[DG], vf[4][NT];
+        {
+            const float* kp = kb + (size_t)min(r0 + li, nrows - 1) * KV;
+#pragma unroll
+            for (int m = 0; m < DG; m += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(kp + m);
+                kf[m] = v.x; kf[m + 1] = v.y; kf[m + 2] = v.z; kf[m + 3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float* vp = vb + (size_t)min(r0 + 4 * g + v, nrows - 1) * KV;
+            if constexpr (NT % 4 == 0) {
+#pragma unroll
+                for (int t = 0; t < NT; t += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(vp + t);
+                    vf[v][t] = x.x; vf[v][t + 1] = x.y; vf[v][t + 2] = x.z; vf[v][t + 3] = x.w;
+                }
+            } else if constexpr (NT == 2) {
+                const float2 x = *reinterpret_cast<const float2*>(vp);
+                vf[v][0] = x.x; vf[v][1] = x.y;
+            } else {
+                vf[v][0] = vp[0];
+            }
+        }
+        pf_v4f acc = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < DG; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[m], qf[m], acc, 0, 0, 0);
+        float sc[4], mx = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool vis = r0 + 4 * g + v < pos0 + tq && tq < T;
+            sc[v] = vis ? acc[v] / scale : -INFINITY;
+            mx = fmaxf(mx, sc[v]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const bool any = m_new != -INFINITY;                                   // false: nothing of this query seen so far
+        const float alpha = !any ? 1.f : (m_run == -INFINITY ? 0.f : expf(m_run - m_new));
+        float p[4], rs = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            p[v] = (any && sc[v] != -INFINITY) ? expf(sc[v] - m_new) : 0.f;
+            rs += p[v];
+        }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, 4 * g + r, 64);                     // O rows are queries 4g+r
+#pragma unroll
+            for (int t = 0; t < NT; ++t) O[t][r] *= ar;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) O[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[v], vf[v][t], O[t], 0, 0, 0);
+    }
+    if (g == 0) {
+        sm[wid * 16 + li] = m_run;
+        sl[wid * 16 + li] = l_run;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) so[(size_t)(wid * 16 + 4 * g + r) * HS + NT * li + t] = O[t][r];
+    __syncthreads();
+    for (int idx = tid; idx < 16 * HS; idx += NW * WAVE) {
+        const int q = idx / HS, d = idx % HS;
+        if (q0 + q >= T) continue;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, sm[w * 16 + q]);
+        float L = 0.f, val = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float mw = sm[w * 16 + q];
+            const float e = mw == -INFINITY ? 0.f : expf(mw - M);
+            L += sl[w * 16 + q] * e;
+            val += so[(size_t)(w * 16 + q) * HS + d] * e;
+        }
+        out[(size_t)(q0 + q) * E + (size_t)h * HS + d] = val / L;
+    }
+}
+
 struct PfEpiArgs {
     const float* P;      // [slots][Tp][rows]
     const float* xn;     // [T] (QKV, SWIGLU) or null
@@ -357,14 +555,23 @@ struct PfEpiArgs {
     float* vc;
     const float* rope;   // [hs/2]
     int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0;  KS: partials per row (uniform K slices, q4_0 GEMM)
-    int U, nk;                   // U > 0: unit-balanced GEMM (PfGemmArgs), the 64-row strip of r has pf_nslots partials
+    int U, nk, sh;               // U > 0: unit-balanced GEMM (PfGemmArgs), the strip r >> sh has pf_nslots partials
     int E, KV, hs, H;
 };
 
+// partials of (t, r) added in slot order; four loads in flight at a time (the trip count is a run-time value: a plain
+// loop would wait for each load before asking for the next)
 __device__ __forceinline__ float pf_sum(const PfEpiArgs& a, int t, int r) {
-    const int n = a.U > 0 ? pf_nslots(r >> 6, a.nk, a.U) : a.KS;
+    const int n = a.U > 0 ? pf_nslots(r >> a.sh, a.nk, a.U) : a.KS;
+    const size_t pitch = (size_t)a.Tp * a.rows;
+    const float* p = a.P + (size_t)t * a.rows + r;
     float s = 0.f;
-    for (int ks = 0; ks < n; ++ks) s += a.P[((size_t)ks * a.Tp + t) * a.rows + r];
+    int ks = 0;
+    for (; ks + 4 <= n; ks += 4, p += 4 * pitch) {
+        const float v0 = p[0], v1 = p[pitch], v2 = p[2 * pitch], v3 = p[3 * pitch];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; ks < n; ++ks, p += pitch) s += *p;
     return s;
 }
 
@@ -387,10 +594,30 @@ __global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
         dst[1] = a1;
     }
 }
-// x[t][r] += sum                                                                        :603-605, :618-620
-__global__ void pf_epi_resid_kernel(PfEpiArgs a) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-    if (r < a.rows) a.out[(size_t)t * a.rows + r] += pf_sum(a, t, r);
+// x[t] += sum (:603-605, :618-620), then the NEXT rmsnorm's products from the finished row (:450-457): xs[t] = x[t]*w and
+// xn[t] = sqrt(dot(x,x)/E + eps).  One workgroup per position; w == nullptr (after the last layer): residual only.
+__global__ __launch_bounds__(1024) void pf_epi_resid_norm_kernel(PfEpiArgs a, const float* __restrict__ w, float* __restrict__ Xs,
+                                                                 float* __restrict__ xn, float eps) {
+    __shared__ float red[16];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    float ss = 0.f;
+    for (int r = tid; r < a.rows; r += 1024) {
+        const float v = a.out[(size_t)t * a.rows + r] + pf_sum(a, t, r);
+        a.out[(size_t)t * a.rows + r] = v;
+        if (w) {
+            ss = fmaf(v, v, ss);
+            Xs[(size_t)t * a.rows + r] = v * w[r];
+        }
+    }
+    if (!w) return;
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 16; ++i) tot += red[i];
+        xn[t] = sqrtf(tot / (float)a.rows + eps);
+    }
 }
 // hb = silu(gate) * up                                                                  :613-616
 __global__ void pf_epi_swiglu_kernel(PfEpiArgs a) {

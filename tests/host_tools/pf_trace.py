@@ -1,5 +1,6 @@
-"""Block timeline of the prefill w1|w3 GEMM (pf_gemm_kernel): wall-clock stamps per workgroup from the DEBUG library.
-   LLMK_LIB=llm.f90_amd/csrc/libllmk_debug.so python tests/host_tools/pf_trace.py [positions]"""
+"""Block timeline of the prefill GEMMs (pf_gemm_kernel): wall-clock stamps per workgroup from the DEBUG library.
+   LLMK_LIB=llm.f90_amd/csrc/libllmk_debug.so LLMK_PF_PLAN=1|2 python tests/host_tools/pf_trace.py [w13|wqkv|wo|w2]
+   LLMK_PF_PLAN forces the 16-row groups per wave of pf_plan (csrc/llmk.hip); the tool needs it to know the grid."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,22 +9,30 @@ import llm_f90_amd
 from llm_f90_amd import llmk
 from llm_f90_amd.tools import gguf
 s = gguf.SHAPES["tinyllama"]
+which = sys.argv[1] if len(sys.argv) > 1 else "w13"
+kern = {"w13": 7, "wqkv": 8, "wo": 9, "w2": 10}[which]
+rows = {"w13": 2 * s.hidden_dim, "wqkv": s.emb_dim + 2 * s.kv_dim, "wo": s.emb_dim, "w2": s.emb_dim}[which]
+K = s.hidden_dim if which == "w2" else s.emb_dim
 m = llmk.Llmk(gguf.synth_fused(s, 1, 0))
 m.prefill([2] + list(range(5, 5 + 127)), 1)
-ms, b = m.time_kernel(7, 66)
-print("w1|w3 GEMM, 128 positions: %.1f us per launch (66 launches), %.1f TFLOP/s" % (ms * 1e3, 2 * 128 * b / 4 / (ms * 1e-3) / 1e12))
-ms, b = m.time_kernel(7, 1)
-total = (2 * s.hidden_dim // 64) * (s.emb_dim // 64)
-nb = 512 if total % 512 == 0 or total / (512 * -(-total // 512)) + 0.08 >= total / (256 * -(-total // 256)) else 256
-U = -(-total // nb)
+ms, b = m.time_kernel(kern, 66)
+print("%s GEMM, 128 positions: %.1f us per launch (66 launches), %.1f TFLOP/s" % (which, ms * 1e3, 2 * 128 * rows * K / (ms * 1e-3) / 1e12))
+if which == "w2":
+    sys.exit(0)            # its activations live where the stamps go
+ms, b = m.time_kernel(kern, 1)
+nr = int(os.environ.get("LLMK_PF_PLAN", "1"))
+total = (rows // (64 * nr)) * (K // 64)
+U = -(-total // 256)
 nb = -(-total // U)
-raw = m.peek(7, nb * 40)
-t = raw.view(np.uint64).reshape(nb, 20).astype(np.float64) / 100.0   # us (100 MHz)
+u = m.peek(7, nb * 40).view(np.uint64).reshape(nb, 20)
+ok = u[:, 17] > u[:, 0]
+print("shader clock while the kernel runs: %.0f MHz (median over blocks)" % np.median((u[ok, 19] - u[ok, 18]).astype(np.float64) / ((u[ok, 17] - u[ok, 0]).astype(np.float64) / 100.0)))
+t = u.astype(np.float64) / 100.0   # us (100 MHz)
 t -= t[:, 0].min()
 pc = lambda v: "min %6.2f  med %6.2f  p90 %6.2f  max %6.2f" % tuple(np.percentile(v, [0, 50, 90, 100]))
-print("blocks", nb, "units per block", U)
-print("entry     :", pc(t[:, 0]))
-print("prologue  :", pc(t[:, 1] - t[:, 0]))
-for i in range(min(U, 16)):
-    print("step %2d   :" % i, pc(t[:, 2 + i] - t[:, 1 + i]))
-print("exit      :", pc(t[:, 1 + min(U, 16)]))
+print("blocks", nb, "units per block", U, "(assuming the forced plan applied)")
+print("entry     :", pc(t[ok, 0]))
+print("prologue  :", pc(t[ok, 1] - t[ok, 0]))
+for i in range(min(U, 15)):
+    print("step %2d   :" % i, pc(t[ok, 2 + i] - t[ok, 1 + i]))
+print("exit      :", pc(t[ok, 17]))
