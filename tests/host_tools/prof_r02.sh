@@ -56,4 +56,16 @@ for k, v in d.items():
     print(k, {c: int(statistics.mean(x)) for c, x in v.items()}, "launches", len(next(iter(v.values()))))
 PY
 done
+# batched prefill: bench line, kernel stats of the same command, GEMM block timelines, MFMA/LDS probe
+echo "=== prefill 512"
+timeout 300 python $ROOT/bench.py --prefill 512 > $OUT/prefill512_bench.json 2> $OUT/prefill512_bench.err
+cut -c1-900 $OUT/prefill512_bench.json
+rm -rf /tmp/st_pf
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_pf -- python $ROOT/bench.py --prefill 512 > /dev/null 2> /tmp/st_pf.err || tail -3 /tmp/st_pf.err
+reduce_stats /tmp/st_pf $OUT/prefill512_kernel_stats.csv
+for g in w13 wqkv wo w2; do for nr in 1 2; do
+  echo "--- $g, $nr row group(s) per wave"; LLMK_PF_PLAN=$nr LLMK_LIB=$ROOT/llm.f90_amd/csrc/libllmk_debug.so timeout 120 python $ROOT/tests/host_tools/pf_trace.py $g
+done; done > $OUT/prefill_gemm_timeline.txt 2>&1
+tail -30 $OUT/prefill_gemm_timeline.txt
+[ -x $ROOT/llm.f90_amd/csrc/probes/pf_mfma_probe ] && timeout 120 $ROOT/llm.f90_amd/csrc/probes/pf_mfma_probe > $OUT/pf_mfma_probe.txt 2>&1
 ls -la $OUT
