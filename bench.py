@@ -196,13 +196,14 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
 def prefill_line(a):
     """`--prefill N`: prompt tokens/s of llmk_prefill (batched MFMA GEMMs) next to the token-by-token loop it replaces.
     Roofline of its dominant kernel, the w1|w3 GEMM at 128 positions: f32 matrix-core peak (157.3 TFLOP/s,
-    MI355X_MICROARCH.md) -- at 128 positions per pass the GEMM is MFMA-bound (2*128 flop per 4-byte weight = 64 flop/B:
-    the matrix rate needs 2.5 TB/s of weights)."""
+    MI355X_MICROARCH.md; f16 and q4_0 weights are converted exactly to f32 A operands, same instruction) -- at 128 positions
+    per pass the GEMM is MFMA-bound (f32: 2*128 flop per 4-byte weight = 64 flop/B, the matrix rate needs 2.5 TB/s of weights)."""
     shape = gguf.SHAPES[a.shape]
     n = a.prefill
-    if a.type != "f32" or n < 1 or n + 1 > shape.seq_len:
-        raise SystemExit("--prefill N: f32 weights, N < seq_len")
-    m = llmk.Llmk(gguf.synth_fused(shape, SEED, 0))
+    if n < 1 or n + 1 > shape.seq_len:
+        raise SystemExit("--prefill N: N < seq_len")
+    wt = {"f32": 0, "f16": 1, "q4_0": 2}[a.type]
+    m = llmk.Llmk(gguf.synth_fused(shape, SEED, wt))
     rng = np.random.default_rng(SEED)
     prompt = [2] + (rng.integers(3, shape.vocab_size, n - 1) + 1).tolist()
     for _ in range(max(1, a.warmup // 4)):
@@ -218,14 +219,15 @@ def prefill_line(a):
     for pos in range(1, nseq + 1):
         m.forward(prompt[pos - 1], pos)
     dt_seq = (time.perf_counter() - t0) / nseq
-    ms, wbytes = m.time_kernel(7, 66)
-    flop = 2.0 * 128 * wbytes / 4.0
+    ms, wbytes = m.time_kernel(7, 2 * shape.n_layers)
+    flop = 2.0 * 128 * 2 * shape.hidden_dim * shape.emb_dim
+    kname = "pf_gemm_q4_kernel<4> x2" if wt == 2 else "pf_gemm_kernel<8>"
     out = {"metric": f"prompt tokens/sec {a.shape} prefill", "value": n / dt, "unit": "tokens/s", "n_gpus": 1,
            "steps": reps, "warmup": max(1, a.warmup // 4), "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": f"{a.shape} f32 prefill of a {n}-token prompt (llmk_prefill, 128 positions per pass)",
+           "config": {"workload": f"{a.shape} {a.type} prefill of a {n}-token prompt (llmk_prefill, 128 positions per pass)",
                       "token_by_token_tok_s": 1.0 / dt_seq, "speedup": (n / dt) * dt_seq, "seed": SEED},
-           "roofline": {"bound": "mfma", "kernel": "pf_gemm_kernel<8> (w1|w3, 128 positions, v_mfma_f32_16x16x4_f32)",
+           "roofline": {"bound": "mfma", "kernel": f"{kname} (w1|w3, 128 positions, v_mfma_f32_16x16x4_f32)",
                         "achieved": flop / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                         "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "us_per_launch": ms * 1000.0,
                         "flop_per_launch": flop, "weight_bytes_per_launch": wbytes,

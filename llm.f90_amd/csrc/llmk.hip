@@ -1134,7 +1134,8 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     if (kernel >= 7) {   // the prefill GEMMs at PF_TMAX positions: 7 w1|w3, 8 wqkv, 9 wo, 10 w2 (whatever the workspaces hold: timing only)
-        if (c->cfg.weight_type == LLMK_TYPE_Q4_0 || c->tp_size != 1 || c->E % PF_KSTEP || c->H % PF_KSTEP) return LLMK_E_ARG;
+        const int pf_step = c->cfg.weight_type == LLMK_TYPE_Q4_0 ? PF_KSTEP_Q4 : PF_KSTEP;
+        if (c->tp_size != 1 || c->E % pf_step || c->H % pf_step) return LLMK_E_ARG;
         rc = pf_setup(c);
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->pf_Xs, 0, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
@@ -1157,8 +1158,11 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
             PfEpiArgs e;
             const int tid = kernel == 7 ? LLMK_W13 : kernel == 8 ? LLMK_WQKV : kernel == 9 ? LLMK_WO : LLMK_W2;
             const int rows = kernel == 7 ? 2 * c->H : kernel == 8 ? c->E + 2 * c->KV : c->E;
-            return pf_gemm(c, (const char*)c->t[tid].data + (size_t)l * rows * c->t[tid].row_bytes, kernel == 10 ? c->pf_HB : c->pf_Xs,
-                           rows, kernel == 10 ? c->H : c->E, PF_TMAX, &e);
+            const char* w = (const char*)c->t[tid].data + (size_t)l * rows * c->t[tid].row_bytes;
+            const float* X = kernel == 10 ? c->pf_HB : c->pf_Xs;
+            const int K = kernel == 10 ? c->H : c->E;
+            if (c->cfg.weight_type == LLMK_TYPE_Q4_0) return pf_gemm_q4(c, w, (int)c->t[tid].row_bytes, X, rows, K, PF_TMAX, &e);
+            return pf_gemm(c, w, X, rows, K, PF_TMAX, &e);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);

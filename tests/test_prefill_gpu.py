@@ -99,7 +99,7 @@ def test_prefill_in_two_calls_and_after_decode(gguf):
 
 
 def test_prefill_tinyllama_long_prompt_vs_sequential(gguf):
-    """BASELINE.json's shape, a 150-token prompt (three batches: 64 + 64 + 22), then 8 decoded tokens on the token kernel"""
+    """BASELINE.json's shape, a 150-token prompt (two batches: 128 + 22), then 8 decoded tokens on the token kernel"""
     s = gguf.SHAPES["tinyllama"]
     fw = gguf.synth_fused(s, 20260928)
     rng = np.random.default_rng(1)
@@ -142,7 +142,8 @@ def test_prefill_falls_back_to_the_token_by_token_pass_when_the_shape_does_not_t
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-70bish", 33), ("tk-small16", 40), ("tk-small", 7)])
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-70bish", 33), ("tk-small16", 40), ("tk-small", 7),
+                                     ("tk-small-long", 100), ("tk-small-long", 150), ("tk-small-long", 300)])
 def test_prefill_q4_matches_oracle_on_decoded_weights(shape, n, gguf):
     """q4_0 matrices: the A operand of the MFMA is (nibble - 8) * d computed in registers; pinned, like the q4_0 decode
     path, to the f32 reference arithmetic on the host-decoded weights; then decoding continues from the cache"""
@@ -165,7 +166,8 @@ def test_prefill_q4_matches_oracle_on_decoded_weights(shape, n, gguf):
     m.close()
 
 
-@pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-hs64", 33), ("tk-small16", 40), ("tiny-hs128", 5)])
+@pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-hs64", 33), ("tk-small16", 40), ("tiny-hs128", 5),
+                                     ("tk-small-long", 100), ("tk-small-long", 150), ("tiny-hs128-long", 300)])
 def test_prefill_f16_matches_oracle_on_decoded_weights(shape, n, gguf):
     """f16 matrices go through the same batched MFMA GEMMs (exact half -> float conversion of the A operand): pinned, like
     the f16 decode path, to the f32 reference arithmetic on the host-decoded weights; then decoding continues from the cache"""
