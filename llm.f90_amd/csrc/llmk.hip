@@ -644,7 +644,7 @@ hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X
 template <int NG, int NR>
 hipError_t pf_gemm_launch(llmk_ctx* c, const PfGemmArgs& a, const PfPlan& p) {
     // the LDS request (> half of the CU's 160 KB) pins one workgroup per CU: every CU gets one block of equal length
-    const size_t smem = std::max((size_t)2 * NG * 16 * PF_LDW * sizeof(float), (size_t)84 * 1024);
+    const size_t smem = std::max(((size_t)2 * NG * 16 * PF_LDW + (size_t)NG * 16 * (64 * NR + PF_TPAD)) * sizeof(float), (size_t)84 * 1024);
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
     if (c->cfg.weight_type == LLMK_TYPE_F16) {
         HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));

@@ -53,16 +53,11 @@ constexpr int PF_LDW = PF_KSTEP + 4;         // LDS row pitch in floats (+16 byt
 __host__ __device__ inline int pf_first_block(int strip, int nk, int U) { return strip * nk / U; }
 __host__ __device__ inline int pf_nslots(int strip, int nk, int U) { return ((strip + 1) * nk - 1) / U - strip * nk / U + 1; }
 
-// write the wave's partial tile (D layout of 16x16x4: lane l, register v <-> weight row 4*(l/16)+v, token l%16) and clear it
-template <int NG>
-__device__ __forceinline__ void pf_flush(pf_v4f (&acc)[NG], bool active, float* dst, int rows) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (active) *reinterpret_cast<float4*>(dst + (size_t)g * 16 * rows) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
-        acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
-    }
-}
-
+// The block's partial tile goes to P through LDS.  In the accumulators (D layout of 16x16x4: lane l, register v <-> weight
+// row 4*(l/16)+v, token l%16) a wave's store instruction would touch 16 positions x 64 bytes; written to LDS as
+// [position][strip row] and read back row-major, every store instruction writes whole 512-byte (256 with one row group)
+// runs of P[slot][position][rows].  All CUs flush at about the same time: scattered, a workgroup's 64 KB took 2.2 us.
+constexpr int PF_TPAD = 4;     // floats of padding per position in the transpose buffer
 // f16 weights: a lane's 16 bytes are 8 columns, so a chunk is 32 columns (8 MFMA steps after the exact half -> float
 // conversion) and a 64-column step has two chunks; the activation side is f32 either way.
 //
@@ -235,8 +230,19 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
         PF_WNEXT();                                                                                                  \
         if ((S_) < nsteps && (++ck == a.nk || (S_) == nsteps - 1)) {                                                 \
             const int slot = (int)blockIdx.x - pf_first_block(cs, a.nk, a.U);                                        \
-            float* dst_ = a.P + ((size_t)slot * TP + li) * a.rows + cs * SR + wid * (16 * NR) + (lane >> 4) * 4;     \
-            _Pragma("unroll") for (int r = 0; r < NR; ++r) pf_flush<NG>(acc[r], active, dst_ + r * 16, a.rows);      \
+            float* tb_ = xs + 2 * TP * PF_LDW;                      /* [TP][SR + PF_TPAD] */                           \
+            _Pragma("unroll") for (int r = 0; r < NR; ++r)                                                           \
+                _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                     \
+                    *reinterpret_cast<pf_v4f*>(tb_ + (g * 16 + li) * (SR + PF_TPAD) + wid * (16 * NR) + r * 16 + (lane >> 4) * 4) = acc[r][g]; \
+                    acc[r][g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};                                                        \
+                }                                                                                                    \
+            __syncthreads();                                                                                         \
+            float* dst_ = a.P + (size_t)slot * TP * a.rows + cs * SR;                                                \
+            _Pragma("unroll") for (int k = 0; k < TP * SR / 4 / NT; ++k) {                                           \
+                const int idx_ = tid + k * NT, t_ = idx_ / (SR / 4), c_ = idx_ % (SR / 4) * 4;                       \
+                const pf_v4f v_ = *reinterpret_cast<const pf_v4f*>(tb_ + t_ * (SR + PF_TPAD) + c_);                  \
+                if (cs * SR + c_ < a.rows) *reinterpret_cast<pf_v4f*>(dst_ + (size_t)t_ * a.rows + c_) = v_;         \
+            }                                                                                                        \
             ck = 0;                                                                                                  \
             ++cs;                                                                                                    \
             active = cs * SR + wid * (16 * NR) < a.rows;                                                             \
