@@ -221,7 +221,7 @@ def prefill_line(a):
     dt_seq = (time.perf_counter() - t0) / nseq
     ms, wbytes = m.time_kernel(7, 2 * shape.n_layers)
     flop = 2.0 * 128 * 2 * shape.hidden_dim * shape.emb_dim
-    kname = "pf_gemm_q4_kernel<4> x2" if wt == 2 else "pf_gemm_kernel<8>"
+    kname = f"pf_gemm_kernel<8, {a.type}>"
     out = {"metric": f"prompt tokens/sec {a.shape} prefill", "value": n / dt, "unit": "tokens/s", "n_gpus": 1,
            "steps": reps, "warmup": max(1, a.warmup // 4), "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",

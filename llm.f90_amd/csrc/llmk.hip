@@ -543,17 +543,7 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
 }
 
 // ---- batched prefill (prefill.h) ------------------------------------------------------------------------
-// q4_0 GEMM: K slices -- enough (64-row strip x slice) blocks for >= 2 per CU, slices whole multiples of the step
-void pf_split(const llmk_ctx* c, int rows, int K, int* ks_out, int* kslice_out) {
-    const int strips = (rows + 63) / 64;
-    const int step = PF_KSTEP_Q4;
-    int ks = (2 * c->n_cu + strips - 1) / strips;
-    int kslice = ((K + ks - 1) / ks + step - 1) / step * step;
-    if (kslice < 2 * step) kslice = 2 * step;
-    *kslice_out = kslice;
-    *ks_out = (K + kslice - 1) / kslice;
-}
-// f32 / f16 GEMM: row groups per wave, units per block and workgroups per CU (prefill.h PfGemmArgs).  Every candidate
+// GEMM plan: row groups per wave, units per block and workgroups per CU (prefill.h PfGemmArgs).  Every candidate
 // is priced with the measured step times (tests/host_tools/pf_trace.py, round 2): a step of NR row groups at 128
 // positions keeps a SIMD's matrix core busy for 1.7*NR us per resident wave, plus ~0.5 us of barrier / staging per step;
 // the first weights take ~4 us to arrive and every partial tile costs a write and a read in the epilogue.
@@ -593,13 +583,7 @@ int pf_setup(llmk_ctx* c) {
     size_t pcap = 0;
     const int Ks[4] = {c->E, c->E, c->E, c->H};
     for (int i = 0; i < 4; ++i) {
-        if (c->cfg.weight_type == LLMK_TYPE_Q4_0) {
-            int ks, kslice;
-            pf_split(c, rows[i], Ks[i], &ks, &kslice);
-            pcap = std::max(pcap, (size_t)ks * T * rows[i]);
-        } else {
-            pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
-        }
+        pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
     }
     HIPCHK(hipMalloc(&c->pf_X, T * c->E * sizeof(float)));
     HIPCHK(hipMalloc(&c->pf_Xs, T * c->E * sizeof(float)));
@@ -611,42 +595,15 @@ int pf_setup(llmk_ctx* c) {
     HIPCHK(hipMalloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
     return LLMK_OK;
 }
-// P[ks][Tp][rows] = X[T][K] . W[rows][K]^T over K slices; the epilogue's partial count goes to e->KS
-// q4_0: rows of nibbles + scales (row_stride bytes apart); a pass of more than 64 positions is two launches
-hipError_t pf_gemm_q4(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
-    int ks, kslice;
-    pf_split(c, rows, K, &ks, &kslice);
-    e->KS = ks; e->U = 0; e->nk = 0; e->sh = 6;
-    const int Tp = (T + 15) / 16 * 16;
-    for (int t0 = 0; t0 < T; t0 += 64) {
-        PfGemmQ4Args a;
-        a.W = (const char*)W; a.RS = row_stride; a.X = X + (size_t)t0 * K; a.P = c->pf_P + (size_t)t0 * rows;
-        a.rows = rows; a.K = K; a.T = std::min(64, T - t0); a.Tp = Tp; a.kslice = kslice;
-        const dim3 grid((rows + 63) / 64, ks), block(PF_WAVES * WAVE);
-        const int NG = (a.T + 15) / 16;
-        const size_t smem = (size_t)2 * NG * 16 * PF_LDW_Q4 * sizeof(float);
-#define PFQ(NG_)                                                                                                              \
-    do {                                                                                                                      \
-        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_q4_kernel<NG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(pf_gemm_q4_kernel<NG_>, grid, block, smem, c->stream, a);                                          \
-    } while (0)
-        switch (NG) {
-            case 1: PFQ(1); break;
-            case 2: PFQ(2); break;
-            case 3: PFQ(3); break;
-            default: PFQ(4); break;
-        }
-#undef PFQ
-        HIPRET(hipGetLastError());
-    }
-    return hipSuccess;
-}
 template <int NG, int NR>
 hipError_t pf_gemm_launch(llmk_ctx* c, const PfGemmArgs& a, const PfPlan& p) {
     // the LDS request (> half of the CU's 160 KB) pins one workgroup per CU: every CU gets one block of equal length
     const size_t smem = std::max(((size_t)2 * NG * 16 * PF_LDW + (size_t)NG * 16 * (64 * NR + PF_TPAD)) * sizeof(float), (size_t)84 * 1024);
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
-    if (c->cfg.weight_type == LLMK_TYPE_F16) {
+    if (c->cfg.weight_type == LLMK_TYPE_Q4_0) {
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_Q4_0, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, c->stream, a);
+    } else if (c->cfg.weight_type == LLMK_TYPE_F16) {
         HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, c->stream, a);
     } else {
@@ -655,10 +612,10 @@ hipError_t pf_gemm_launch(llmk_ctx* c, const PfGemmArgs& a, const PfPlan& p) {
     }
     return hipGetLastError();
 }
-hipError_t pf_gemm(llmk_ctx* c, const void* W, const float* X, int rows, int K, int T, PfEpiArgs* e) {
+hipError_t pf_gemm(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
     const PfPlan p = pf_plan(c, rows, K);
     PfGemmArgs a;
-    a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T;
+    a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T; a.RS = row_stride;
     a.nk = p.nk; a.U = p.U; a.total = p.total;
 #ifdef LLMK_PF_TRACE
     a.trace = (unsigned long long*)c->pf_HB;     // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
@@ -687,9 +644,7 @@ hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
         auto gemm = [&](int tid, int rows_per_layer, const float* X, int K) -> hipError_t {
             const DevTensor& dt = c->t[tid];
             const char* w = (const char*)dt.data + (size_t)l * rows_per_layer * dt.row_bytes;
-            if (c->cfg.weight_type == LLMK_TYPE_Q4_0)
-                return pf_gemm_q4(c, w, (int)dt.row_bytes, X, rows_per_layer, K, T, &e);
-            return pf_gemm(c, w, X, rows_per_layer, K, T, &e);
+            return pf_gemm(c, w, (int)dt.row_bytes, X, rows_per_layer, K, T, &e);
         };
         float* kc = c->d_kc + (size_t)l * c->S * KV;
         float* vc = c->d_vc + (size_t)l * c->S * KV;
@@ -1075,7 +1030,7 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     if (rc) return rc;
     for (int i = 0; i < n; ++i)
         if (tokens[i] < 1 || tokens[i] > c->V) return LLMK_E_ARG;
-    const int pf_step = c->cfg.weight_type == LLMK_TYPE_Q4_0 ? PF_KSTEP_Q4 : PF_KSTEP;
+    const int pf_step = PF_KSTEP;
     const bool batched = c->tp_size == 1 && !c->comm && c->E % pf_step == 0 && c->H % pf_step == 0 && c->KV % 16 == 0 && !(getenv("LLMK_PREFILL") && getenv("LLMK_PREFILL")[0] == '0');
     if (!batched) {
         for (int i = 0; i < n; ++i) {
@@ -1134,7 +1089,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
     if (kernel >= 7) {   // the prefill GEMMs at PF_TMAX positions: 7 w1|w3, 8 wqkv, 9 wo, 10 w2 (whatever the workspaces hold: timing only)
-        const int pf_step = c->cfg.weight_type == LLMK_TYPE_Q4_0 ? PF_KSTEP_Q4 : PF_KSTEP;
+        const int pf_step = PF_KSTEP;
         if (c->tp_size != 1 || c->E % pf_step || c->H % pf_step) return LLMK_E_ARG;
         rc = pf_setup(c);
         if (rc) return rc;
@@ -1161,8 +1116,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
             const char* w = (const char*)c->t[tid].data + (size_t)l * rows * c->t[tid].row_bytes;
             const float* X = kernel == 10 ? c->pf_HB : c->pf_Xs;
             const int K = kernel == 10 ? c->H : c->E;
-            if (c->cfg.weight_type == LLMK_TYPE_Q4_0) return pf_gemm_q4(c, w, (int)c->t[tid].row_bytes, X, rows, K, PF_TMAX, &e);
-            return pf_gemm(c, w, X, rows, K, PF_TMAX, &e);
+            return pf_gemm(c, w, (int)c->t[tid].row_bytes, X, rows, K, PF_TMAX, &e);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);

@@ -42,6 +42,7 @@ struct PfGemmArgs {
     int nk;              // 64-column steps per strip = K / PF_KSTEP
     int U;               // units per block
     int total;           // strips * nk   (strip = 64 rows, or 128 with two row groups per wave)
+    int RS;              // q4_0: bytes between rows (K/2 nibble bytes, then the row's f16 scales: llmk.hip q4_row_stride)
 #ifdef LLMK_PF_TRACE
     unsigned long long* trace;   // [grid][20] wall-clock stamps: entry, prologue done, end of steps 0..14; [17] exit, [18],[19] shader clock at entry / exit
 #endif
@@ -70,10 +71,11 @@ template <int NG, int WT, int NR>
 __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) {
     constexpr int NW = PF_WAVES;
     constexpr int TP = NG * 16;
-    constexpr int BW = (WT == WT_F16) ? 2 : 4;          // bytes per weight
-    constexpr int CPL = 16 / BW;                          // columns per lane load: 4 / 8
-    constexpr int CW = 4 * CPL;                           // columns per chunk (4 lane groups): 16 / 32
-    constexpr int NJ = PF_KSTEP / CW;                     // chunks per step: 4 / 2
+    constexpr bool Q4 = WT == WT_Q4_0;
+    constexpr int BW = (WT == WT_F16) ? 2 : 4;          // bytes per weight (f32 / f16)
+    constexpr int CPL = Q4 ? 16 : 16 / BW;                // columns per lane load: 4 / 8 / 16 (half a q4_0 block)
+    constexpr int CW = 4 * CPL;                           // columns per chunk (4 lane groups): 16 / 32 / 64
+    constexpr int NJ = PF_KSTEP / CW;                     // chunks per step: 4 / 2 / 1
     constexpr int SR = 16 * NR * NW;                      // rows per strip
     constexpr int NT = NW * WAVE;                         // threads
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
@@ -82,12 +84,18 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     const int u0 = blockIdx.x * a.U, nsteps = min(a.U, a.total - u0);
     if (nsteps <= 0) return;                          // whole block: no barrier is pending
     const int li = lane & 15, lk = (lane >> 4) * CPL;
-    const size_t rowb = (size_t)a.K * BW;
-    const char* wbase = static_cast<const char*>(a.W) + (size_t)lk * BW;
+    // q4_0: a 64-column step is two 32-weight blocks; lane group q = lane/16 takes columns 16q .. 16q+15 = the low (q even)
+    // or high (q odd) nibbles of all 16 bytes of block q/2 -- both groups of a block load the same 16 bytes
+    const size_t rowb = Q4 ? (size_t)a.RS : (size_t)a.K * BW;
+    const char* wbase = static_cast<const char*>(a.W) + (Q4 ? (size_t)(lane >> 5) * 16 : (size_t)lk * BW);
+    constexpr int STEPB = Q4 ? 32 : PF_KSTEP * BW;        // weight bytes per row per step
+    const bool hi_nib = (lane >> 4) & 1;
+    const unsigned nib_mask = hi_nib ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
     // cursors over the block's units: weights run ahead of the MFMAs, activations one step
     int cs = u0 / a.nk, ck = u0 % a.nk;                   // strip / column step being multiplied
     int ws = cs, wk = ck, wi = 0, xk = ck, xi = 0;
-    const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * (PF_KSTEP * BW);
+#define wkl wk
+    const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * STEPB;
     bool active = cs * SR + wid * (16 * NR) < a.rows;     // ragged last strip (NR 1): idle waves still take the barriers
     // activation staging: thread -> (token, 16-byte column group) of the TP x 64 tile, TP*16/256 vectors per thread
     constexpr int XN = TP * (PF_KSTEP / 4), XV = (XN + NT - 1) / NT;   // XN % NT = 0 or NT/2 (odd NG, 8 waves)
@@ -113,11 +121,17 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     // about to be multiplied might be the newest load -- s_waitcnt vmcnt(0) at the top of every step, no weights in
     // flight across a step at all (round-2 ISA reading).
     float4 w0[NR * NJ], w1[NR * NJ], w2[NR == 1 ? NJ : 1];
+    float w0d[NR], w1d[NR], w2d[1];                      // q4_0: the block scale that belongs to the stage
     pf_v4f xr[XV];
 #define PF_WLOAD_PART(W_, LO_, HI_)                                                                                  \
     do {                                                                                                             \
-        _Pragma("unroll") for (int q = (LO_); q < (HI_); ++q)                                                        \
-            W_[q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * CW * BW));  \
+        _Pragma("unroll") for (int q = (LO_); q < (HI_); ++q) {                                                      \
+            W_[q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (Q4 ? 0 : (q % NJ) * CW * BW))); \
+            if constexpr (Q4) {                                                                                      \
+                const char* rp_ = wp + (size_t)q * 16 * rowb - (size_t)(lane >> 5) * 16 - (size_t)wkl * 32;           \
+                W_##d[q] = __half2float(reinterpret_cast<const __half*>(rp_ + (a.K >> 1))[2 * wkl + (lane >> 5)]);   \
+            }                                                                                                        \
+        }                                                                                                            \
     } while (0)
 #define PF_WNEXT()                                                                                                   \
     do {                                                                                                             \
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
         wk = wrap_ ? 0 : wk;                                                                                         \
         ws += wrap_ ? 1 : 0;                                                                                         \
         const char* nxt_ = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb;                   \
-        wp = wrap_ ? nxt_ : wp + adv_ * (PF_KSTEP * BW);                                                             \
+        wp = wrap_ ? nxt_ : wp + adv_ * STEPB;                                                                       \
     } while (0)
 #define PF_WLOAD(W_)                                                                                                 \
     do {                                                                                                             \
@@ -157,13 +171,18 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
             if (i < XV - 1 || XN % NT == 0 || xlast) *reinterpret_cast<pf_v4f*>(xs + (BUF_) * TP * PF_LDW + xo[i]) = xr[i]; \
     } while (0)
     // a quarter of a step: 16 columns, one float4 of activations per token group (f16: half of a 32-column chunk)
-    auto piece = [&](const float4 (&wc)[NR * NJ], int buf, int pc) {
+    auto piece = [&](const float4 (&wc)[NR * NJ], const float (&wd)[NR == 1 ? 1 : NR], int buf, int pc) {
         const float* xb = xs + buf * TP * PF_LDW;
         const int j = pc / (CPL / 4), h = pc % (CPL / 4);
         float4 w[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            if constexpr (WT == WT_F16) {
+            if constexpr (Q4) {
+                // (n - 8) * d exactly as the decode path computes it: n * d - 8 d in f32; the high nibbles are read as 16 n
+                const unsigned qd = (h == 0 ? __float_as_uint(wc[r].x) : h == 1 ? __float_as_uint(wc[r].y) : h == 2 ? __float_as_uint(wc[r].z) : __float_as_uint(wc[r].w)) & nib_mask;
+                const float d = hi_nib ? wd[r] * 0.0625f : wd[r], m8 = -8.0f * wd[r];
+                w[r] = make_float4(fmaf(cvt_ubyte<0>(qd), d, m8), fmaf(cvt_ubyte<1>(qd), d, m8), fmaf(cvt_ubyte<2>(qd), d, m8), fmaf(cvt_ubyte<3>(qd), d, m8));
+            } else if constexpr (WT == WT_F16) {
                 const __half2 p0 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[r * NJ + j].x : &wc[r * NJ + j].z);
                 const __half2 p1 = *reinterpret_cast<const __half2*>(h == 0 ? &wc[r * NJ + j].y : &wc[r * NJ + j].w);
                 w[r] = make_float4(__low2float(p0), __high2float(p0), __low2float(p1), __high2float(p1));
@@ -215,17 +234,17 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     {                                                                                                                \
         const bool mul_ = active && (S_) < nsteps;                                                                   \
         PF_XSTORE(((S_) + 1) & 1);                                                                                   \
-        if (mul_) piece(CUR_, (S_) & 1, 0);                                                                          \
+        if (mul_) piece(CUR_, CUR_##d, (S_) & 1, 0);                                                                          \
         PF_XLOAD_PART(0, XV / 2);                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if (mul_) piece(CUR_, (S_) & 1, 1);                                                                          \
+        if (mul_) piece(CUR_, CUR_##d, (S_) & 1, 1);                                                                          \
         PF_XLOAD_PART(XV / 2, XV);                                                                                   \
         PF_XNEXT();                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if (mul_) piece(CUR_, (S_) & 1, 2);                                                                          \
+        if (mul_) piece(CUR_, CUR_##d, (S_) & 1, 2);                                                                          \
         PF_WLOAD_PART(NXT_, 0, NR * NJ / 2);                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
-        if (mul_) piece(CUR_, (S_) & 1, 3);                                                                          \
+        if (mul_) piece(CUR_, CUR_##d, (S_) & 1, 3);                                                                          \
         PF_WLOAD_PART(NXT_, NR * NJ / 2, NR * NJ);                                                                   \
         PF_WNEXT();                                                                                                  \
         if ((S_) < nsteps && (++ck == a.nk || (S_) == nsteps - 1)) {                                                 \
@@ -273,122 +292,8 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
 #undef PF_XLOAD
 #undef PF_XLOAD_PART
 #undef PF_XNEXT
+#undef wkl
 #undef PF_XSTORE
-}
-
-// ---- q4_0 weights (device layout of llmk_upload: rows of K/2 nibble bytes + K/32 f16 scales, RS bytes apart) -----------
-// A lane load is ONE block: 16 bytes of nibbles = 32 columns of its row, plus the block's scale; the 4 lane groups of a
-// wave cover 4 blocks = 128 columns, which is the pipeline step.  Byte j of a block holds element j (low nibble) and
-// element 16+j (high nibble); the A operand of MFMA step (dword i, byte c) is (n-8)*d computed exactly as the decode
-// path does ((n - 8) * d in f32), against X[t][k0 + 4i + c] (low) and X[t][k0 + 16 + 4i + c] (high).
-constexpr int PF_KSTEP_Q4 = 128;
-constexpr int PF_LDW_Q4 = PF_KSTEP_Q4 + 4;
-
-struct PfGemmQ4Args {
-    const char* W;       // [rows] x RS bytes: K/32 blocks of 16 nibble bytes, then K/32 f16 scales
-    int RS;              // row stride in bytes
-    const float* X;      // [T][K]
-    float* P;            // [KS][Tp][rows]
-    int rows, K, T;
-    int Tp;              // token pitch of P (a 128-position pass is two launches of 64)
-    int kslice;          // columns per K slice (multiple of PF_KSTEP_Q4)
-};
-
-template <int NG>
-__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_q4_kernel(PfGemmQ4Args a) {
-    constexpr int TP = NG * 16;
-    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    float* xs = reinterpret_cast<float*>(pf_smem);                    // [2][TP][PF_LDW_Q4]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int row0 = blockIdx.x * 64 + wid * 16, ks = blockIdx.y;
-    const int kb = ks * a.kslice, ke = min(a.K, kb + a.kslice);
-    const int nsteps = (ke - kb) / PF_KSTEP_Q4;
-    const int li = lane & 15, lg = lane >> 4;                         // row of the strip, block of the step
-    const bool active = row0 < a.rows;
-    const int nblk = a.K >> 5;
-    const char* rowp = a.W + (size_t)min(row0 + li, a.rows - 1) * a.RS;
-    const uint4* Wn = reinterpret_cast<const uint4*>(rowp);
-    const __half* Sc = reinterpret_cast<const __half*>(rowp + (a.K >> 1));
-    const size_t wrow = (size_t)(kb >> 5) + lg;
-    (void)nblk;
-    constexpr int XV = TP * (PF_KSTEP_Q4 / 4) / (PF_WAVES * WAVE);
-    const float* xg[XV];
-    int xo[XV];
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const int idx = tid + i * PF_WAVES * WAVE, t = idx / (PF_KSTEP_Q4 / 4), c4 = idx % (PF_KSTEP_Q4 / 4);
-        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + kb + c4 * 4;
-        xo[i] = t * PF_LDW_Q4 + c4 * 4;
-    }
-    pf_v4f acc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
-
-    uint4 wc = ldg_nt(Wn + wrow), wn;
-    __half dc = Sc[wrow], dn;
-    float4 xr[XV];
-#pragma unroll
-    for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i]);
-#pragma unroll
-    for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(xs + xo[i]) = xr[i];
-    __syncthreads();
-
-    for (int s = 0; s < nsteps; ++s) {
-        const int sn = min(s + 1, nsteps - 1);                          // clamped: the loads stay unconditional
-        wn = ldg_nt(Wn + wrow + sn * (PF_KSTEP_Q4 / 32));
-        dn = Sc[wrow + sn * (PF_KSTEP_Q4 / 32)];
-#pragma unroll
-        for (int i = 0; i < XV; ++i) xr[i] = *reinterpret_cast<const float4*>(xg[i] + sn * PF_KSTEP_Q4);
-        const float* xb = xs + (s & 1) * TP * PF_LDW_Q4;
-        if (active) {
-            const float d = __half2float(dc), d16 = d * 0.0625f, m8 = -8.0f * d;
-            const unsigned q[4] = {wc.x, wc.y, wc.z, wc.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned lo = q[i] & 0x0F0F0F0Fu, hi = q[i] & 0xF0F0F0F0u;     // hi bytes = 16 * nibble
-                float4 xl[NG], xh[NG];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const float* xrow = xb + (g * 16 + li) * PF_LDW_Q4 + lg * 32 + 4 * i;
-                    xl[g] = *reinterpret_cast<const float4*>(xrow);
-                    xh[g] = *reinterpret_cast<const float4*>(xrow + 16);
-                }
-                const float a0 = fmaf(cvt_ubyte<0>(lo), d, m8), a1 = fmaf(cvt_ubyte<1>(lo), d, m8);
-                const float a2 = fmaf(cvt_ubyte<2>(lo), d, m8), a3 = fmaf(cvt_ubyte<3>(lo), d, m8);
-                const float b0 = fmaf(cvt_ubyte<0>(hi), d16, m8), b1 = fmaf(cvt_ubyte<1>(hi), d16, m8);
-                const float b2 = fmaf(cvt_ubyte<2>(hi), d16, m8), b3 = fmaf(cvt_ubyte<3>(hi), d16, m8);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, xl[g].x, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, xl[g].y, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, xl[g].z, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, xl[g].w, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, xh[g].x, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, xh[g].y, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b2, xh[g].z, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(b3, xh[g].w, acc[g], 0, 0, 0);
-            }
-        }
-        float* xw = xs + ((s + 1) & 1) * TP * PF_LDW_Q4;
-#pragma unroll
-        for (int i = 0; i < XV; ++i) *reinterpret_cast<float4*>(xw + xo[i]) = xr[i];
-        wc = wn;
-        dc = dn;
-        __syncthreads();
-    }
-    if (active) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            float* dst = a.P + ((size_t)ks * a.Tp + g * 16 + li) * a.rows + row0 + (lane >> 4) * 4;
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[g].x, acc[g].y, acc[g].z, acc[g].w);
-        }
-    }
 }
 
 // x[t] = token_embedding_table(:, token_t)                                              llama2.f90:520
@@ -560,7 +465,7 @@ struct PfEpiArgs {
     float* kc;           // QKV: this layer's caches [S][KV]
     float* vc;
     const float* rope;   // [hs/2]
-    int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0;  KS: partials per row (uniform K slices, q4_0 GEMM)
+    int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0;  KS: partials per row when U == 0 (uniform K slices)
     int U, nk, sh;               // U > 0: unit-balanced GEMM (PfGemmArgs), the strip r >> sh has pf_nslots partials
     int E, KV, hs, H;
 };

@@ -130,9 +130,9 @@ def test_prefill_argument_errors(gguf):
 
 
 def test_prefill_falls_back_to_the_token_by_token_pass_when_the_shape_does_not_tile(gguf):
-    """q4_0 with a hidden size that is not a multiple of the 128-column step (tiny-hs64: H = 704): llmk_prefill runs the
+    """a hidden size that is not a multiple of the 64-column step (tiny-mha: H = 352): llmk_prefill runs the
     token-by-token pass inside and is bit-identical to llmk_forward"""
-    fw = gguf.synth_fused(gguf.SHAPES["tiny-hs64"], 4242, 2)
+    fw = gguf.synth_fused(gguf.SHAPES["tiny-mha"], 4242, 2)
     prompt = [2, 40, 41, 42, 43]
     a = llmk.Llmk(fw)
     for pos, tok in enumerate(prompt, 1):
@@ -143,7 +143,7 @@ def test_prefill_falls_back_to_the_token_by_token_pass_when_the_shape_does_not_t
 
 
 @pytest.mark.parametrize("shape,n", [("tiny-gqa", 19), ("tiny-70bish", 33), ("tk-small16", 40), ("tk-small", 7),
-                                     ("tk-small-long", 100), ("tk-small-long", 150), ("tk-small-long", 300)])
+                                     ("tk-small-long", 100), ("tk-small-long", 150), ("tk-small-long", 300), ("tiny-hs64", 33)])
 def test_prefill_q4_matches_oracle_on_decoded_weights(shape, n, gguf):
     """q4_0 matrices: the A operand of the MFMA is (nibble - 8) * d computed in registers; pinned, like the q4_0 decode
     path, to the f32 reference arithmetic on the host-decoded weights; then decoding continues from the cache"""
