@@ -164,9 +164,9 @@ int llmk_forward(llmk_ctx *ctx, int token, int pos, float *logits_out);
 /* The prompt loop of llama2.f90:376-402 as ONE call: tokens[0..n) (1-based ids) sit at
  * positions pos0 .. pos0+n-1 (1-based); their KV-cache rows are written and logits_out[vocab_size] receives the
  * logits of the LAST position -- what n llmk_forward calls would leave behind, within the 1e-4 parity bar (only the
- * order of the dot-product partial sums differs).  single-GPU contexts (f32, f16, q4_0) batch up to 64 positions per pass
+ * order of the dot-product partial sums differs).  single-GPU contexts (f32, f16, q4_0) batch up to 128 positions per pass
  * through MFMA GEMMs (a layer's weights cross HBM once per batch); tensor-parallel contexts, and shapes whose emb_dim /
- * hidden_dim is not a multiple of the GEMM's column step (64; 128 for q4_0), run the token-by-token pass inside. */
+ * hidden_dim is not a multiple of the GEMM's 64-column step, run the token-by-token pass inside. */
 int llmk_prefill(llmk_ctx* ctx, const int* tokens, int n, int pos0, float* logits_out);
 
 /* Same pass, but the temperature-0 consumer (`token = maxloc(logits,DIM=1)`, llama2.f90:388) runs
@@ -185,8 +185,8 @@ int llmk_timings(llmk_ctx *ctx, float ms[5]);
  * ctx's stream with HIP events around them and returns the average milliseconds per launch and
  * the algorithmic bytes one launch moves.  kernel: 0 qkv, 1 attention, 2 wo, 3 w13, 4 w2,
  * 5 classifier (successive launches walk the layers), 6 the persistent whole-token kernel
- * (LLMK_E_ARG when the ctx runs the multi-kernel path), 7 the w1|w3 GEMM of llmk_prefill at 64 positions
- * (bytes = the layer's w1|w3 weights; flop = 2 * 64 * bytes / 4). */
+ * (LLMK_E_ARG when the ctx runs the multi-kernel path), 7..10 the w1|w3, wqkv, wo, w2 GEMMs of llmk_prefill at 128 positions
+ * (bytes = that matrix of one layer; flop = 2 * 128 * rows * K). */
 int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double *bytes_per_launch);
 
 /* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),
