@@ -102,7 +102,14 @@ struct TkShape {
     static constexpr int LPR_E = (E + SEGW - 1) / SEGW, LPR_H = (H + SEGW - 1) / SEGW;   // 1 KB segments per row (q4_0: last may be ragged)
     static constexpr int NBLK_E = E / 32, NBLK_H = H / 32;               // q4_0 blocks per row
     static constexpr int NBP_E = NBLK_E + 1, NBP_H = NBLK_H + 1;         // q4_0: pitch (in float4) of the transposed x image in LDS
-    static constexpr int NB = Q4 ? 3 : 5;                                // ring depth (q4_0: 4 would spill, 237 VGPRs at 3)
+    // ring depth = tiles per streaming wave requested ahead of the dots.  Deeper is not better: what is queued at the memory
+    // controllers when a phase ends is what the next exchange's polls wait behind.  f32 (streaming-bound): 5 (4: -2.6 %);
+    // f16 (exchange-bound, half the bytes per tile-time): 4 (5: 1,710 tok/s, 4: 1,855, 3: 1,808, 6 spills);
+    // q4_0: 3 (4 would spill, 237 VGPRs at 3).
+#ifndef LLMK_NB_Q4
+#define LLMK_NB_Q4 3
+#endif
+    static constexpr int NB = Q4 ? LLMK_NB_Q4 : (WT == WT_F16 ? 4 : 5);
     // COOP (q4_0): all eight waves gather the phase's input vector, one eighth each, and the tiles are requested from
     // inside the dot products (tk_step).  The dequantise-and-dot of a q4_0 tile takes 1.9 us, so the loads' issue hides
     // behind ALU work instead of behind the exchange, and a wave that polls right after its phase has almost nothing of
