@@ -368,33 +368,42 @@ __global__ __launch_bounds__(PF_ATT_WAVES * WAVE) void pf_attn_kernel(const floa
     const float* kb = kc + (size_t)kvh * HS + g * DG;
     const float* vb = vc + (size_t)kvh * HS + NT * li;
     const int ntile = (nrows + 15) >> 4;
+    // K / V fragments of a tile are requested one tile ahead (unconditional loads of a clamped tile index): a tile's two
+    // dozen MFMAs and its softmax take far less than an L2 round trip
+    float kn[DG], vn[4][NT];
+#define PF_ATT_LOAD(R0_)                                                                                  \
+    do {                                                                                                  \
+        const float* kp_ = kb + (size_t)min((R0_) + li, nrows - 1) * KV;                                  \
+        _Pragma("unroll") for (int m = 0; m < DG; m += 4) {                                               \
+            const float4 v_ = *reinterpret_cast<const float4*>(kp_ + m);                                  \
+            kn[m] = v_.x; kn[m + 1] = v_.y; kn[m + 2] = v_.z; kn[m + 3] = v_.w;                           \
+        }                                                                                                 \
+        _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                   \
+            const float* vp_ = vb + (size_t)min((R0_) + 4 * g + v, nrows - 1) * KV;                       \
+            if constexpr (NT % 4 == 0) {                                                                  \
+                _Pragma("unroll") for (int t = 0; t < NT; t += 4) {                                       \
+                    const float4 x_ = *reinterpret_cast<const float4*>(vp_ + t);                          \
+                    vn[v][t] = x_.x; vn[v][t + 1] = x_.y; vn[v][t + 2] = x_.z; vn[v][t + 3] = x_.w;       \
+                }                                                                                         \
+            } else if constexpr (NT == 2) {                                                               \
+                const float2 x_ = *reinterpret_cast<const float2*>(vp_);                                  \
+                vn[v][0] = x_.x; vn[v][1] = x_.y;                                                         \
+            } else {                                                                                      \
+                vn[v][0] = vp_[0];                                                                        \
+            }                                                                                             \
+        }                                                                                                 \
+    } while (0)
+    PF_ATT_LOAD(min(wid, ntile - 1) << 4);
     for (int kt = wid; kt < ntile; kt += NW) {
         const int r0 = kt << 4;
         float kf[DG], vf[4][NT];
-        {
-            const float* kp = kb + (size_t)min(r0 + li, nrows - 1) * KV;
 #pragma unroll
-            for (int m = 0; m < DG; m += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(kp + m);
-                kf[m] = v.x; kf[m + 1] = v.y; kf[m + 2] = v.z; kf[m + 3] = v.w;
-            }
-        }
+        for (int m = 0; m < DG; ++m) kf[m] = kn[m];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float* vp = vb + (size_t)min(r0 + 4 * g + v, nrows - 1) * KV;
-            if constexpr (NT % 4 == 0) {
+        for (int v = 0; v < 4; ++v)
 #pragma unroll
-                for (int t = 0; t < NT; t += 4) {
-                    const float4 x = *reinterpret_cast<const float4*>(vp + t);
-                    vf[v][t] = x.x; vf[v][t + 1] = x.y; vf[v][t + 2] = x.z; vf[v][t + 3] = x.w;
-                }
-            } else if constexpr (NT == 2) {
-                const float2 x = *reinterpret_cast<const float2*>(vp);
-                vf[v][0] = x.x; vf[v][1] = x.y;
-            } else {
-                vf[v][0] = vp[0];
-            }
-        }
+            for (int t = 0; t < NT; ++t) vf[v][t] = vn[v][t];
+        PF_ATT_LOAD(min(kt + NW, ntile - 1) << 4);
         pf_v4f acc = (pf_v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < DG; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[m], qf[m], acc, 0, 0, 0);
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(PF_ATT_WAVES * WAVE) void pf_attn_kernel(const floa
 #pragma unroll
             for (int v = 0; v < 4; ++v) O[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[v], vf[v][t], O[t], 0, 0, 0);
     }
+#undef PF_ATT_LOAD
     if (g == 0) {
         sm[wid * 16 + li] = m_run;
         sl[wid * 16 + li] = l_run;
