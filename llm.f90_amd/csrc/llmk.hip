@@ -620,7 +620,7 @@ hipError_t pf_gemm(llmk_ctx* c, const void* W, int row_stride, const float* X, i
 #ifdef LLMK_PF_TRACE
     a.trace = (unsigned long long*)c->pf_HB;     // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
 #endif
-    e->KS = 0; e->U = p.U; e->nk = p.nk; e->sh = p.nr == 2 ? 7 : 6;
+    e->U = p.U; e->nk = p.nk; e->sh = p.nr == 2 ? 7 : 6;
 #define PF_CASE(NG_)                                                                         \
     case NG_: return p.nr == 2 ? pf_gemm_launch<NG_, 2>(c, a, p) : pf_gemm_launch<NG_, 1>(c, a, p)
     switch ((T + 15) / 16) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
     const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * STEPB;
     bool active = cs * SR + wid * (16 * NR) < a.rows;     // ragged last strip (NR 1): idle waves still take the barriers
     // activation staging: thread -> (token, 16-byte column group) of the TP x 64 tile, TP*16/256 vectors per thread
-    constexpr int XN = TP * (PF_KSTEP / 4), XV = (XN + NT - 1) / NT;   // XN % NT = 0 or NT/2 (odd NG, 8 waves)
+    constexpr int XN = TP * (PF_KSTEP / 4), XV = (XN + NT - 1) / NT;   // XN % NT = 0 or NT/2 (never with 4 waves)
     const bool xlast = (XV - 1) * NT + tid < XN;
     const float* xg[XV];
     int xo[XV];
@@ -475,15 +475,15 @@ struct PfEpiArgs {
     float* kc;           // QKV: this layer's caches [S][KV]
     float* vc;
     const float* rope;   // [hs/2]
-    int rows, KS, Tp, T, pos0;   // pos0: 1-based position of token 0;  KS: partials per row when U == 0 (uniform K slices)
-    int U, nk, sh;               // U > 0: unit-balanced GEMM (PfGemmArgs), the strip r >> sh has pf_nslots partials
+    int rows, Tp, T, pos0;       // pos0: 1-based position of token 0
+    int U, nk, sh;               // the GEMM's units per block / steps per strip (PfGemmArgs): the strip r >> sh has pf_nslots partials
     int E, KV, hs, H;
 };
 
 // partials of (t, r) added in slot order; four loads in flight at a time (the trip count is a run-time value: a plain
 // loop would wait for each load before asking for the next)
 __device__ __forceinline__ float pf_sum(const PfEpiArgs& a, int t, int r) {
-    const int n = a.U > 0 ? pf_nslots(r >> a.sh, a.nk, a.U) : a.KS;
+    const int n = pf_nslots(r >> a.sh, a.nk, a.U);
     const size_t pitch = (size_t)a.Tp * a.rows;
     const float* p = a.P + (size_t)t * a.rows + r;
     float s = 0.f;
