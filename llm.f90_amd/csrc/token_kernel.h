@@ -116,7 +116,8 @@ struct TkShape {
     // its own queued ahead of the poll -- the reason the f32 / f16 kernels keep a wave that never streams (section 3b of
     // DESIGN.md) does not apply, and an 88 KB sweep by one wave was 7.3 us per layer.
     // Measured for f16 too (round 2, ring depth 4): any vector gathered by the streaming waves loses -- hb only 1,710 tok/s,
-    // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.
+    // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills
+    // that the next phase does not need until its input vector has been gathered (1,675).
     static constexpr bool COOP = Q4;
     static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
     static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
