@@ -554,6 +554,8 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
     // ~4 us until the first weights arrive; every partial tile is written once and read once by the epilogue.  Also
     // measured and dropped: two workgroups per CU (their waves share the SIMDs' matrix cores: same step rate per CU, but
     // the pairs drift apart and the kernel waits for the slower one) and eight waves per workgroup (two per SIMD in step).
+    // Four row groups per wave (128 accumulator registers, 256-row strips): step 8.2 us for 512 MFMAs -- 87 % of the matrix rate
+    // in the loop against 84 % with two, eaten by the coarser units (TinyLlama w1|w3 67.9 vs 62.2 us; Llama-2-7B q4_0 +0.4 %).
     static const double step_us[2] = {2.45, 4.25};
     PfPlan best{};
     double best_t = 1e30;
