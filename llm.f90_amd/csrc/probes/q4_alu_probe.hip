@@ -13,6 +13,13 @@
 //      (n ^ 8 = n - 8 in two's complement): per dword 1 v_xor + 6 v_dot8c_i32_i4, per block (4 dwords) 4 v_lshl_add +
 //      2 v_cvt_f32_i32 + 3 f32 ops.  No per-weight conversion at all.
 //   9  6 v_dot8c_i32_i4 only
+//  10  int8 matrix-core recipe: per 16-byte block load (4 dwords = 32 weights of one row) 4 v_and + 4 (v_lshrrev + v_and) unpack
+//      the nibbles to bytes, 4 chained v_mfma_i32_16x16x32_i8 against a block-diagonal B (16 columns = 4 blocks x 3 int8 digits
+//      of x + 1 spare: every block lands in its own output columns, so the per-(row, block) scales stay separable), then
+//      4 v_cvt_f32_i32 + 4 v_fma (scales).  0.6 VALU operations per weight instead of 2.25.
+//  11  the same idea on v_mfma_i32_4x4x4_16B_i8 (16 independent 4x4x4 products per instruction: MFMA-block = q4_0 block, A = 3
+//      int8 digits of x (+1 spare row), B = 4 weight ROWS x 4 nibbles) -- fits the token kernel's 4-row tiles: lane (blk, row)
+//      loads its row's 16-byte block, 8 MFMAs per load, then 3 v_cvt_f32_i32 + 2 v_fma (digits) + 2 v_fma (scale, 8 sum x)
 // Prints cycles (s_memtime) per dword per wave for 1 and 2 waves per SIMD.
 //   hipcc --offload-arch=gfx950 -O3 q4_alu_probe.hip -o q4_alu_probe && ./q4_alu_probe
 #include <hip/hip_runtime.h>
@@ -69,6 +76,55 @@ __global__ __launch_bounds__(512) void probe(const unsigned* __restrict__ qin, c
             }
         }
         acc[0] = facc;
+    } else if constexpr (V == 10) {
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        long bx[4];
+        for (int m = 0; m < 4; ++m) bx[m] = ((long)__float_as_uint(x[2 * m]) << 32) | (long)__float_as_uint(x[2 * m + 1]);
+#pragma unroll 1
+        for (int it = 0; it < ITERS / 2; ++it) {
+#pragma unroll
+            for (int ld = 0; ld < 8; ++ld) {
+                i4v d = {0, 0, 0, 0};
+                const unsigned M = 0x0f0f0f0fu;
+                const unsigned a0 = q[0] + it + ld, a1 = q[1] + it + ld, a2 = q[2] + it + ld, a3 = q[3] + it + ld;
+                const long A0 = ((long)(a1 & M) << 32) | (long)(a0 & M), A1 = ((long)(a3 & M) << 32) | (long)(a2 & M);
+                const long A2 = ((long)((a1 >> 4) & M) << 32) | (long)((a0 >> 4) & M), A3 = ((long)((a3 >> 4) & M) << 32) | (long)((a2 >> 4) & M);
+                d = __builtin_amdgcn_mfma_i32_16x16x32_i8(A0, bx[0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_16x16x32_i8(A1, bx[1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_16x16x32_i8(A2, bx[2], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_16x16x32_i8(A3, bx[3], d, 0, 0, 0);
+                const h2 s01 = __builtin_bit_cast(h2, q[0]), s23 = __builtin_bit_cast(h2, q[1]);
+                outv[0] = fmaf((float)s01[0], (float)d[0], outv[0]); outv[1] = fmaf((float)s01[1], (float)d[1], outv[1]);
+                outv[2] = fmaf((float)s23[0], (float)d[2], outv[2]); outv[3] = fmaf((float)s23[1], (float)d[3], outv[3]);
+            }
+        }
+        acc = outv;
+    } else if constexpr (V == 11) {
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        int xd[8];
+        for (int m = 0; m < 8; ++m) xd[m] = (int)__float_as_uint(x[m]);
+        float racc = 0.f;
+#pragma unroll 1
+        for (int it = 0; it < ITERS / 2; ++it) {
+#pragma unroll
+            for (int ld = 0; ld < 8; ++ld) {
+                i4v d = {0, 0, 0, 0};
+                const unsigned M = 0x0f0f0f0fu;
+                const unsigned a0 = q[0] + it + ld, a1 = q[1] + it + ld, a2 = q[2] + it + ld, a3 = q[3] + it + ld;
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[0], (int)(a0 & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[1], (int)(a1 & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[2], (int)(a2 & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[3], (int)(a3 & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[4], (int)((a0 >> 4) & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[5], (int)((a1 >> 4) & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[6], (int)((a2 >> 4) & M), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_i32_4x4x4i8(xd[7], (int)((a3 >> 4) & M), d, 0, 0, 0);
+                const float v = fmaf((float)d[2], 65536.f, fmaf((float)d[1], 256.f, (float)d[0]));
+                const h2 s01 = __builtin_bit_cast(h2, q[0]);
+                racc = fmaf((float)s01[0], fmaf(v, x[0], -x[1]), racc);
+            }
+        }
+        acc[0] = racc;
     } else if constexpr (V == 7) {
 #pragma unroll 1
         for (int it = 0; it < ITERS / 2; ++it) {
@@ -171,7 +227,7 @@ void run(int threads, const unsigned* q, const float* x, float* out, unsigned lo
     double s = 0;
     for (int i = 0; i < nw; ++i) s += (double)h[i];
     // __builtin_readcyclecounter = s_memtime = shader cycles
-    const double ndw = V == 7 ? (ITERS / 2) * 32.0 : ITERS * 4.0;
+    const double ndw = (V == 7 || V == 10 || V == 11) ? (ITERS / 2) * 32.0 : ITERS * 4.0;
     printf("{\"variant\": %d, \"waves_per_simd\": %d, \"cycles_per_dword\": %.4f}\n", V, threads / 256, s / nw / ndw);
     free(h);
 }
@@ -182,7 +238,7 @@ int main() {
     hipMemset(q, 0x5a, 512 * 16); hipMemset(x, 0x3c, 512 * 32);
     for (int th : {256, 512}) {
         run<0>(th, q, x, out, cyc); run<1>(th, q, x, out, cyc); run<2>(th, q, x, out, cyc); run<3>(th, q, x, out, cyc);
-        run<4>(th, q, x, out, cyc); run<5>(th, q, x, out, cyc); run<6>(th, q, x, out, cyc); run<7>(th, q, x, out, cyc); run<8>(th, q, x, out, cyc); run<9>(th, q, x, out, cyc);
+        run<4>(th, q, x, out, cyc); run<5>(th, q, x, out, cyc); run<6>(th, q, x, out, cyc); run<7>(th, q, x, out, cyc); run<8>(th, q, x, out, cyc); run<9>(th, q, x, out, cyc); run<10>(th, q, x, out, cyc); run<11>(th, q, x, out, cyc);
     }
     return 0;
 }
