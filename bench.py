@@ -229,7 +229,8 @@ def prefill_line(a):
                       "token_by_token_tok_s": 1.0 / dt_seq, "speedup": (n / dt) * dt_seq, "seed": SEED},
            "roofline": {"bound": "mfma", "kernel": f"{kname} (w1|w3, 128 positions, v_mfma_f32_16x16x4_f32)",
                         "achieved": flop / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                        "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "us_per_launch": ms * 1000.0,
+                        "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": pmc_traffic("pf_gemm_kernel", "prefill_w13", a.type),
+                        "us_per_launch": ms * 1000.0,
                         "flop_per_launch": flop, "weight_bytes_per_launch": wbytes,
                         "hbm_GBps": wbytes / (ms * 1e-3) / 1e9}}
     print(json.dumps(out))

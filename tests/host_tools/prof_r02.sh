@@ -63,6 +63,20 @@ cut -c1-900 $OUT/prefill512_bench.json
 rm -rf /tmp/st_pf
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_pf -- python $ROOT/bench.py --prefill 512 > /dev/null 2> /tmp/st_pf.err || tail -3 /tmp/st_pf.err
 reduce_stats /tmp/st_pf $OUT/prefill512_kernel_stats.csv
+# HBM traffic of the w1|w3 GEMM alone (own PMC pass; only that GEMM is launched: 44 launches walking the layers)
+cat > /tmp/pf_w13_only.py <<'PY'
+import os, sys
+sys.path.insert(0, os.environ["LLMK_ROOT"])
+import llm_f90_amd
+from llm_f90_amd import llmk
+from llm_f90_amd.tools import gguf
+m = llmk.Llmk(gguf.synth_fused(gguf.SHAPES["tinyllama"], 1, 0))
+print(m.time_kernel(7, 44))
+PY
+rm -rf /tmp/pm_pf
+LLMK_ROOT=$ROOT timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pm_pf -- python /tmp/pf_w13_only.py > /dev/null 2> /tmp/pm_pf.err || tail -3 /tmp/pm_pf.err
+cc=$(find /tmp/pm_pf -name "*counter_collection.csv" | head -1)
+[ -n "$cc" ] && python $ROOT/profiles/summarize_pmc.py "$cc" FETCH_SIZE | head -4 | tee $OUT/prefill_w13_f32_pmc_fetch_size.csv
 for g in w13 wqkv wo w2; do for nr in 1 2; do
   echo "--- $g, $nr row group(s) per wave"; LLMK_PF_PLAN=$nr LLMK_LIB=$ROOT/llm.f90_amd/csrc/libllmk_debug.so timeout 120 python $ROOT/tests/host_tools/pf_trace.py $g
 done; done > $OUT/prefill_gemm_timeline.txt 2>&1
