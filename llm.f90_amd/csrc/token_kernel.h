@@ -203,6 +203,9 @@ __device__ __forceinline__ float4 tk_ldkv(__amdgpu_buffer_rsrc_t rs, int voff) {
 // list's handoff-payload row), so: 16-byte sc1 loads (two granules each), ALL of a lane's NL loads in
 // flight at once, so a pass costs one round trip.
 // Returns false on timeout / sticky error.
+// (Measured and dropped, round 2: two passes in flight half a round trip apart, so that a pass that just missed the last
+// producer is not followed by a whole further round trip -- f16 1,850 -> 1,480 tok/s, f32 1,380 -> 1,290: twice the poll
+// traffic in the service wave's queue costs more than the shorter wait saves.)
 // NBP > 0: the values are written in the transposed q4_0 image (see TkLds), element e -> float4 (e>>2): block (e>>5),
 // group (e>>2)&7
 template <int NBP>
