@@ -63,6 +63,15 @@ cut -c1-900 $OUT/prefill512_bench.json
 rm -rf /tmp/st_pf
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_pf -- python $ROOT/bench.py --prefill 512 > /dev/null 2> /tmp/st_pf.err || tail -3 /tmp/st_pf.err
 reduce_stats /tmp/st_pf $OUT/prefill512_kernel_stats.csv
+# the other weight types through the same prefill, profiled the same way
+for cfg in "tinyllama f16" "tinyllama q4_0" "llama2-7b q4_0"; do
+  set -- $cfg; n=prefill512_$1_$2
+  timeout 600 python $ROOT/bench.py --prefill 512 --shape $1 --type $2 > $OUT/${n}_bench.json 2> $OUT/${n}_bench.err
+  cut -c1-300 $OUT/${n}_bench.json
+  rm -rf /tmp/st_$n
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$n -- python $ROOT/bench.py --prefill 512 --shape $1 --type $2 > /dev/null 2> /tmp/st_$n.err || tail -3 /tmp/st_$n.err
+  reduce_stats /tmp/st_$n $OUT/${n}_kernel_stats.csv
+done
 # HBM traffic of the w1|w3 GEMM alone (own PMC pass; only that GEMM is launched: 44 launches walking the layers)
 cat > /tmp/pf_w13_only.py <<'PY'
 import os, sys
