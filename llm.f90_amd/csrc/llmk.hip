@@ -97,10 +97,20 @@ struct llmk_ctx {
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
     size_t tk_lds = 0;
-    // batched prefill workspaces (prefill.h), allocated by the first llmk_prefill
-    float *pf_X = nullptr, *pf_Xs = nullptr, *pf_Q = nullptr, *pf_XB = nullptr, *pf_HB = nullptr, *pf_P = nullptr, *pf_xn = nullptr;
+    // batched prefill (prefill.h), allocated by the first llmk_prefill.  Two LANES = workspace set + stream: consecutive
+    // 128-position batches of a prompt alternate between them, so one batch's small kernels (epilogues, attention) and
+    // launch gaps run under the other's GEMMs.  The only cross-batch dependency is the KV cache: batch k+1's attention in
+    // layer l waits for batch k's K/V rows of layer l (event kv[l]).
+    struct PfLane {
+        float *X = nullptr, *Xs = nullptr, *Q = nullptr, *XB = nullptr, *HB = nullptr, *P = nullptr, *xn = nullptr;
+        hipStream_t stream = nullptr;      // lane 0: the ctx stream
+        std::vector<hipEvent_t> kv;        // per layer: this lane's batch has written its K/V rows
+        hipEvent_t done = nullptr;         // this lane's batch has left the last layer
+    } pf[2];
     int* pf_tok = nullptr;
+    hipEvent_t pf_start = nullptr;         // tokens are on the device (and everything before the prefill call is done)
 };
+typedef llmk_ctx::PfLane PfLane;
 
 namespace {
 
@@ -579,94 +589,104 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
 }
 int pf_max_slots(const PfPlan& p) { return (p.nk - 1) / p.U + 2; }
 int pf_setup(llmk_ctx* c) {
-    if (c->pf_X) return LLMK_OK;
+    if (c->pf[0].X) return LLMK_OK;
     const size_t T = PF_TMAX;
     const int rows[4] = {c->E + 2 * c->KV, c->E, 2 * c->H, c->E};
     size_t pcap = 0;
     const int Ks[4] = {c->E, c->E, c->E, c->H};
-    for (int i = 0; i < 4; ++i) {
-        pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
+    for (int i = 0; i < 4; ++i) pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
+    for (int i = 0; i < 2; ++i) {
+        PfLane& w = c->pf[i];
+        HIPCHK(hipMalloc(&w.X, T * c->E * sizeof(float)));
+        HIPCHK(hipMalloc(&w.Xs, T * c->E * sizeof(float)));
+        HIPCHK(hipMalloc(&w.Q, T * c->E * sizeof(float)));
+        HIPCHK(hipMalloc(&w.XB, T * c->E * sizeof(float)));
+        HIPCHK(hipMalloc(&w.HB, T * c->H * sizeof(float)));
+        HIPCHK(hipMalloc(&w.P, pcap * sizeof(float)));
+        HIPCHK(hipMalloc(&w.xn, T * sizeof(float)));
+        if (i == 0) w.stream = c->stream;
+        else HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        w.kv.resize(c->L);
+        for (int l = 0; l < c->L; ++l) HIPCHK(hipEventCreateWithFlags(&w.kv[l], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     }
-    HIPCHK(hipMalloc(&c->pf_X, T * c->E * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_Xs, T * c->E * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_Q, T * c->E * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_XB, T * c->E * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_HB, T * c->H * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_P, pcap * sizeof(float)));
-    HIPCHK(hipMalloc(&c->pf_xn, T * sizeof(float)));
+    HIPCHK(hipEventCreateWithFlags(&c->pf_start, hipEventDisableTiming));
     HIPCHK(hipMalloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
     return LLMK_OK;
 }
 template <int NG, int NR>
-hipError_t pf_gemm_launch(llmk_ctx* c, const PfGemmArgs& a, const PfPlan& p) {
+hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, const PfPlan& p) {
     // the LDS request (> half of the CU's 160 KB) pins one workgroup per CU: every CU gets one block of equal length
     const size_t smem = std::max(((size_t)2 * NG * 16 * PF_LDW + (size_t)NG * 16 * (64 * NR + PF_TPAD)) * sizeof(float), (size_t)84 * 1024);
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
     if (c->cfg.weight_type == LLMK_TYPE_Q4_0) {
         HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_Q4_0, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, c->stream, a);
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
     } else if (c->cfg.weight_type == LLMK_TYPE_F16) {
         HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, c->stream, a);
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, w.stream, a);
     } else {
         HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F32, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32, NR>), grid, block, smem, c->stream, a);
+        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32, NR>), grid, block, smem, w.stream, a);
     }
     return hipGetLastError();
 }
-hipError_t pf_gemm(llmk_ctx* c, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
+hipError_t pf_gemm(llmk_ctx* c, const PfLane& w, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
     const PfPlan p = pf_plan(c, rows, K);
     PfGemmArgs a;
-    a.W = W; a.X = X; a.P = c->pf_P; a.rows = rows; a.K = K; a.T = T; a.RS = row_stride;
+    a.W = W; a.X = X; a.P = w.P; a.rows = rows; a.K = K; a.T = T; a.RS = row_stride;
     a.nk = p.nk; a.U = p.U; a.total = p.total;
 #ifdef LLMK_PF_TRACE
-    a.trace = (unsigned long long*)c->pf_HB;     // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
+    a.trace = (unsigned long long*)w.HB;         // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
 #endif
     e->U = p.U; e->nk = p.nk; e->sh = p.nr == 2 ? 7 : 6;
 #define PF_CASE(NG_)                                                                         \
-    case NG_: return p.nr == 2 ? pf_gemm_launch<NG_, 2>(c, a, p) : pf_gemm_launch<NG_, 1>(c, a, p)
+    case NG_: return p.nr == 2 ? pf_gemm_launch<NG_, 2>(c, w, a, p) : pf_gemm_launch<NG_, 1>(c, w, a, p)
     switch ((T + 15) / 16) {
         PF_CASE(1); PF_CASE(2); PF_CASE(3); PF_CASE(4); PF_CASE(5); PF_CASE(6); PF_CASE(7);
-        default: return p.nr == 2 ? pf_gemm_launch<8, 2>(c, a, p) : pf_gemm_launch<8, 1>(c, a, p);
+        default: return p.nr == 2 ? pf_gemm_launch<8, 2>(c, w, a, p) : pf_gemm_launch<8, 1>(c, w, a, p);
     }
 #undef PF_CASE
 }
 // one batch of T <= PF_TMAX prompt positions pos0 .. pos0+T-1 (1-based) through all layers; X[T-1] ends up in d_x
-hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
+// `prev`: the lane of the batch before this one (null for the first batch of a call); `last`: this batch ends the prompt
+hipError_t pf_batch(llmk_ctx* c, PfLane& w, const PfLane* prev, const int* tok, int T, int pos0, bool last) {
     const int E = c->E, H = c->H, KV = c->KV, QKV = E + 2 * KV, Tp = (T + 15) / 16 * 16;
     const float* emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
-    hipLaunchKernelGGL(pf_embed_kernel, dim3((E + 255) / 256, T), dim3(256), 0, c->stream, emb, tok, c->pf_X, E);
+    hipLaunchKernelGGL(pf_embed_kernel, dim3((E + 255) / 256, T), dim3(256), 0, w.stream, emb, tok, w.X, E);
     HIPRET(hipGetLastError());
     PfEpiArgs e;
     memset(&e, 0, sizeof(e));
-    e.P = c->pf_P; e.xn = c->pf_xn; e.rope = c->d_rope; e.Tp = Tp; e.T = T; e.pos0 = pos0;
+    e.P = w.P; e.xn = w.xn; e.rope = c->d_rope; e.Tp = Tp; e.T = T; e.pos0 = pos0;
     e.E = E; e.KV = KV; e.hs = c->hs; e.H = H;
     for (int l = 0; l < c->L; ++l) {
         // layer l of tensor tid: data plane (and the q4_0 scale plane), rows_per_layer rows
         auto gemm = [&](int tid, int rows_per_layer, const float* X, int K) -> hipError_t {
             const DevTensor& dt = c->t[tid];
-            const char* w = (const char*)dt.data + (size_t)l * rows_per_layer * dt.row_bytes;
-            return pf_gemm(c, w, (int)dt.row_bytes, X, rows_per_layer, K, T, &e);
+            const char* wt = (const char*)dt.data + (size_t)l * rows_per_layer * dt.row_bytes;
+            return pf_gemm(c, w, wt, (int)dt.row_bytes, X, rows_per_layer, K, T, &e);
         };
         float* kc = c->d_kc + (size_t)l * c->S * KV;
         float* vc = c->d_vc + (size_t)l * c->S * KV;
         // rmsnorm (layer 0 here, later layers in the previous residual's kernel) + QKV + RoPE + KV write   llama2.f90:527-565
         if (l == 0) {
-            hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, c->stream, c->pf_X,
-                               (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data, c->pf_Xs, c->pf_xn, E, c->eps);
+            hipLaunchKernelGGL(pf_norm_kernel, dim3(T), dim3(256), 0, w.stream, w.X,
+                               (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data, w.Xs, w.xn, E, c->eps);
             HIPRET(hipGetLastError());
         }
-        HIPRET(gemm(LLMK_WQKV, QKV, c->pf_Xs, E));
-        e.rows = QKV; e.out = c->pf_Q; e.kc = kc; e.vc = vc;
-        hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, c->stream, e);
+        HIPRET(gemm(LLMK_WQKV, QKV, w.Xs, E));
+        e.rows = QKV; e.out = w.Q; e.kc = kc; e.vc = vc;
+        hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, w.stream, e);
         HIPRET(hipGetLastError());
+        if (!last) HIPRET(hipEventRecord(w.kv[l], w.stream));             // the next batch's attention reads these rows
+        if (prev) HIPRET(hipStreamWaitEvent(w.stream, prev->kv[l], 0));   // ... as this one reads the previous batch's
         // causal attention: position pos0+t sees cache rows 0 .. pos0+t-1                 :572-598
 #define ATT(HS_)                                                                                                         \
     do {                                                                                                                 \
         const size_t smem = ((size_t)PF_ATT_WAVES * 16 * (HS_) + 2 * PF_ATT_WAVES * 16) * sizeof(float);                 \
         HIPRET(hipFuncSetAttribute((const void*)pf_attn_kernel<HS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL((pf_attn_kernel<HS_>), dim3(c->nh, (T + 15) / 16), dim3(PF_ATT_WAVES * WAVE), smem, c->stream, \
-                           c->pf_Q, kc, vc, c->pf_XB, KV, c->kv_mul, pos0, T, E);                                        \
+        hipLaunchKernelGGL((pf_attn_kernel<HS_>), dim3(c->nh, (T + 15) / 16), dim3(PF_ATT_WAVES * WAVE), smem, w.stream, \
+                           w.Q, kc, vc, w.XB, KV, c->kv_mul, pos0, T, E);                                        \
     } while (0)
         switch (c->hs) {
             case 16: ATT(16); break;
@@ -678,25 +698,26 @@ hipError_t pf_batch(llmk_ctx* c, const int* tok, int T, int pos0) {
 #undef ATT
         HIPRET(hipGetLastError());
         // x += wo . xb                                                                    :603-605
-        HIPRET(gemm(LLMK_WO, E, c->pf_XB, E));
-        e.rows = E; e.out = c->pf_X;
-        hipLaunchKernelGGL(pf_epi_resid_norm_kernel, dim3(T), dim3(1024), 0, c->stream, e,
-                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, c->pf_Xs, c->pf_xn, c->eps);
+        HIPRET(gemm(LLMK_WO, E, w.XB, E));
+        e.rows = E; e.out = w.X;
+        hipLaunchKernelGGL(pf_epi_resid_norm_kernel, dim3(T), dim3(1024), 0, w.stream, e,
+                           (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data + (size_t)l * E, w.Xs, w.xn, c->eps);
         HIPRET(hipGetLastError());
         // (rmsnorm above) + w1|w3 + SwiGLU                                                :608-616
-        HIPRET(gemm(LLMK_W13, 2 * H, c->pf_Xs, E));
-        e.rows = 2 * H; e.out = c->pf_HB;
-        hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, c->stream, e);
+        HIPRET(gemm(LLMK_W13, 2 * H, w.Xs, E));
+        e.rows = 2 * H; e.out = w.HB;
+        hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, w.stream, e);
         HIPRET(hipGetLastError());
         // x += w2 . hb                                                                    :618-620
-        HIPRET(gemm(LLMK_W2, E, c->pf_HB, H));
-        e.rows = E; e.out = c->pf_X;
-        hipLaunchKernelGGL(pf_epi_resid_norm_kernel, dim3(T), dim3(1024), 0, c->stream, e,
-                           l + 1 < c->L ? (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)(l + 1) * E : nullptr, c->pf_Xs,
-                           c->pf_xn, c->eps);
+        HIPRET(gemm(LLMK_W2, E, w.HB, H));
+        e.rows = E; e.out = w.X;
+        hipLaunchKernelGGL(pf_epi_resid_norm_kernel, dim3(T), dim3(1024), 0, w.stream, e,
+                           l + 1 < c->L ? (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)(l + 1) * E : nullptr, w.Xs,
+                           w.xn, c->eps);
         HIPRET(hipGetLastError());
     }
-    return hipMemcpyAsync(c->d_x, c->pf_X + (size_t)(T - 1) * E, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    if (last) HIPRET(hipMemcpyAsync(c->d_x, w.X + (size_t)(T - 1) * E, (size_t)E * sizeof(float), hipMemcpyDeviceToDevice, w.stream));
+    return hipEventRecord(w.done, w.stream);
 }
 
 }  // namespace
@@ -1048,7 +1069,17 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     std::vector<int> tok0(tokens, tokens + n);
     for (int& t : tok0) --t;
     HIPCHK(hipMemcpyAsync(c->pf_tok, tok0.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    for (int i = 0; i < n; i += PF_TMAX) HIPCHK(pf_batch(c, c->pf_tok + i, std::min(PF_TMAX, n - i), pos0 + i));
+    HIPCHK(hipEventRecord(c->pf_start, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->pf[1].stream, c->pf_start, 0));
+    int k = 0;
+    for (int i = 0; i < n; i += PF_TMAX, ++k) {
+        // batch k runs on lane k % 2; its lane's previous batch (k - 2) is ordered by the stream, batch k - 1 by the KV events
+        const bool last = i + PF_TMAX >= n;
+        HIPCHK(pf_batch(c, c->pf[k & 1], k > 0 ? &c->pf[(k - 1) & 1] : nullptr, c->pf_tok + i, std::min(PF_TMAX, n - i), pos0 + i, last));
+    }
+    // the classifier runs on the ctx stream (= lane 0's): after everything lane 1 was given, too -- nothing of this call is
+    // still running when it returns
+    if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stream, c->pf[1].done, 0));
     HIPCHK(launch_cls(c));                          // final rmsnorm + classifier of the last position   :627-636
     HIPCHK(hipMemcpyAsync(c->h_logits, c->d_logits, (size_t)c->V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1095,7 +1126,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
         if (c->tp_size != 1 || c->E % pf_step || c->H % pf_step) return LLMK_E_ARG;
         rc = pf_setup(c);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c->pf_Xs, 0, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
+        HIPCHK(hipMemsetAsync(c->pf[0].Xs, 0, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
     }
     // Successive launches walk the layers so the weight stream never re-hits the 256 MiB Infinity
     // Cache (the classifier has one matrix: its figure is cache-assisted beyond the first launch).
@@ -1116,9 +1147,9 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
             const int tid = kernel == 7 ? LLMK_W13 : kernel == 8 ? LLMK_WQKV : kernel == 9 ? LLMK_WO : LLMK_W2;
             const int rows = kernel == 7 ? 2 * c->H : kernel == 8 ? c->E + 2 * c->KV : c->E;
             const char* w = (const char*)c->t[tid].data + (size_t)l * rows * c->t[tid].row_bytes;
-            const float* X = kernel == 10 ? c->pf_HB : c->pf_Xs;
+            const float* X = kernel == 10 ? c->pf[0].HB : c->pf[0].Xs;
             const int K = kernel == 10 ? c->H : c->E;
-            return pf_gemm(c, w, (int)c->t[tid].row_bytes, X, rows, K, PF_TMAX, &e);
+            return pf_gemm(c, c->pf[0], w, (int)c->t[tid].row_bytes, X, rows, K, PF_TMAX, &e);
         }
         switch (kernel) {
             case 0: return launch_qkv(c, l);
@@ -1176,7 +1207,7 @@ int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
             len = c->KVl;
             break;
 #ifdef LLMK_PF_TRACE
-        case 7: src = c->pf_HB; len = PF_TMAX * c->H; break;
+        case 7: src = c->pf[0].HB; len = PF_TMAX * c->H; break;
 #endif
         case 6:  // debug: raw trace stamps reinterpret as floats (2 per stamp)
             if (!c->d_trace) return LLMK_E_ARG;
@@ -1341,8 +1372,9 @@ int llmk_destroy(llmk_ctx* c) {
         if (c->t[i].data) hipFree(c->t[i].data);
     }
     void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,
-                   c->d_gran, c->d_zeros, c->d_trace, c->d_part, c->pf_X, c->pf_Xs, c->pf_Q, c->pf_XB, c->pf_HB, c->pf_P,
-                   c->pf_xn, c->pf_tok};
+                   c->d_gran, c->d_zeros, c->d_trace, c->d_part, c->pf_tok,
+                   c->pf[0].X, c->pf[0].Xs, c->pf[0].Q, c->pf[0].XB, c->pf[0].HB, c->pf[0].P, c->pf[0].xn,
+                   c->pf[1].X, c->pf[1].Xs, c->pf[1].Q, c->pf[1].XB, c->pf[1].HB, c->pf[1].P, c->pf[1].xn};
     for (void* p : dev)
         if (p) hipFree(p);
     if (c->h_tokpos) hipHostFree(c->h_tokpos);
@@ -1350,6 +1382,12 @@ int llmk_destroy(llmk_ctx* c) {
     if (c->h_next) hipHostFree(c->h_next);
     for (int i = 0; i < 8; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    for (PfLane& w : c->pf) {
+        for (hipEvent_t e : w.kv) hipEventDestroy(e);
+        if (w.done) hipEventDestroy(w.done);
+    }
+    if (c->pf_start) hipEventDestroy(c->pf_start);
+    if (c->pf[1].stream) hipStreamDestroy(c->pf[1].stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return LLMK_OK;
