@@ -174,6 +174,18 @@ int llmk_prefill(llmk_ctx* ctx, const int* tokens, int n, int pos0, float* logit
  * SURVEY.md section 8(f) rank 1. */
 int llmk_forward_greedy(llmk_ctx *ctx, int token, int pos, int *next_token);
 
+/* The temperature-0 generation loop of llama2.f90:379-396 for n positions in ONE call, without a host round trip per
+ * token: position pos0 is fed `token`, every later position the device argmax (first maximum wins, llama2.f90:388) of the
+ * position before it.  ids_out[i] = the 1-based token chosen after position pos0+i (= what llmk_forward_greedy returns
+ * there).  On the persistent-kernel path the n launches are enqueued back to back: each launch leaves the per-CU maxima
+ * of its classifier rows in device memory and the next one folds them at its start, so the token never leaves the
+ * device; ids reach the host through mapped memory as they are resolved, and on_token (optional) is called from the
+ * calling thread, in order, as each arrives -- the host can stream the text exactly as llama2.f90:396 does.  Other
+ * contexts run the same positions through llmk_forward_greedy.  The logits of every position are still computed and
+ * written (device memory); only their trip to the host is dropped.  SURVEY.md section 8(f) rank 1. */
+typedef void (*llmk_token_fn)(int index, int token, void *user);
+int llmk_decode_greedy(llmk_ctx *ctx, int token, int pos0, int n, int *ids_out, llmk_token_fn on_token, void *user);
+
 /* Zero the KV cache (new sequence), as llama2.f90:316-318. */
 int llmk_reset(llmk_ctx *ctx);
 
@@ -193,6 +205,16 @@ int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double
  * 1 = q (E), 2 = xb (attention output, E), 3 = hb (H), 4 = key_cache row [layer][pos-1] (KV),
  * 5 = value_cache row (KV). */
 int llmk_peek(llmk_ctx *ctx, int which, int layer, int pos, float *out, int n);
+
+/* Which implementation of the token pass this ctx runs RIGHT NOW (it can change: a timed-out persistent kernel retires
+ * to the multi-kernel path; llmk_set_tensor_type does the same): one of LLMK_PATH_*, or a negative LLMK_E_* code.
+ * For labels in benchmarks and logs -- no reference counterpart. */
+#define LLMK_PATH_MULTI_KERNEL 0     /* 5 launches per layer (csrc/kernels.h)                                        */
+#define LLMK_PATH_TOKEN_KERNEL 1     /* persistent whole-token kernel (csrc/token_kernel.h)                          */
+#define LLMK_PATH_TP_P2P 2           /* tensor-parallel rank: 6 launches per layer + one-shot peer-memory exchanges  */
+#define LLMK_PATH_TP_RCCL 3          /* tensor-parallel rank: eager launches + ncclAllReduce / ncclAllGather         */
+#define LLMK_PATH_TP_UNCONNECTED 4   /* tensor-parallel rank without collectives yet (llmk_tp_segment stepping only) */
+int llmk_path(llmk_ctx *ctx);
 
 int llmk_destroy(llmk_ctx *ctx);
 

@@ -97,6 +97,9 @@ struct llmk_ctx {
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
     size_t tk_lds = 0;
+    // pipelined greedy decode (llmk_decode_greedy): per-CU classifier maxima of the last two launches, and the ids as they
+    // are resolved (host-mapped; 0 = not there yet)
+    // (the candidates sit behind the device error word, the ids behind the host error word: token_kernel.h tk_cand)
     // batched prefill (prefill.h), allocated by the first llmk_prefill.  Two LANES = workspace set + stream: consecutive
     // 128-position batches of a prompt alternate between them, so one batch's small kernels (epilogues, attention) and
     // launch gaps run under the other's GEMMs.  The only cross-batch dependency is the KV cache: batch k+1's attention in
@@ -109,6 +112,7 @@ struct llmk_ctx {
     } pf[2];
     int* pf_tok = nullptr;
     hipEvent_t pf_start = nullptr;         // tokens are on the device (and everything before the prefill call is done)
+    bool pf_ready = false;                 // pf_setup ran to its end
 };
 typedef llmk_ctx::PfLane PfLane;
 
@@ -285,9 +289,12 @@ hipError_t launch_embed(llmk_ctx* c) {
 
 // direct = true: token/pos/serial travel as kernel arguments and the logits (+ a sticky error word) are written
 // straight into the pinned host buffer, so a token is ONE launch and one stream sync (no copy nodes around it)
+// what a launch of the pipelined greedy decode adds to the arguments (all null otherwise)
+struct TkGreedy { int gflags = 0, id_index = 0; };
 template <class TK>
-hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
+hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
     TokenArgs a;
+    a.gflags = g.gflags | ((TK_DEBUG && getenv("LLMK_TK_NOSYNC")) ? TKG_NOSYNC : 0);   // NOSYNC: libllmk_debug.so only
     a.emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
     a.rms_att = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;
     a.rms_ffn = (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data;
@@ -301,7 +308,7 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     a.vc = c->d_vc;
     a.rope = c->d_rope;
     a.tokpos = direct ? nullptr : c->d_tokpos;
-    a.tok_imm = c->h_tokpos[0];
+    a.tok_imm = (g.gflags & TKG_CAND_IN) ? g.id_index : c->h_tokpos[0];   // the token comes from the candidates: the word carries the id's slot
     a.pos_imm = c->h_tokpos[1];
     a.serial_imm = c->h_tokpos[2];
     a.g_qkv = c->d_gran;
@@ -311,23 +318,39 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct) {
     a.g_x = a.g_hb + TK::H;
     a.logits = direct ? c->h_logits_dev : c->d_logits;
     a.err = reinterpret_cast<unsigned*>(c->d_logits + c->V);
-    a.herr = direct ? reinterpret_cast<unsigned*>(c->h_logits_dev + c->V) : nullptr;
+    a.herr = (direct || g.gflags) ? reinterpret_cast<unsigned*>(c->h_logits_dev + c->V) : nullptr;
     a.zeros = c->d_zeros;
     a.trace = c->d_trace;
     a.L = c->L;
     a.S = c->S;
     a.eps = c->eps;
-    a.nosync = (TK_DEBUG && getenv("LLMK_TK_NOSYNC")) ? 1 : 0;   // libllmk_debug.so only
-    hipLaunchKernelGGL((token_kernel<TK>), dim3((TK_DEBUG && c->tk_short_grid) ? TK_NCU - 1 : TK_NCU), dim3(TK_THREADS), c->tk_lds, c->stream, a);
+    const dim3 grid((TK_DEBUG && c->tk_short_grid) ? TK_NCU - 1 : TK_NCU);
+    if (g.gflags) hipLaunchKernelGGL((token_kernel<TK, true>), grid, dim3(TK_THREADS), c->tk_lds, c->stream, a);
+    else hipLaunchKernelGGL((token_kernel<TK>), grid, dim3(TK_THREADS), c->tk_lds, c->stream, a);
     return hipGetLastError();
 }
-hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false) {
+hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false, const TkGreedy& g = TkGreedy()) {
     switch (c->tk_shape) {
-        case 1: return launch_token_kernel_t<TkTinyLlama>(c, direct);
-        case 2: return launch_token_kernel_t<TkSmall>(c, direct);
-        case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct);
-        case 4: return launch_token_kernel_t<TkSmallF16>(c, direct);
-        default: return launch_token_kernel_t<TkLlama7BQ4>(c, direct);
+        case 1: return launch_token_kernel_t<TkTinyLlama>(c, direct, g);
+        case 2: return launch_token_kernel_t<TkSmall>(c, direct, g);
+        case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct, g);
+        case 4: return launch_token_kernel_t<TkSmallF16>(c, direct, g);
+        default: return launch_token_kernel_t<TkLlama7BQ4>(c, direct, g);
+    }
+}
+// the last position of a pipelined greedy run has no next launch to fold its candidates: this does (1 wave)
+__global__ __launch_bounds__(64) void cand_resolve_kernel(const float2* __restrict__ cand, int* id_out, int* next) {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = threadIdx.x; k < TK_NCU; k += 64) {
+        const float2 cd = cand[k];
+        const int ci = __float_as_int(cd.y);
+        if (cd.x > bv || (cd.x == bv && ci < bi)) { bv = cd.x; bi = ci; }
+    }
+    tk_wave_argmax(bv, bi);
+    if (threadIdx.x == 0) {
+        next[0] = bi + 1;
+        __hip_atomic_store(id_out, bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -346,6 +369,7 @@ int tk_setup(llmk_ctx* c, int id) {
     // hardware admits.  Assert it with the occupancy query instead of assuming it; a part that cannot host the grid takes
     // the multi-kernel path.  (hipLaunchCooperativeKernel would run the same check per launch for +15-19 us each.)
     HIPCHK(hipFuncSetAttribute((const void*)token_kernel<TK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
+    HIPCHK(hipFuncSetAttribute((const void*)token_kernel<TK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->tk_lds));
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, token_kernel<TK>, TK_THREADS, c->tk_lds));
     if (per_cu < 1 || (long long)per_cu * c->n_cu < TK_NCU) return LLMK_OK;
@@ -588,13 +612,31 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
     return best;
 }
 int pf_max_slots(const PfPlan& p) { return (p.nk - 1) / p.U + 2; }
-int pf_setup(llmk_ctx* c) {
-    if (c->pf[0].X) return LLMK_OK;
+hipError_t pf_prepare(const llmk_ctx* c);
+void pf_teardown(llmk_ctx* c) {
+    for (PfLane& w : c->pf) {
+        float** bufs[] = {&w.X, &w.Xs, &w.Q, &w.XB, &w.HB, &w.P, &w.xn};
+        for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+        for (hipEvent_t e : w.kv) if (e) hipEventDestroy(e);
+        w.kv.clear();
+        if (w.done) { hipEventDestroy(w.done); w.done = nullptr; }
+    }
+    if (c->pf[1].stream) { hipStreamDestroy(c->pf[1].stream); c->pf[1].stream = nullptr; }
+    c->pf[0].stream = nullptr;
+    if (c->pf_start) { hipEventDestroy(c->pf_start); c->pf_start = nullptr; }
+    if (c->pf_tok) { hipFree(c->pf_tok); c->pf_tok = nullptr; }
+    c->pf_ready = false;
+}
+// Workspaces, the second lane's stream, the KV events and the kernels' dynamic-LDS limits.  pf_ready is set only after
+// the LAST step succeeded; a failure part-way frees everything again, so a later llmk_prefill retries the setup instead
+// of launching on null buffers.
+int pf_setup_inner(llmk_ctx* c) {
     const size_t T = PF_TMAX;
     const int rows[4] = {c->E + 2 * c->KV, c->E, 2 * c->H, c->E};
     size_t pcap = 0;
     const int Ks[4] = {c->E, c->E, c->E, c->H};
     for (int i = 0; i < 4; ++i) pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
+    HIPCHK(pf_prepare(c));
     for (int i = 0; i < 2; ++i) {
         PfLane& w = c->pf[i];
         HIPCHK(hipMalloc(&w.X, T * c->E * sizeof(float)));
@@ -606,7 +648,7 @@ int pf_setup(llmk_ctx* c) {
         HIPCHK(hipMalloc(&w.xn, T * sizeof(float)));
         if (i == 0) w.stream = c->stream;
         else HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-        w.kv.resize(c->L);
+        w.kv.assign(c->L, nullptr);
         for (int l = 0; l < c->L; ++l) HIPCHK(hipEventCreateWithFlags(&w.kv[l], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     }
@@ -614,21 +656,57 @@ int pf_setup(llmk_ctx* c) {
     HIPCHK(hipMalloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
     return LLMK_OK;
 }
+int pf_setup(llmk_ctx* c) {
+    if (c->pf_ready) return LLMK_OK;
+    const int rc = pf_setup_inner(c);
+    if (rc) { pf_teardown(c); return rc; }
+    c->pf_ready = true;
+    return LLMK_OK;
+}
+// dynamic-LDS request of pf_gemm_kernel<NG, *, NR> (> half of the CU's 160 KB: pins one workgroup per CU, so every CU
+// gets one block of equal length)
+template <int NG, int NR>
+constexpr size_t pf_gemm_smem() {
+    const size_t need = ((size_t)2 * NG * 16 * PF_LDW + (size_t)NG * 16 * (64 * NR + PF_TPAD)) * sizeof(float);
+    return need > (size_t)84 * 1024 ? need : (size_t)84 * 1024;
+}
+constexpr size_t pf_attn_smem(int hs) { return ((size_t)PF_ATT_WAVES * 16 * hs + 2 * PF_ATT_WAVES * 16) * sizeof(float); }
+// The limits are raised ONCE, in pf_setup (as g_prepare does for the decode kernels): a launch is a launch, with no
+// runtime call in the 5 us gaps between the prefill's dependent kernels, and an LDS failure surfaces at setup.
+template <int NG, int WT>
+hipError_t pf_gemm_prepare_one() {
+    HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_smem<NG, 1>()));
+    return hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_smem<NG, 2>());
+}
+template <int WT>
+hipError_t pf_gemm_prepare() {
+    HIPRET((pf_gemm_prepare_one<1, WT>())); HIPRET((pf_gemm_prepare_one<2, WT>())); HIPRET((pf_gemm_prepare_one<3, WT>()));
+    HIPRET((pf_gemm_prepare_one<4, WT>())); HIPRET((pf_gemm_prepare_one<5, WT>())); HIPRET((pf_gemm_prepare_one<6, WT>()));
+    HIPRET((pf_gemm_prepare_one<7, WT>()));
+    return pf_gemm_prepare_one<8, WT>();
+}
+hipError_t pf_prepare(const llmk_ctx* c) {
+    switch (c->cfg.weight_type) {
+        case LLMK_TYPE_Q4_0: HIPRET(pf_gemm_prepare<WT_Q4_0>()); break;
+        case LLMK_TYPE_F16: HIPRET(pf_gemm_prepare<WT_F16>()); break;
+        default: HIPRET(pf_gemm_prepare<WT_F32>()); break;
+    }
+    const int smem = (int)pf_attn_smem(c->hs);
+    switch (c->hs) {
+        case 16: return hipFuncSetAttribute((const void*)pf_attn_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        case 32: return hipFuncSetAttribute((const void*)pf_attn_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        case 64: return hipFuncSetAttribute((const void*)pf_attn_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        case 128: return hipFuncSetAttribute((const void*)pf_attn_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    return hipErrorInvalidValue;
+}
 template <int NG, int NR>
 hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, const PfPlan& p) {
-    // the LDS request (> half of the CU's 160 KB) pins one workgroup per CU: every CU gets one block of equal length
-    const size_t smem = std::max(((size_t)2 * NG * 16 * PF_LDW + (size_t)NG * 16 * (64 * NR + PF_TPAD)) * sizeof(float), (size_t)84 * 1024);
+    constexpr size_t smem = pf_gemm_smem<NG, NR>();
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
-    if (c->cfg.weight_type == LLMK_TYPE_Q4_0) {
-        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_Q4_0, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
-    } else if (c->cfg.weight_type == LLMK_TYPE_F16) {
-        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F16, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, w.stream, a);
-    } else {
-        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT_F32, NR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32, NR>), grid, block, smem, w.stream, a);
-    }
+    if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
+    else if (c->cfg.weight_type == LLMK_TYPE_F16) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, w.stream, a);
+    else hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32, NR>), grid, block, smem, w.stream, a);
     return hipGetLastError();
 }
 hipError_t pf_gemm(llmk_ctx* c, const PfLane& w, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
@@ -683,8 +761,7 @@ hipError_t pf_batch(llmk_ctx* c, PfLane& w, const PfLane* prev, const int* tok, 
         // causal attention: position pos0+t sees cache rows 0 .. pos0+t-1                 :572-598
 #define ATT(HS_)                                                                                                         \
     do {                                                                                                                 \
-        const size_t smem = ((size_t)PF_ATT_WAVES * 16 * (HS_) + 2 * PF_ATT_WAVES * 16) * sizeof(float);                 \
-        HIPRET(hipFuncSetAttribute((const void*)pf_attn_kernel<HS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        const size_t smem = pf_attn_smem(HS_);                                                                           \
         hipLaunchKernelGGL((pf_attn_kernel<HS_>), dim3(c->nh, (T + 15) / 16), dim3(PF_ATT_WAVES * WAVE), smem, w.stream, \
                            w.Q, kc, vc, w.XB, KV, c->kv_mul, pos0, T, E);                                        \
     } while (0)
@@ -829,12 +906,14 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     CK(hipMalloc(&c->d_xb, (size_t)E * sizeof(float)));
     CK(hipMalloc(&c->d_hb, (size_t)H * sizeof(float)));
     CK(hipMalloc(&c->d_part, (size_t)E * sizeof(float)));
-    CK(hipMalloc(&c->d_logits, ((size_t)V + 4) * sizeof(float)));  // [V] = sticky device error word
+    // [V] = sticky device error word; behind it (at V + 4) the two candidate buffers of the pipelined greedy decode
+    CK(hipMalloc(&c->d_logits, ((size_t)V + 4 + 4 * TK_NCU) * sizeof(float)));
     CK(hipMalloc(&c->d_rope, (size_t)(hs / 2) * sizeof(float)));
     CK(hipMalloc(&c->d_tokpos, 4 * sizeof(int)));
     CK(hipMalloc(&c->d_next, 2 * sizeof(int)));
     CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
-    CK(hipHostMalloc(&c->h_logits, ((size_t)V + 4) * sizeof(float), hipHostMallocMapped));
+    // [V] = the error word as the host sees it; behind it (at V + 4) the ids of llmk_decode_greedy, S ints
+    CK(hipHostMalloc(&c->h_logits, ((size_t)V + 4 + S) * sizeof(float), hipHostMallocMapped));
     CK(hipHostGetDevicePointer((void**)&c->h_logits_dev, c->h_logits, 0));
     c->tk_direct = !(getenv("LLMK_TK_DIRECT") && getenv("LLMK_TK_DIRECT")[0] == '0');
     CK(hipHostMalloc(&c->h_next, 2 * sizeof(int), hipHostMallocDefault));
@@ -861,7 +940,7 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         else CK(pe);
     }
     if (rc == LLMK_OK) {
-        CK(hipMemset(c->d_logits, 0, ((size_t)V + 4) * sizeof(float)));
+        CK(hipMemset(c->d_logits, 0, ((size_t)V + 4 + 4 * TK_NCU) * sizeof(float)));
         c->h_tokpos[0] = 0; c->h_tokpos[1] = 0; c->h_tokpos[2] = 0; c->h_tokpos[3] = 0;
         CK(hipMemset(c->d_kc, 0, kvn * sizeof(float)));  // s%key_cache(:,:,:) = 0   llama2.f90:317
         CK(hipMemset(c->d_vc, 0, kvn * sizeof(float)));
@@ -1075,7 +1154,12 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     for (int i = 0; i < n; i += PF_TMAX, ++k) {
         // batch k runs on lane k % 2; its lane's previous batch (k - 2) is ordered by the stream, batch k - 1 by the KV events
         const bool last = i + PF_TMAX >= n;
-        HIPCHK(pf_batch(c, c->pf[k & 1], k > 0 ? &c->pf[(k - 1) & 1] : nullptr, c->pf_tok + i, std::min(PF_TMAX, n - i), pos0 + i, last));
+        const hipError_t pe = pf_batch(c, c->pf[k & 1], k > 0 ? &c->pf[(k - 1) & 1] : nullptr, c->pf_tok + i, std::min(PF_TMAX, n - i), pos0 + i, last);
+        if (pe != hipSuccess) {   // nothing of this call may still be running (on either lane) when it returns
+            hipStreamSynchronize(c->pf[1].stream);
+            hipStreamSynchronize(c->stream);
+            return LLMK_E_HIP + (int)pe;
+        }
     }
     // the classifier runs on the ctx stream (= lane 0's): after everything lane 1 was given, too -- nothing of this call is
     // still running when it returns
@@ -1092,6 +1176,71 @@ int llmk_forward_greedy(llmk_ctx* c, int token, int pos, int* next_token) {
     int rc = run_token(c, token, pos, true);
     if (rc) return rc;
     *next_token = *c->h_next;
+    return LLMK_OK;
+}
+
+// The temperature-0 generation loop of llama2.f90:379-396 for n positions with no host round trip between them.
+int llmk_decode_greedy(llmk_ctx* c, int token, int pos0, int n, int* ids_out, llmk_token_fn on_token, void* user) {
+    if (!c || !ids_out || n < 1 || pos0 < 1 || pos0 + n - 1 > c->S || token < 1 || token > c->V) return LLMK_E_ARG;
+    int rc = check_ready(c);
+    if (rc) return rc;
+    const bool timed = (c->cfg.flags & (LLMK_FLAG_TIMINGS | LLMK_FLAG_NO_GRAPH)) != 0;
+    int done = 0;
+    if (c->use_tk && !timed && !c->p2p && !c->comm && c->tp_size == 1) {
+        // n launches enqueued back to back: launch i takes its token from launch i-1's candidates (device memory) and leaves
+        // its own; ids reach the host through mapped memory as CU 0 of the NEXT launch resolves them
+        HIPCHK(hipSetDevice(c->cfg.device));
+        int* h_ids = reinterpret_cast<int*>(c->h_logits + c->V + 4);
+        int* h_ids_dev = reinterpret_cast<int*>(c->h_logits_dev + c->V + 4);
+        float2* d_cand = reinterpret_cast<float2*>(c->d_logits + c->V + 4);
+        memset(h_ids, 0, (size_t)n * sizeof(int));
+        reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
+        for (int i = 0; i < n; ++i) {
+            c->h_tokpos[0] = token - 1;
+            c->h_tokpos[1] = pos0 + i;
+            c->h_tokpos[2] += 1;
+            TkGreedy g;
+            g.gflags = TKG_CAND_OUT | ((i & 1) ? TKG_PARITY : 0) | (i ? TKG_CAND_IN | TKG_ID : 0);
+            g.id_index = i - 1;
+            c->tk_short_grid = false;
+            HIPCHK(launch_token_kernel(c, false, g));
+        }
+        hipLaunchKernelGGL(cand_resolve_kernel, dim3(1), dim3(64), 0, c->stream, d_cand + (size_t)((n - 1) & 1) * TK_NCU,
+                           h_ids_dev + (n - 1), c->d_next);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(c->h_next + 1, c->d_logits + c->V, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        // drain: ids are 1-based, 0 = not resolved yet
+        volatile int* ids = h_ids;
+        while (done < n) {
+            if (ids[done] != 0) {
+                ids_out[done] = ids[done];
+                if (on_token) on_token(done, ids_out[done], user);
+                ++done;
+                continue;
+            }
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) { if (ids[done] == 0) break; continue; }   // stream drained without the id: an error below
+            if (q != hipErrorNotReady) return LLMK_E_HIP + (int)q;
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (; done < n && ids[done] != 0; ++done) {
+            ids_out[done] = ids[done];
+            if (on_token) on_token(done, ids_out[done], user);
+        }
+        const unsigned err = (unsigned)c->h_next[1];
+        if (err == 0 && done == n) return LLMK_OK;
+        // a timed-out exchange: every later launch drained on the sticky word.  Retire the token kernel and redo the rest,
+        // from the first position whose id never arrived, on the multi-kernel path (it rewrites those KV rows).
+        rc = tk_retire(c, err, pos0 + done);
+        if (rc) return rc;
+        if (done > 0) token = ids_out[done - 1];
+    }
+    for (int i = done; i < n; ++i) {
+        rc = run_token(c, token, pos0 + i, true);
+        if (rc) return rc;
+        token = ids_out[i] = *c->h_next;
+        if (on_token) on_token(i, token, user);
+    }
     return LLMK_OK;
 }
 
@@ -1358,6 +1507,14 @@ int llmk_tp_read_logits(llmk_ctx* c, float* out_slice) {
     return LLMK_OK;
 }
 
+int llmk_path(llmk_ctx* c) {
+    if (!c) return -LLMK_E_ARG;
+    if (c->p2p) return LLMK_PATH_TP_P2P;
+    if (c->comm) return LLMK_PATH_TP_RCCL;
+    if (c->tp_size > 1) return LLMK_PATH_TP_UNCONNECTED;
+    return c->use_tk ? LLMK_PATH_TOKEN_KERNEL : LLMK_PATH_MULTI_KERNEL;
+}
+
 int llmk_destroy(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     hipSetDevice(c->cfg.device);
@@ -1371,10 +1528,9 @@ int llmk_destroy(llmk_ctx* c) {
     for (int i = 0; i < LLMK_N_TENSORS; ++i) {
         if (c->t[i].data) hipFree(c->t[i].data);
     }
+    pf_teardown(c);
     void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,
-                   c->d_gran, c->d_zeros, c->d_trace, c->d_part, c->pf_tok,
-                   c->pf[0].X, c->pf[0].Xs, c->pf[0].Q, c->pf[0].XB, c->pf[0].HB, c->pf[0].P, c->pf[0].xn,
-                   c->pf[1].X, c->pf[1].Xs, c->pf[1].Q, c->pf[1].XB, c->pf[1].HB, c->pf[1].P, c->pf[1].xn};
+                   c->d_gran, c->d_zeros, c->d_trace, c->d_part};
     for (void* p : dev)
         if (p) hipFree(p);
     if (c->h_tokpos) hipHostFree(c->h_tokpos);
@@ -1382,12 +1538,6 @@ int llmk_destroy(llmk_ctx* c) {
     if (c->h_next) hipHostFree(c->h_next);
     for (int i = 0; i < 8; ++i)
         if (c->ev[i]) hipEventDestroy(c->ev[i]);
-    for (PfLane& w : c->pf) {
-        for (hipEvent_t e : w.kv) hipEventDestroy(e);
-        if (w.done) hipEventDestroy(w.done);
-    }
-    if (c->pf_start) hipEventDestroy(c->pf_start);
-    if (c->pf[1].stream) hipStreamDestroy(c->pf[1].stream);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return LLMK_OK;

@@ -64,7 +64,7 @@ struct TokenArgs {
     const float* rope;       // [hs/2]
     const int* tokpos;       // {token0, pos1, serial} in device memory (graph replay), or null: the three fields below
     int tok_imm, pos_imm, serial_imm;
-    unsigned* herr;          // optional sticky error word in HOST memory (direct mode: logits also point at host memory)
+    unsigned* herr;          // optional sticky error word in HOST memory (direct mode, where logits also point at host memory; the greedy pipeline: its ids sit behind it)
     unsigned long long* g_qkv;  // granules [E+2KV]
     unsigned long long* g_xb;   // [E]   attention output
     unsigned long long* g_xa;   // [E]   x after attention residual
@@ -76,11 +76,37 @@ struct TokenArgs {
     unsigned long long* trace;  // debug build only: [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave
     int L, S;
     float eps;               // rmsnorm epsilon
-    int nosync;              // debug build only: do not wait for exchange tags (wrong results; measures the pure streaming rate)
+    int gflags;              // TKG_* bits (pipelined greedy decode, host error word; debug build: TKG_NOSYNC)
     // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
     int q0, qn, o0, on;
     int c0, cn;              // this CU's rows of the classifier
+    // Pipelined greedy decode (llmk_decode_greedy): `token = maxloc(logits,DIM=1)` (llama2.f90:388) without a host round
+    // trip.  Every CU leaves the first maximum of ITS classifier rows in cand_out[c] = {logit, 0-based row}; the NEXT launch
+    // (ordered behind this one by the stream) starts by folding the 256 candidates of cand_in -- 2 KB, first maximum wins --
+    // on every CU that needs the embedding row, so the token never leaves the device and no exchange is added.
+    // The candidates live behind the error word (err + 4: two buffers of TK_NCU float2, alternating by launch parity) and
+    // the resolved ids behind the host error word (herr + 4: ints) -- no further pointer arguments: the kernel is at its
+    // SGPR ceiling, and three more pointers cost the f32 instantiation 36 bytes of scratch.
+    // The flags share the word of the debug build's "do not wait" switch, and with TKG_CAND_IN the unused tok_imm carries
+    // the index of the id to store: the argument block is exactly as large as before.
 };
+constexpr int TKG_CAND_OUT = 1;    // leave candidates in buffer (gflags >> 1) & 1
+constexpr int TKG_PARITY = 2;
+constexpr int TKG_CAND_IN = 4;     // the token is the fold of the OTHER buffer (else tok_imm / tokpos[0])
+constexpr int TKG_ID = 8;
+constexpr int TKG_NOSYNC = 32;     // debug build only: do not wait for exchange tags (wrong results; measures the pure streaming rate)
+__device__ __forceinline__ float2* tk_cand(const TokenArgs& a, int buf) {
+    return reinterpret_cast<float2*>(a.err + 4) + buf * TK_NCU;
+}
+// first-maximum-wins fold of {value, index-as-float-bits} pairs over a wave; every lane ends with the winner
+__device__ __forceinline__ void tk_wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
 
 template <int E_, int H_, int NH_, int NKV_, int V_, int WT_ = WT_F32>
 struct TkShape {
@@ -805,7 +831,32 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
 // SERVICE wave of a CU: everything that depends on other CUs.  Per phase: gather the input vector
 // (granule sweep), rmsnorm, barrier A, barrier B, epilogue + publish.
 // ------------------------------------------------------------------------------------------------
-template <class SH>
+// the 0-based token of this launch: an argument / device word, or (GR) the fold of the previous launch's candidates
+template <bool GR>
+__device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
+    if constexpr (GR) {
+        if (a.gflags & TKG_CAND_IN) {   // the previous launch's per-CU maxima -> its greedy token (plain loads: a kernel boundary lies between)
+            const float2* cand_in = tk_cand(a, ((a.gflags >> 1) & 1) ^ 1);
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < TK_NCU / WAVE; ++k) {     // ascending CU = ascending row ranges: '>' keeps the first maximum
+                const float2 cd = cand_in[lane + k * WAVE];
+                const int ci = __float_as_int(cd.y);
+                if (cd.x > bv || (cd.x == bv && ci < bi)) { bv = cd.x; bi = ci; }
+            }
+            tk_wave_argmax(bv, bi);
+            if ((a.gflags & TKG_ID) && c == 0 && lane == 0)
+                __hip_atomic_store(reinterpret_cast<int*>(a.herr + 4) + a.tok_imm, bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return bi;
+        }
+    }
+    return a.tokpos ? a.tokpos[0] : a.tok_imm;
+}
+// GR: the pipelined-greedy variant (token from the previous launch's candidates, candidates of its own).  A separate
+// instantiation because the f32 kernel sits at the register ceiling: with the candidate code compiled in, hipcc spills 20
+// bytes per lane in the STREAMING waves' loop (one s_waitcnt vmcnt(0) + scratch store per slot: the ring drains).
+template <class SH, bool GR>
 __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c, int lane, int tid) {
     typedef TkLds<SH> LD;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
@@ -815,7 +866,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
     const int L = a.L;
-    const int tok = a.tokpos ? a.tokpos[0] : a.tok_imm, pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
+    const int tok = tk_token<GR>(a, c, lane);
+    const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
     constexpr int HPC = TK_NCU / SH::NH;
     // head h runs on CU h*HPC + (its kv group mod HPC): with the dispatcher placing block b on XCD b % 8 the heads
@@ -831,7 +883,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         rope_cs[SH::HS / 2 + lane] = sinf(rval);
     }
     unsigned long long* tr = (TK_DEBUG && a.trace) ? a.trace + (size_t)c * TK_TRACE_N : nullptr;
-    const bool nosync = TK_DEBUG && a.nosync != 0;
+    const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
 #define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
 
     for (int l = 0; l < L; ++l) {
@@ -1002,6 +1054,16 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
     for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = part[j] / xn_fin;
+    if (GR && (a.gflags & TKG_CAND_OUT)) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int j = lane; j < cn; j += WAVE) {       // the same quotient as the stored logit; ascending j per lane
+            const float v = part[j] / xn_fin;
+            if (v > bv) { bv = v; bi = c0 + j; }
+        }
+        tk_wave_argmax(bv, bi);
+        if (lane == 0) tk_cand(a, (a.gflags >> 1) & 1)[c] = make_float2(bv, __int_as_float(bi));
+    }
     if (!ok && lane == 0) {
         atomicOr(a.err, 0x1000u);
         if (a.herr) __hip_atomic_store(a.herr, 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1245,7 +1307,7 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
     const int L = a.L;
     const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
-    const bool nosync = TK_DEBUG && a.nosync != 0;
+    const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
     constexpr int HPC = TK_NCU / SH::NH;
     const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
@@ -1279,7 +1341,7 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
     tk_phase_body<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
-template <class SH>
+template <class SH, bool GR = false>
 __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1299,7 +1361,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         a.cn = SH::RPT * (SH::CB + (c < SH::CX ? 1 : 0));
         a.c0 = SH::RPT * (c * SH::CB + min(c, SH::CX));
     }
-    if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH>(a, lds, c, lane, tid); }
+    if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
     else if constexpr (SH::COOP) tk_stream_coop<SH>(a, lds, c, wid, lane, tid);
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }

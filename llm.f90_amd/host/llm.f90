@@ -97,8 +97,32 @@ contains
 end module arg_parse
 
 
+! Tokens of llmk_decode_greedy reach the terminal as they are resolved, like the reference's own loop prints them
+! (llama2.f90:396): the C-ABI calls ts_on_token from the calling thread, in order.
+module token_stream
+  use iso_c_binding
+  implicit none
+  character(:), dimension(:), allocatable :: ts_vocab
+  integer(4), allocatable :: ts_len(:)
+  logical :: ts_print = .true.
+  real :: ts_first = 0                  ! the host's time_ms() at the first streamed token (0: none yet)
+contains
+  subroutine ts_on_token(idx, tok, user) bind(C)
+    integer(c_int), value :: idx, tok
+    type(c_ptr), value :: user
+    integer(4) :: ticks
+    if (ts_print) write (*, fmt="(A)", advance="no") ts_vocab(tok)(1:ts_len(tok))
+    if (ts_first == 0) then
+       call system_clock(ticks)          ! the same clock as time_ms() (llama2.f90:417-425)
+       ts_first = real(ticks)
+    end if
+  end subroutine
+end module token_stream
+
+
 program llm
   use iso_c_binding
+  use token_stream
   use precision_module
   use weight_module
   use arg_parse
@@ -119,7 +143,8 @@ program llm
   integer(4), allocatable :: vocab_len(:)
   integer, allocatable :: prompt_tokens(:)
   integer(c_int), allocatable :: batch(:)
-  integer :: pos0, k
+  integer(c_int), allocatable :: stream_ids(:)
+  integer :: pos0, k, loop_end
   integer :: seq_len, pos, token, next_tok, l, hs, j, max_len
   integer(c_int) :: flags, rc
   real(kind=wp) :: t_start, t_end
@@ -218,25 +243,35 @@ program llm
      if (lead) write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
      pos0 = k + 2
   end if
-  do pos = pos0, seq_len
-     if (opts%device_argmax .and. opts%temperature == 0 .and. pos > size(prompt_tokens)) then
-        call llmk_check(llmk_forward_greedy(ctx, int(token, c_int), int(pos, c_int), rc), "llmk_forward_greedy")
-        next_tok = rc
+  ! --device-argmax at temperature 0: every position after the prompt is one call (llmk_decode_greedy: the argmax stays on
+  ! the device, the launches are enqueued back to back, the ids stream back through mapped memory and are printed as they
+  ! arrive).  The positions whose next token is a PROMPT token still go through the loop below.
+  loop_end = seq_len
+  if (opts%device_argmax .and. opts%temperature == 0 .and. opts%ngpu == 1) loop_end = min(seq_len, max(size(prompt_tokens), pos0 - 1))
+  do pos = pos0, loop_end
+     call llmk_check(llmk_forward(ctx, int(token, c_int), int(pos, c_int), logits), "llmk_forward")
+     if (pos <= size(prompt_tokens)) then
+        next_tok = prompt_tokens(pos)
+     else if (opts%temperature == 0) then
+        next_tok = maxloc(logits, dim=1)
      else
-        call llmk_check(llmk_forward(ctx, int(token, c_int), int(pos, c_int), logits), "llmk_forward")
-        if (pos <= size(prompt_tokens)) then
-           next_tok = prompt_tokens(pos)
-        else if (opts%temperature == 0) then
-           next_tok = maxloc(logits, dim=1)
-        else
-           probs = softmax_t(logits / opts%temperature)
-           next_tok = sample(probs)
-        end if
+        probs = softmax_t(logits / opts%temperature)
+        next_tok = sample(probs)
      end if
      token = next_tok
      if (lead) write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
      if (t_start == 0) t_start = time_ms()           ! clock starts after the first token
   end do
+  if (loop_end < seq_len) then
+     allocate(stream_ids(seq_len - loop_end))
+     ts_vocab = vocab
+     ts_len = vocab_len
+     ts_print = lead
+     call llmk_check(llmk_decode_greedy(ctx, int(token, c_int), int(loop_end + 1, c_int), int(seq_len - loop_end, c_int), &
+          stream_ids, c_funloc(ts_on_token), c_null_ptr), "llmk_decode_greedy")
+     token = stream_ids(size(stream_ids))
+     if (t_start == 0) t_start = ts_first
+  end if
   t_end = time_ms()
 
   call llmk_check(llmk_timings(ctx, ktimes), "llmk_timings")

@@ -100,6 +100,20 @@ module llmk_binding
        integer(c_int), value :: token, pos
        integer(c_int), intent(out) :: next_token
      end function
+     ! n positions at temperature 0 with the argmax on the device and no host round trip per token; on_token
+     ! (void(int index, int token, void* user), or c_null_funptr) is called in order as the ids arrive
+     integer(c_int) function llmk_decode_greedy(ctx, token, pos0, n, ids_out, on_token, user) bind(C, name="llmk_decode_greedy")
+       import :: c_int, c_ptr, c_funptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: token, pos0, n
+       integer(c_int), intent(out) :: ids_out(*)
+       type(c_funptr), value :: on_token
+       type(c_ptr), value :: user
+     end function
+     integer(c_int) function llmk_path(ctx) bind(C, name="llmk_path")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
      integer(c_int) function llmk_reset(ctx) bind(C, name="llmk_reset")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

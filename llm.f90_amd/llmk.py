@@ -24,8 +24,14 @@ FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_p2p_handle", "llmk_tp_p2p_connect",
            "llmk_tp_p2p_connect_local", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
-           "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_reset", "llmk_timings",
-           "llmk_time_kernel", "llmk_peek", "llmk_destroy", "llmk_strerror", "llmk_version"]
+           "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_decode_greedy", "llmk_reset", "llmk_timings",
+           "llmk_time_kernel", "llmk_peek", "llmk_path", "llmk_destroy", "llmk_strerror", "llmk_version"]
+PATH_NAMES = {0: "multi-kernel (5 launches per layer)", 1: "persistent whole-token kernel",
+              2: "tensor-parallel rank: 6 launches per layer + one-shot peer-memory exchanges",
+              3: "tensor-parallel rank: eager launches + RCCL collectives", 4: "tensor-parallel rank, collectives not connected"}
+
+
+TOKEN_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_void_p)
 
 
 class LlmkError(RuntimeError):
@@ -75,11 +81,13 @@ def lib():
         L.llmk_forward.argtypes = [vp, ci, ci, cf]
         L.llmk_prefill.argtypes = [vp, C.POINTER(ci), ci, ci, cf]
         L.llmk_forward_greedy.argtypes = [vp, ci, ci, C.POINTER(ci)]
+        L.llmk_decode_greedy.argtypes = [vp, ci, ci, ci, C.POINTER(ci), vp, vp]
         L.llmk_reset.argtypes = [vp]
         L.llmk_timings.argtypes = [vp, cf]
         L.llmk_time_kernel.argtypes = [vp, ci, ci, cf, C.POINTER(C.c_double)]
         L.llmk_peek.argtypes = [vp, ci, ci, ci, cf, ci]
         L.llmk_destroy.argtypes = [vp]
+        L.llmk_path.argtypes = [vp]
         L.llmk_strerror.argtypes = [ci]
         L.llmk_strerror.restype = C.c_char_p
         L.llmk_version.argtypes = []
@@ -150,6 +158,14 @@ class Llmk:
         nxt = C.c_int(0)
         _ck(lib().llmk_forward_greedy(self._h, token, pos, C.byref(nxt)))
         return nxt.value
+
+    def decode_greedy(self, token: int, pos0: int, n: int, on_token=None) -> np.ndarray:
+        """n positions from pos0 at temperature 0 with the argmax on the device (llmk_decode_greedy); returns the n ids."""
+        ids = np.zeros(n, np.int32)
+        cb = TOKEN_FN(on_token) if on_token else None
+        _ck(lib().llmk_decode_greedy(self._h, token, pos0, n, ids.ctypes.data_as(C.POINTER(C.c_int)),
+                                     C.cast(cb, C.c_void_p) if cb else None, None))
+        return ids
 
     def generate(self, n: int, prompt=(), want_logits: bool = True, greedy_on_device: bool = False):
         """The reference generation loop at temperature 0 (llama2.f90:376-402)."""
@@ -233,6 +249,12 @@ class Llmk:
         out = np.empty(n, np.float32)
         _ck(lib().llmk_peek(self._h, which, layer, pos, out.ctypes.data_as(C.POINTER(C.c_float)), n))
         return out
+
+    def path(self) -> int:
+        return lib().llmk_path(self._h)
+
+    def path_name(self) -> str:
+        return PATH_NAMES.get(self.path(), "?")
 
     def close(self):
         if self._h:

@@ -1,0 +1,24 @@
+"""Build-time guards that need no GPU: hipcc cross-compiles for gfx950 here."""
+import os
+import re
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_persistent_kernels_do_not_spill():
+    """The persistent token kernels sit at the 256-VGPR ceiling on purpose (register tile ring).  A spill in a streaming
+    wave costs one `s_waitcnt vmcnt(0)` + scratch store per ring slot -- the whole prefetch ring drains -- and hipcc's
+    allocation at the ceiling flips on unrelated edits (round 3: `if (a.gflags & 16)` instead of `if (a.herr)` in the
+    service wave put 36 bytes of scratch into the f32 kernel's streaming loop).  So: zero scratch, checked on every build."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_tools", "tk_resources.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l for l in r.stdout.splitlines() if "token_kernel" in l or "tk2" in l]
+    assert len(rows) >= 5, r.stdout
+    for l in rows:
+        m = re.search(r"VGPR\s+(\d+).*scratch\s+(\d+)", l)
+        assert m, l
+        assert int(m.group(2)) == 0, l
+        assert int(m.group(1)) <= 256, l

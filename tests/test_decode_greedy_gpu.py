@@ -1,0 +1,111 @@
+"""llmk_decode_greedy: the temperature-0 generation loop (llama2.f90:379-396) with the argmax on the device and the
+launches enqueued back to back.  Bar: the ids are the real reference's own greedy ids (goldens), and bit-identical to
+what the per-token entry points return."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, safe_positions
+from llm_f90_amd import llmk
+
+pytestmark = pytest.mark.gpu
+LLM = os.path.join(ROOT, "llm.f90_amd", "host", "llm")
+
+
+@pytest.mark.parametrize("tag", ["tk-small", "tk-small-long", "tiny-gqa", "tiny-hs128"])
+@pytest.mark.parametrize("flags", [0, llmk.FLAG_MULTI_KERNEL], ids=["default", "multikernel"])
+def test_decode_greedy_returns_the_reference_ids(tag, flags, gguf):
+    """tk-small* run the pipelined persistent kernel, the tiny shapes the per-token fallback inside the same call."""
+    g = load_golden(tag)
+    fw = gguf.synth_fused(gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+    n = int(g["n"])
+    m = llmk.Llmk(fw, flags=flags)
+    if tag.startswith("tk-small") and flags == 0:
+        assert m.path() == 1
+    seen = []
+    ids = m.decode_greedy(2, 1, n, on_token=lambda i, t, u: seen.append((i, t)))
+    assert np.array_equal(ids, g["tokens"])                       # the real reference's transcript, id for id
+    assert seen == list(enumerate(ids.tolist()))                  # streamed in order, each id once
+    m.reset()
+    toks, _ = m.generate(n, want_logits=False, greedy_on_device=True)
+    assert np.array_equal(ids, toks)
+    m.close()
+
+
+def test_decode_greedy_resumes_after_forward_and_prefill(gguf):
+    """positions 1..k through llmk_forward / llmk_prefill (a prompt), the rest in one pipelined call; twice in a row
+    (the candidate buffers and id slots are reused); the KV rows it leaves are the per-token path's."""
+    g = load_golden("tk-small-long")
+    fw = gguf.synth_fused(gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+    ref = g["tokens"]
+    n = 200
+    m = llmk.Llmk(fw)
+    for k in (1, 7, 130):
+        m.reset()
+        tok = 2
+        for pos in range(1, k + 1):
+            tok = int(np.argmax(m.forward(tok, pos))) + 1
+        assert tok == ref[k - 1]
+        ids = m.decode_greedy(tok, k + 1, n - k)
+        assert np.array_equal(ids, ref[k:n]), k
+    m.reset()
+    k = 129
+    lg = m.prefill([2] + ref[:k - 1].tolist(), 1)
+    ids = m.decode_greedy(int(np.argmax(lg)) + 1, k + 1, n - k)
+    assert np.array_equal(ids, ref[k:n])
+    kv = m.peek(4, fw.shape.kv_dim, 1, n)
+    m.reset()
+    m.generate(n, want_logits=False)
+    np.testing.assert_array_equal(kv, m.peek(4, fw.shape.kv_dim, 1, n))
+    with pytest.raises(llmk.LlmkError):
+        m.decode_greedy(2, fw.shape.seq_len, 2)                   # runs past the context
+    m.close()
+
+
+def test_decode_greedy_tinyllama_full_size_matches_the_real_reference(gguf):
+    """BASELINE.json configs[1] at its real size: 256 positions in one call against the reference's own ids."""
+    g = load_golden("tinyllama")
+    s = gguf.SHAPES["tinyllama"]
+    m = llmk.Llmk(gguf.synth_fused(s, int(g["seed"])))
+    assert m.path() == 1
+    n = 256
+    ids = m.decode_greedy(2, 1, n)
+    safe = safe_positions(g, n)
+    first_bad = int(np.argmin(safe)) if not safe.all() else n     # teacher forcing is impossible here: compare up to the
+    assert first_bad > 64                                         # first position whose top-1 margin is inside the tolerance
+    assert np.array_equal(ids[:first_bad], g["tokens"][:first_bad])
+    m.reset()
+    toks, _ = m.generate(n, want_logits=False)                    # host consumer, same kernel arithmetic: identical ids
+    assert np.array_equal(ids, toks)
+    m.close()
+
+
+@pytest.mark.parametrize("wtype,shape", [(1, "tk-small16")])
+def test_decode_greedy_f16_kernel(wtype, shape, gguf):
+    fw = gguf.synth_fused(gguf.SHAPES[shape], 4242, wtype)
+    m = llmk.Llmk(fw)
+    assert m.path() == 1
+    n = 96
+    ids = m.decode_greedy(2, 1, n)
+    m.reset()
+    toks, _ = m.generate(n, want_logits=False)
+    assert np.array_equal(ids, toks)
+    m.close()
+
+
+def test_cli_device_argmax_streams_the_reference_transcript(gguf, tmp_path):
+    """`llm --device-argmax` = one llmk_decode_greedy call after the prompt; stdout is the reference's, byte for byte."""
+    for tag in ("tk-small", "tk-small-prompt", "tk-small-long-prompt"):
+        g = load_golden(tag)
+        path = str(tmp_path / "m.gguf")
+        gguf.write_synth_gguf(path, gguf.SHAPES[str(g["shape"])], int(g["seed"]))
+        args = [LLM, "-m", path, "-n", str(int(g["n"])), "-t", "0", "--device-argmax"]
+        if str(g["prompt"]):
+            args += ["-p", str(g["prompt"])]
+        r = subprocess.run(args, capture_output=True, cwd=str(tmp_path), timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out, ref = r.stdout.split(b"\n"), bytes(g["stdout"]).split(b"\n")
+        k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
+        assert out[:k] == ref[:k], tag
