@@ -157,6 +157,16 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
         handles = [None] * tp_size
         rep.dist.all_gather_object(handles, m.tp_p2p_handle())
         m.tp_p2p_connect(handles)
+        # the peer-memory path proves itself on THIS node before the first token; unless every rank passes, all ranks
+        # drop it together and run over RCCL (the line's "parallelism" says which collective actually ran)
+        verdicts = [None] * tp_size
+        rep.dist.all_gather_object(verdicts, m.tp_p2p_selftest(64))
+        m.p2p_selftest = verdicts
+        if any(verdicts):
+            m.tp_p2p_disable()
+            uids = [None] * tp_size
+            rep.dist.all_gather_object(uids, llmk.Llmk.tp_unique_id() if tp_rank == 0 else None)
+            m.tp_init_comm(uids[0])
     elif tp_size > 1 or rep is not None:
         uid = llmk.Llmk.tp_unique_id() if tp_rank == 0 else bytes(128)
         if rep is not None and rep.dist is not None:
@@ -349,7 +359,7 @@ def main():
     elapsed, gpu_ids = runs[order[repeats // 2]]
     if any(ids != gpu_ids for _, ids in runs):
         raise SystemExit("greedy transcripts differ between repetitions")
-    if not np.all(np.isfinite(lg)):
+    if not step and not np.all(np.isfinite(lg)):     # (--greedy-on-device never brings logits to the host)
         raise SystemExit("non-finite logits")
 
     tok_s = (1 if a.tp else world) * K / elapsed   # --tp: ONE model over all ranks; else N replicas
@@ -366,7 +376,8 @@ def main():
         "value_all": [round((1 if a.tp else world) * K / t, 1) for t, _ in runs],
         "config": {"workload": f"{a.shape} {a.type} decode, greedy, positions {W + 1}..{W + K} (./llm -n {W + K} -t 0)",
                    "consumer": "device argmax, K positions pipelined in one call (llmk_decode_greedy): an AUXILIARY line, the headline keeps the reference's host consumer" if step else "logits to host + host argmax (llmk_forward)",
-                   "parallelism": ((f"tp{world} (row-parallel GEMVs, " + ("one-shot peer-memory all-reduce" if a.tp_collective == "p2p" else "RCCL all-reduce")
+                   "parallelism": ((f"tp{world} (row-parallel GEMVs, " + ("one-shot peer-memory all-reduce" if m.path() == 2 else "RCCL all-reduce")
+                                    + (f", peer-memory self-test verdicts per rank {getattr(m, 'p2p_selftest', None)}" if a.tp_collective == "p2p" else "")
                                     + (", ALL RANKS SHARING ONE GPU: protocol check, not a scaling number" if os.environ.get("LLMK_SHARE_GPU") else "") + ")")
                                    if a.tp else "replicas" if world > 1 else "single GPU"), "seed": SEED,
                    "path": m.path_name()},

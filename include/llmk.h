@@ -114,6 +114,13 @@ int llmk_tp_init_comm(llmk_ctx *ctx, const char id[128]);
 int llmk_tp_p2p_handle(llmk_ctx *ctx, char handle_out[64]);
 int llmk_tp_p2p_connect(llmk_ctx *ctx, const char *handles);
 int llmk_tp_p2p_connect_local(llmk_ctx *ctx, llmk_ctx *const *ranks);
+/* Prove the peer-memory path on the hardware it runs on before the first token (all ranks call it together, after the
+ * connect): `iters` rounds of both all-reduce halves and the all-gather on known integers, with the real kernels and
+ * their bounded spins.  0 = this rank saw only correct sums; LLMK_E_TIMEOUT / LLMK_E_COMM / a HIP code otherwise.  The
+ * host gathers the ranks' verdicts over its side channel; unless ALL are 0, every rank calls llmk_tp_p2p_disable and
+ * llmk_tp_init_comm, and the token pass runs over RCCL (what `llm --ngpu` and `bench.py --tp` do). */
+int llmk_tp_p2p_selftest(llmk_ctx *ctx, int iters);
+int llmk_tp_p2p_disable(llmk_ctx *ctx);
 
 /* Single-process stepping of a tensor-parallel ctx, for verification on one GPU (no communicator): the
  * caller plays the collective.  llmk_tp_begin sets token/pos; llmk_tp_segment runs
@@ -137,7 +144,9 @@ int llmk_upload(llmk_ctx *ctx, int tensor_id, const void *host, size_t nbytes, i
 
 /* Same, for `rows` consecutive rows of layer `layer` starting at `row_offset` (lets a loader
  * stream one GGUF tensor at a time, e.g. attn_k into rows E..E+KV-1 of wqkv, read_ggml.f90:286,
- * without materialising the fused array on the host). */
+ * without materialising the fused array on the host).  Rows and offsets are those of the FULL tensor on a
+ * tensor-parallel ctx too: the shim keeps the part of the range its shard holds (possibly nothing), so a rank may hand
+ * over whole layers or only its own rows (host/gguf_loader.f90 stream_ggml_matrices reads nothing else from the file). */
 int llmk_upload_rows(llmk_ctx *ctx, int tensor_id, int layer, int row_offset, int rows, const void *host,
                      size_t nbytes, int ggml_type);
 

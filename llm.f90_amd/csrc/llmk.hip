@@ -53,6 +53,7 @@ struct DevTensor {
     int type = LLMK_TYPE_F32;
     bool uploaded = false;
     size_t rows_uploaded = 0;
+    bool alias = false;      // `data` points into another tensor's allocation (the rmsnorm gains share one): never freed itself
 };
 
 }  // namespace
@@ -296,9 +297,7 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
     TokenArgs a;
     a.gflags = g.gflags | ((TK_DEBUG && getenv("LLMK_TK_NOSYNC")) ? TKG_NOSYNC : 0);   // NOSYNC: libllmk_debug.so only
     a.emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
-    a.rms_att = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;
-    a.rms_ffn = (const float*)c->t[LLMK_RMS_FFN_WEIGHT].data;
-    a.rms_final = (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data;
+    a.rms = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;      // att | ffn | final in one allocation (llmk_create_tp)
     a.wqkv = c->t[LLMK_WQKV].data;
     a.wo = c->t[LLMK_WO].data;
     a.w13 = c->t[LLMK_W13].data;
@@ -307,20 +306,18 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
     a.kc = c->d_kc;
     a.vc = c->d_vc;
     a.rope = c->d_rope;
-    a.tokpos = direct ? nullptr : c->d_tokpos;
+    a.tokpos = (direct || g.gflags) ? nullptr : c->d_tokpos;   // immediates: direct mode, and every launch of a greedy pipeline (its own pos and serial)
     a.tok_imm = (g.gflags & TKG_CAND_IN) ? g.id_index : c->h_tokpos[0];   // the token comes from the candidates: the word carries the id's slot
     a.pos_imm = c->h_tokpos[1];
     a.serial_imm = c->h_tokpos[2];
-    a.g_qkv = c->d_gran;
-    a.g_xb = a.g_qkv + TK::QKV;
-    a.g_xa = a.g_xb + TK::E;
-    a.g_hb = a.g_xa + TK::E;
-    a.g_x = a.g_hb + TK::H;
+    a.g_qkv = c->d_gran;         // qkv | xb | xa | hb | x (token_kernel.h tk_g_xb ...)
     a.logits = direct ? c->h_logits_dev : c->d_logits;
     a.err = reinterpret_cast<unsigned*>(c->d_logits + c->V);
     a.herr = (direct || g.gflags) ? reinterpret_cast<unsigned*>(c->h_logits_dev + c->V) : nullptr;
     a.zeros = c->d_zeros;
+#ifdef LLMK_TK_DEBUG
     a.trace = c->d_trace;
+#endif
     a.L = c->L;
     a.S = c->S;
     a.eps = c->eps;
@@ -892,10 +889,18 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         // q4_0 device row: K/2 nibble bytes (16-byte vectors, one per 32-weight block), then the K/32 f16 block scales,
         // zero-padded to whole groups of 64 (a wave-wide scale load past a ragged row end must read finite zeros)
         t.row_bytes = t.type == LLMK_TYPE_Q4_0 ? q4_row_stride(d.K) : row_bytes_for(t.type, d.K);
-        CK(hipMalloc(&t.data, rows * t.row_bytes + TENSOR_SLACK));
+        // the three rmsnorm gain tensors share ONE allocation, att [L][E] | ffn [L][E] | final [E]: the persistent kernel
+        // addresses them from one pointer (token_kernel.h TokenArgs::rms)
+        if (i == LLMK_RMS_FFN_WEIGHT || i == LLMK_RMS_FINAL_WEIGHT) {
+            t.alias = true;
+            t.data = (char*)c->t[LLMK_RMS_ATT_WEIGHT].data + (size_t)(i == LLMK_RMS_FFN_WEIGHT ? L : 2 * L) * E * sizeof(float);
+            continue;
+        }
+        const size_t extra = i == LLMK_RMS_ATT_WEIGHT ? ((size_t)L + 1) * E * sizeof(float) : 0;
+        CK(hipMalloc(&t.data, rows * t.row_bytes + extra + TENSOR_SLACK));
         if (rc == LLMK_OK) {
             if (t.type == LLMK_TYPE_Q4_0) CK(hipMemset(t.data, 0, rows * t.row_bytes + TENSOR_SLACK));
-            else CK(hipMemset((char*)t.data + rows * t.row_bytes, 0, TENSOR_SLACK));
+            else CK(hipMemset((char*)t.data + rows * t.row_bytes + extra, 0, TENSOR_SLACK));
         }
     }
     const size_t kvn = (size_t)L * S * c->KVl;
@@ -999,31 +1004,52 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
     return LLMK_OK;
 }
 
-// One FULL layer of a full (unsharded) host tensor -> this rank's shard of it.
-static int upload_layer_sharded(llmk_ctx* c, int tid, int layer, const uint8_t* src, int type) {
+// Rows [row0, row0 + nrows) of one layer of a full (unsharded) host tensor -> the part of them this rank's shard holds.
+// The shard is a few runs of global rows (its query heads / K rows / V rows; its gate / up rows; its vocabulary rows) or,
+// for the row-parallel wo / w2, every row but only the input columns of the local heads / hidden slice: each run is
+// intersected with the rows handed over, so a loader may stream any row range -- in particular ONLY the rows of its own
+// shard (host/gguf_loader.f90 stream_ggml_matrices) -- and whole layers keep working.
+static int upload_rows_sharded(llmk_ctx* c, int tid, int layer, int row0, int nrows, const uint8_t* src, int type) {
     const TensorDesc& g = c->gdesc[tid];
     const size_t pitch = row_bytes_for(type, g.K);
     const int r = c->tp_rank, E = c->E, KV = c->KV, H = c->H;
-    int rc = LLMK_OK;
+    struct Run { int gfirst, n, lfirst; };            // global first row, count, local first row
+    Run runs[3];
+    int nruns = 0;
+    size_t col_off = 0, col_bytes = pitch;
     switch (tid) {
         case LLMK_WQKV:  // rows: this rank's query heads, then its kv heads' K rows, then their V rows
-            rc = upload_block(c, tid, layer, 0, c->Eq, src + (size_t)(r * c->Eq) * pitch, pitch, 0, pitch);
-            if (!rc) rc = upload_block(c, tid, layer, c->Eq, c->KVl, src + (size_t)(E + r * c->KVl) * pitch, pitch, 0, pitch);
-            if (!rc) rc = upload_block(c, tid, layer, c->Eq + c->KVl, c->KVl, src + (size_t)(E + KV + r * c->KVl) * pitch, pitch, 0, pitch);
-            return rc;
+            runs[nruns++] = {r * c->Eq, c->Eq, 0};
+            runs[nruns++] = {E + r * c->KVl, c->KVl, c->Eq};
+            runs[nruns++] = {E + KV + r * c->KVl, c->KVl, c->Eq + c->KVl};
+            break;
         case LLMK_WO:    // all E rows, the input columns of this rank's heads
-            return upload_block(c, tid, layer, 0, E, src, pitch, row_bytes_for(type, r * c->Eq), row_bytes_for(type, c->Eq));
+            runs[nruns++] = {0, E, 0};
+            col_off = row_bytes_for(type, r * c->Eq); col_bytes = row_bytes_for(type, c->Eq);
+            break;
         case LLMK_W13:   // gate rows then up rows of this rank's hidden slice
-            rc = upload_block(c, tid, layer, 0, c->Hl, src + (size_t)(r * c->Hl) * pitch, pitch, 0, pitch);
-            if (!rc) rc = upload_block(c, tid, layer, c->Hl, c->Hl, src + (size_t)(H + r * c->Hl) * pitch, pitch, 0, pitch);
-            return rc;
+            runs[nruns++] = {r * c->Hl, c->Hl, 0};
+            runs[nruns++] = {H + r * c->Hl, c->Hl, c->Hl};
+            break;
         case LLMK_W2:    // all E rows, the input columns of this rank's hidden slice
-            return upload_block(c, tid, layer, 0, E, src, pitch, row_bytes_for(type, r * c->Hl), row_bytes_for(type, c->Hl));
+            runs[nruns++] = {0, E, 0};
+            col_off = row_bytes_for(type, r * c->Hl); col_bytes = row_bytes_for(type, c->Hl);
+            break;
         case LLMK_WCLS:
-            return upload_block(c, tid, layer, 0, c->Vl, src + (size_t)(r * c->Vl) * pitch, pitch, 0, pitch);
+            runs[nruns++] = {r * c->Vl, c->Vl, 0};
+            break;
         default:         // replicated: embedding table and norm gains
-            return upload_block(c, tid, layer, 0, g.rows, src, pitch, 0, pitch);
+            runs[nruns++] = {0, g.rows, 0};
+            break;
     }
+    for (int i = 0; i < nruns; ++i) {
+        const int a = std::max(runs[i].gfirst, row0), b = std::min(runs[i].gfirst + runs[i].n, row0 + nrows);
+        if (a >= b) continue;
+        const int rc = upload_block(c, tid, layer, runs[i].lfirst + (a - runs[i].gfirst), b - a, src + (size_t)(a - row0) * pitch, pitch,
+                                    col_off, col_bytes);
+        if (rc) return rc;
+    }
+    return LLMK_OK;
 }
 
 int llmk_upload_rows(llmk_ctx* c, int tid, int layer, int row_offset, int rows, const void* host, size_t nbytes,
@@ -1036,10 +1062,7 @@ int llmk_upload_rows(llmk_ctx* c, int tid, int layer, int row_offset, int rows, 
     if (ggml_type != t.type) return LLMK_E_TYPE;
     if (nbytes != (size_t)rows * row_bytes_for(ggml_type, g.K)) return LLMK_E_SIZE;
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (c->tp_size > 1) {   // a shard is cut from a whole layer: partial-row uploads are a single-GPU convenience
-        if (row_offset != 0 || rows != g.rows) return LLMK_E_ARG;
-        return upload_layer_sharded(c, tid, layer, (const uint8_t*)host, ggml_type);
-    }
+    if (c->tp_size > 1) return upload_rows_sharded(c, tid, layer, row_offset, rows, (const uint8_t*)host, ggml_type);
     const size_t pitch = row_bytes_for(ggml_type, g.K);
     return upload_block(c, tid, layer, row_offset, rows, (const uint8_t*)host, pitch, 0, pitch);
 }
@@ -1200,12 +1223,12 @@ int llmk_decode_greedy(llmk_ctx* c, int token, int pos0, int n, int* ids_out, ll
             c->h_tokpos[1] = pos0 + i;
             c->h_tokpos[2] += 1;
             TkGreedy g;
-            g.gflags = TKG_CAND_OUT | ((i & 1) ? TKG_PARITY : 0) | (i ? TKG_CAND_IN | TKG_ID : 0);
+            g.gflags = TKG_GREEDY | (i ? TKG_CAND_IN | TKG_ID : 0);
             g.id_index = i - 1;
             c->tk_short_grid = false;
             HIPCHK(launch_token_kernel(c, false, g));
         }
-        hipLaunchKernelGGL(cand_resolve_kernel, dim3(1), dim3(64), 0, c->stream, d_cand + (size_t)((n - 1) & 1) * TK_NCU,
+        hipLaunchKernelGGL(cand_resolve_kernel, dim3(1), dim3(64), 0, c->stream, d_cand + (size_t)((pos0 + n - 1) & 1) * TK_NCU,
                            h_ids_dev + (n - 1), c->d_next);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->h_next + 1, c->d_logits + c->V, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1381,6 +1404,7 @@ int llmk_tp_unique_id(char id_out[128]) {
 
 int llmk_tp_init_comm(llmk_ctx* c, const char id_in[128]) {
     if (!c || !id_in || c->comm) return LLMK_E_ARG;
+    if (c->p2p) return LLMK_E_STATE;      // llmk_tp_p2p_disable first: a ctx runs ONE kind of collective
     HIPCHK(hipSetDevice(c->cfg.device));
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof(id));
@@ -1449,6 +1473,87 @@ int llmk_tp_p2p_connect_local(llmk_ctx* c, llmk_ctx* const* ranks) {
         c->peers.inbox[r] = o->d_inbox;
     }
     c->p2p = true;
+    return LLMK_OK;
+}
+
+// ---- self-test of the peer-memory collectives ----------------------------------------------------------------------------
+// What differs between one GPU and eight is exactly what a 1-GPU box cannot show: peers' system-scope stores landing in
+// this rank's fine-grained inbox over xGMI, lazy peer access through the IPC mapping, polls of memory a remote device
+// writes.  So every rank proves it on the hardware it runs on BEFORE the first token: `iters` rounds of both all-reduce
+// halves and the all-gather on known integers (exact in f32), with the bounded spins of the real kernels.  The host
+// collects the ranks' verdicts over its side channel and keeps the peer-memory path only if ALL passed; otherwise every
+// rank calls llmk_tp_p2p_disable and the token pass runs over RCCL (llmk_tp_init_comm).
+__global__ void tp_selftest_fill_kernel(float* part, float* x, float* logits, int E, int V, int me, int P, int it) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) { part[i] = (float)((i * 7 + me * 13 + it) % 1021); x[i] = 0.f; }
+    if (i < V) logits[i] = (i / (V / P) == me) ? (float)((i * 3 + it) % 4093) : -1.f;
+}
+__global__ void tp_selftest_check_kernel(const float* x, const float* logits, int E, int V, int P, int it, unsigned* bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) {
+        float want = 0.f;
+        for (int r = 0; r < P; ++r) want += (float)((i * 7 + r * 13 + it) % 1021);
+        if (x[i] != 2.f * want) atomicAdd(bad, 1u);      // two all-reduces were added into x
+    }
+    if (i < V && logits[i] != (float)((i * 3 + it) % 4093)) atomicAdd(bad, 1u);
+}
+int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) {
+    if (!c || iters < 1) return LLMK_E_ARG;
+    if (!c->p2p) return LLMK_E_COMM;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    unsigned* d_bad = nullptr;
+    HIPCHK(hipMalloc(&d_bad, sizeof(unsigned)));
+    HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
+    const int n = std::max(c->E, c->V);
+    int rc = LLMK_OK;
+    for (int it = 0; it < iters && rc == LLMK_OK; ++it) {
+        c->h_tokpos[2] += 1;                     // fresh epochs, as for a token
+        hipError_t e = hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(tp_selftest_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_part, c->d_x, c->d_logits, c->E,
+                               c->V, c->tp_rank, c->tp_size, it);
+            e = launch_tp_allreduce_add(c, 0);
+        }
+        if (e == hipSuccess) e = launch_tp_allreduce_add(c, 1);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(tp_allgather_kernel, dim3((c->V + 255) / 256), dim3(256), 0, c->stream, c->peers, c->d_logits, c->d_tokpos,
+                               2 * c->L, c->tp_rank, c->tp_size, c->E, c->V, reinterpret_cast<unsigned*>(c->d_logits + c->V));
+            hipLaunchKernelGGL(tp_selftest_check_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_x, c->d_logits, c->E, c->V,
+                               c->tp_size, it, d_bad);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
+    }
+    unsigned bad = 0, err = 0;
+    if (rc == LLMK_OK) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(&err, c->d_logits + c->V, sizeof(err), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
+        else if (err) rc = LLMK_E_TIMEOUT;
+        else if (bad) rc = LLMK_E_COMM;
+    }
+    hipFree(d_bad);
+    // leave the ctx as a fresh one: x, the logits and the sticky word
+    hipMemsetAsync(c->d_x, 0, (size_t)c->E * sizeof(float), c->stream);
+    hipMemsetAsync(c->d_logits, 0, ((size_t)c->V + 4) * sizeof(float), c->stream);
+    hipStreamSynchronize(c->stream);
+    if (rc != LLMK_OK)
+        fprintf(stderr, "llmk: rank %d of %d: the peer-memory collectives failed their self-test (%s, %u mismatches, code 0x%x)\n",
+                c->tp_rank, c->tp_size, rc == LLMK_E_TIMEOUT ? "a peer's granules never arrived" : rc == LLMK_E_COMM ? "wrong sums" : "HIP error",
+                bad, err);
+    return rc;
+}
+
+// Stop using the peer-memory collectives on this ctx (after a failed self-test on ANY rank): the token pass then needs
+// the RCCL communicator (llmk_tp_init_comm).  The inbox stays mapped until llmk_destroy.
+int llmk_tp_p2p_disable(llmk_ctx* c) {
+    if (!c) return LLMK_E_ARG;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->p2p = false;
+    if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }
+    if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
     return LLMK_OK;
 }
 
@@ -1526,7 +1631,7 @@ int llmk_destroy(llmk_ctx* c) {
     if (c->graph_logits) hipGraphExecDestroy(c->graph_logits);
     if (c->graph_greedy) hipGraphExecDestroy(c->graph_greedy);
     for (int i = 0; i < LLMK_N_TENSORS; ++i) {
-        if (c->t[i].data) hipFree(c->t[i].data);
+        if (c->t[i].data && !c->t[i].alias) hipFree(c->t[i].data);
     }
     pf_teardown(c);
     void* dev[] = {c->d_kc, c->d_vc, c->d_x, c->d_q, c->d_xb, c->d_hb, c->d_logits, c->d_rope, c->d_tokpos, c->d_next,

@@ -51,9 +51,7 @@ constexpr bool TK_DEBUG = false;
 
 struct TokenArgs {
     const float* emb;        // [V][E]
-    const float* rms_att;    // [L][E]
-    const float* rms_ffn;    // [L][E]
-    const float* rms_final;  // [E]
+    const float* rms;        // rmsnorm gains, ONE allocation: att [L][E] | ffn [L][E] | final [E]  (tk_rms_att ...: see g_qkv)
     const void* wqkv;        // [L][E+2KV][E]   f32 or f16 rows (TkShape::WT)
     const void* wo;          // [L][E][E]
     const void* w13;         // [L][2H][E]
@@ -65,15 +63,17 @@ struct TokenArgs {
     const int* tokpos;       // {token0, pos1, serial} in device memory (graph replay), or null: the three fields below
     int tok_imm, pos_imm, serial_imm;
     unsigned* herr;          // optional sticky error word in HOST memory (direct mode, where logits also point at host memory; the greedy pipeline: its ids sit behind it)
-    unsigned long long* g_qkv;  // granules [E+2KV]
-    unsigned long long* g_xb;   // [E]   attention output
-    unsigned long long* g_xa;   // [E]   x after attention residual
-    unsigned long long* g_hb;   // [H]
-    unsigned long long* g_x;    // [E]   x after FFN residual
+    // exchange granules, ONE allocation: qkv [E+2KV] | xb [E] (attention output) | xa [E] (x after the attention residual) |
+    // hb [H] | x [E] (x after the FFN residual).  One pointer (tk_g_xb<SH>(a) ... add compile-time offsets) instead of five:
+    // the kernel is at its SGPR ceiling and every pointer kept live across the layer loop is two more registers that hipcc
+    // spills to VGPR lanes and reloads (v_readlane) inside the service wave's polling loops -- the token's critical path.
+    unsigned long long* g_qkv;
     float* logits;           // [V]
     unsigned* err;           // sticky error word (0 = ok)
     const float4* zeros;     // [NCU*TK_WAVES] 1 KB blocks of zeros: what empty ring slots / ragged row ends read
+#ifdef LLMK_TK_DEBUG
     unsigned long long* trace;  // debug build only: [NCU][TK_TRACE_N] wall-clock stamps of each CU's service wave
+#endif
     int L, S;
     float eps;               // rmsnorm epsilon
     int gflags;              // TKG_* bits (pipelined greedy decode, host error word; debug build: TKG_NOSYNC)
@@ -90,9 +90,10 @@ struct TokenArgs {
     // The flags share the word of the debug build's "do not wait" switch, and with TKG_CAND_IN the unused tok_imm carries
     // the index of the id to store: the argument block is exactly as large as before.
 };
-constexpr int TKG_CAND_OUT = 1;    // leave candidates in buffer (gflags >> 1) & 1
-constexpr int TKG_PARITY = 2;
-constexpr int TKG_CAND_IN = 4;     // the token is the fold of the OTHER buffer (else tok_imm / tokpos[0])
+// A launch of the GR instantiation always leaves its candidates in buffer pos & 1 (pos is live through the whole kernel
+// anyway; a flag tested after the classifier would be one more register held across the layer loop).
+constexpr int TKG_GREEDY = 1;      // host side only: launch the GR instantiation
+constexpr int TKG_CAND_IN = 4;     // the token is the fold of the previous position's buffer, (pos & 1) ^ 1 (else tok_imm / tokpos[0])
 constexpr int TKG_ID = 8;
 constexpr int TKG_NOSYNC = 32;     // debug build only: do not wait for exchange tags (wrong results; measures the pure streaming rate)
 __device__ __forceinline__ float2* tk_cand(const TokenArgs& a, int buf) {
@@ -181,6 +182,21 @@ struct TkShape {
     static_assert(HS == 64 || HS == 128, "in-kernel attention is written for head sizes 64 and 128");
     static_assert(TPR_H <= TK_NS, "every column part of a w2 row needs a wave");
 };
+
+template <class SH> __device__ __forceinline__ unsigned long long* tk_g_xb(const TokenArgs& a) { return a.g_qkv + SH::QKV; }
+template <class SH> __device__ __forceinline__ unsigned long long* tk_g_xa(const TokenArgs& a) { return a.g_qkv + SH::QKV + SH::E; }
+template <class SH> __device__ __forceinline__ unsigned long long* tk_g_hb(const TokenArgs& a) { return a.g_qkv + SH::QKV + 2 * SH::E; }
+template <class SH> __device__ __forceinline__ unsigned long long* tk_g_x(const TokenArgs& a) { return a.g_qkv + SH::QKV + 2 * SH::E + SH::H; }
+__device__ __forceinline__ const float* tk_rms_att(const TokenArgs& a, int l, int E) { return a.rms + (size_t)l * E; }
+__device__ __forceinline__ const float* tk_rms_ffn(const TokenArgs& a, int l, int E) { return a.rms + (size_t)(a.L + l) * E; }
+__device__ __forceinline__ const float* tk_rms_final(const TokenArgs& a, int E) { return a.rms + (size_t)(2 * a.L) * E; }
+__device__ __forceinline__ unsigned long long* tk_trace(const TokenArgs& a) {
+#ifdef LLMK_TK_DEBUG
+    return a.trace;
+#else
+    return nullptr;
+#endif
+}
 
 // LDS carve (bytes): xs (streaming input, up to H floats) | xraw (E) | partial | attention scratch
 template <class SH>
@@ -836,7 +852,7 @@ template <bool GR>
 __device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
     if constexpr (GR) {
         if (a.gflags & TKG_CAND_IN) {   // the previous launch's per-CU maxima -> its greedy token (plain loads: a kernel boundary lies between)
-            const float2* cand_in = tk_cand(a, ((a.gflags >> 1) & 1) ^ 1);
+            const float2* cand_in = tk_cand(a, (a.pos_imm & 1) ^ 1);
             float bv = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
@@ -882,7 +898,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         rope_cs[lane] = cosf(rval);
         rope_cs[SH::HS / 2 + lane] = sinf(rval);
     }
-    unsigned long long* tr = (TK_DEBUG && a.trace) ? a.trace + (size_t)c * TK_TRACE_N : nullptr;
+    unsigned long long* tr = (TK_DEBUG && tk_trace(a)) ? tk_trace(a) + (size_t)c * TK_TRACE_N : nullptr;
     const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
 #define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
 
@@ -893,16 +909,16 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
         TkNorm<SH::E> nrm;
         const bool coop0 = SH::COOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
-        if (!att_cu && !coop0) nrm.prefetch(a.rms_att + (size_t)l * SH::E, lane);
+        if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane);
         float xn_att = 1.f;
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
             if (coop0) {
-                ok = tk_coop_gather<SH::E, TR_E, true>(a.g_x, e_q - 1, xraw, xs, a.rms_att + (size_t)l * SH::E, red8, a.err, TK_NS, lane, nosync) && ok;
+                ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_q - 1, xraw, xs, tk_rms_att(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             } else if (l == 0) {
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
             } else {
-                ok = tk_gather<SH::E>(a.g_x, e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+                ok = tk_gather<SH::E>(tk_g_x<SH>(a), e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
             }
             TK_STAMP(1);
             if (!coop0) xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
@@ -978,14 +994,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                     o3 += redf[(w + 3) * SH::HS + d0 + lane];
                 }
                 const float o = (o0 + o1) + (o2 + o3);
-                tk_publish(a.g_xb + my_head * SH::HS + d0 + lane, e_att, o);
+                tk_publish(tk_g_xb<SH>(a) + my_head * SH::HS + d0 + lane, e_att, o);
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
         if constexpr (SH::COOP) {
-            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(a.g_xb, e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         } else {
-            if (!att_cu) ok = tk_gather<SH::E, TR_E, 32>(a.g_xb, e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+            if (!att_cu) ok = tk_gather<SH::E, TR_E, 32>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         }
         TK_STAMP(7);
         tk_barrier();
@@ -994,18 +1010,18 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (lane < a.on) {
             const float v = part[lane];
             const int r = a.o0 + lane;
-            tk_publish(a.g_xa + r, e_o, xraw[r] + v);
+            tk_publish(tk_g_xa<SH>(a) + r, e_o, xraw[r] + v);
         }
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
         if constexpr (SH::COOP) {
-            ok = tk_coop_gather<SH::E, TR_E, true>(a.g_xa, e_o, xraw, xs, a.rms_ffn + (size_t)l * SH::E, red8, a.err, TK_NS, lane, nosync) && ok;
+            ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             TK_STAMP(9);
             tk_barrier();
             xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
         } else {
-            nrm.prefetch(a.rms_ffn + (size_t)l * SH::E, lane);
-            ok = tk_gather<SH::E>(a.g_xa, e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+            nrm.prefetch(tk_rms_ffn(a, l, SH::E), lane);
+            ok = tk_gather<SH::E>(tk_g_xa<SH>(a), e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
             TK_STAMP(9);
             xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
             tk_barrier();
@@ -1018,11 +1034,11 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             gsum = gsum / xn_ffn;
             usum = usum / xn_ffn;
             const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
-            tk_publish(a.g_hb + c * (SH::R_A / 2) + lane, e_a, hb * usum);
+            tk_publish(tk_g_hb<SH>(a) + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        if constexpr (SH::COOP) ok = tk_coop_gather<SH::H, TR_H, false>(a.g_hb, e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
-        else ok = tk_gather<SH::H, TR_H, 32>(a.g_hb, e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        if constexpr (SH::COOP) ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+        else ok = tk_gather<SH::H, TR_H, 32>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -1033,7 +1049,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 #pragma unroll
             for (int p = 0; p < SH::TPR_H; ++p) v += part[lane * SH::TPR_H + p];
             const int r = c * SH::R_D + lane;
-            tk_publish(a.g_x + r, e_d, xraw[r] + v);
+            tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
         TK_STAMP(15);
     }
@@ -1041,20 +1057,20 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     float xn_fin;
     if constexpr (SH::COOP) {
-        ok = tk_coop_gather<SH::E, TR_E, true>(a.g_x, ebase + 5u * L, xraw, xs, a.rms_final, red8, a.err, TK_NS, lane, nosync) && ok;
+        ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
         tk_barrier();
         xn_fin = tk_coop_xn<SH::E>(red8, a.eps);
     } else {
         TkNorm<SH::E> nrmf;
-        nrmf.prefetch(a.rms_final, lane);
-        ok = tk_gather<SH::E>(a.g_x, ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
+        nrmf.prefetch(tk_rms_final(a, SH::E), lane);
+        ok = tk_gather<SH::E>(tk_g_x<SH>(a), ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
         xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane, a.eps);
         tk_barrier();
     }
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
     for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = part[j] / xn_fin;
-    if (GR && (a.gflags & TKG_CAND_OUT)) {
+    if constexpr (GR) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int j = lane; j < cn; j += WAVE) {       // the same quotient as the stored logit; ascending j per lane
@@ -1062,7 +1078,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             if (v > bv) { bv = v; bi = c0 + j; }
         }
         tk_wave_argmax(bv, bi);
-        if (lane == 0) tk_cand(a, (a.gflags >> 1) & 1)[c] = make_float2(bv, __int_as_float(bi));
+        if (lane == 0) tk_cand(a, pos & 1)[c] = make_float2(bv, __int_as_float(bi));
     }
     if (!ok && lane == 0) {
         atomicOr(a.err, 0x1000u);
@@ -1326,16 +1342,16 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
             tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
             tk_barrier();
         }
-        if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(a.g_xb, e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
-        tk_coop_gather<SH::E, TR_E, true>(a.g_xa, e_o, xraw, xs, a.rms_ffn + (size_t)l * SH::E, red8, a.err, sw, lane, nosync);
+        tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
-        tk_coop_gather<SH::H, TR_H, false>(a.g_hb, e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);
         if (l + 1 < L) {
-            if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(a.g_x, e_d, xraw, xs, a.rms_att + (size_t)(l + 1) * SH::E, red8, a.err, sw, lane, nosync);
+            if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, a.err, sw, lane, nosync);
         } else {
-            tk_coop_gather<SH::E, TR_E, true>(a.g_x, e_d, xraw, xs, a.rms_final, red8, a.err, sw, lane, nosync);
+            tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, sw, lane, nosync);
         }
     }
     tk_phase_body<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);

@@ -17,7 +17,24 @@ module read_ggml
   use weight_module
   implicit none
   private
-  public :: load_ggml, half_bits_to_real
+  public :: load_ggml, stream_ggml_weights, half_bits_to_real, tensor_sink
+  public :: TID_TOKEN_EMBEDDING_TABLE, TID_RMS_ATT_WEIGHT, TID_RMS_FFN_WEIGHT, TID_WQKV, TID_WO, TID_W13, TID_W2, &
+            TID_RMS_FINAL_WEIGHT, TID_WCLS
+
+  ! Where stream_ggml_weights hands its tensors: rows [row_offset, row_offset + rows) of layer `layer` (0-based) of the
+  ! fused TransformerWeights component `tensor_id` (weight_module.f90:13-26; the TID_* numbers are include/llmk.h's
+  ! LLMK_* tensor ids), `nbytes` bytes in ggml type `ggml_type` at `host`.  The host's sink calls llmk_upload_rows; the
+  ! loader itself knows nothing about the device (tests/host_tools/loader_dump.f90 links it without the library).
+  abstract interface
+     subroutine tensor_sink(tensor_id, layer, row_offset, rows, host, nbytes, ggml_type)
+       import :: c_ptr, c_size_t
+       integer, intent(in) :: tensor_id, layer, row_offset, rows, ggml_type
+       type(c_ptr), intent(in) :: host
+       integer(c_size_t), intent(in) :: nbytes
+     end subroutine
+  end interface
+  integer, parameter :: TID_TOKEN_EMBEDDING_TABLE = 0, TID_RMS_ATT_WEIGHT = 1, TID_RMS_FFN_WEIGHT = 2, TID_WQKV = 3, TID_WO = 4, &
+                        TID_W13 = 5, TID_W2 = 6, TID_RMS_FINAL_WEIGHT = 7, TID_WCLS = 8
 
   integer(4), parameter :: GGUF_MAGIC = 1179993927     ! "GGUF", read_ggml.f90:122
   integer, parameter :: NAME_LEN = 64                  ! reference truncates names/tokens to 64 chars
@@ -35,10 +52,15 @@ module read_ggml
   type(tensor_entry), allocatable :: dir(:)
   integer(8) :: data_pos          ! 1-based stream position of the tensor data section
   integer :: u                    ! unit
+  logical :: deferred = .false.   ! load_ggml(..., defer=.true.) left the matrices in the (still open) file
 
 contains
 
-  subroutine load_ggml(filename, w, c, vocab, scores, token_lengths, v)
+  ! defer (optional, an extension; absent or .false. = the reference's behaviour): read everything BUT the embedding
+  ! table and the five matrix families, and keep the file open -- stream_ggml_weights then moves them to the device one
+  ! tensor (or row range) at a time, so the host never holds more than the largest single tensor it hands over
+  ! (`llm --ngpu N`: each rank reads only the rows of its own shard).
+  subroutine load_ggml(filename, w, c, vocab, scores, token_lengths, v, defer)
     character(len=*), intent(in) :: filename
     type(TransformerWeights), intent(out) :: w
     type(Config), intent(out) :: c
@@ -46,6 +68,7 @@ contains
     character(:), dimension(:), allocatable, intent(out) :: vocab
     integer(4), allocatable, intent(out) :: token_lengths(:)
     logical, intent(in) :: v
+    logical, intent(in), optional :: defer
 
     integer(4) :: magic, version, vtype, etype
     integer(8) :: n_tensors, n_kv, i, j, n, slen, p, tokens_pos, n_tokens, ival
@@ -177,10 +200,15 @@ contains
     end if
     w%wtype = mt
     w%wcls_type = mt
+    deferred = .false.
+    if (present(defer)) deferred = defer
+    if (deferred .and. dir(find("output.weight"))%ttype /= mt) w%wcls_type = GT_F32   ! dequantised on the way (q6_K)
 
-    allocate(w%token_embedding_table(E, vocab_size))
-    call read_matrix_as_f32("token_embd.weight", w%token_embedding_table, E, vocab_size)
-    if (v) print *, "loaded embedding weights:", size(w%token_embedding_table)
+    if (.not. deferred) then
+       allocate(w%token_embedding_table(E, vocab_size))
+       call read_matrix_as_f32("token_embd.weight", w%token_embedding_table, E, vocab_size)
+       if (v) print *, "loaded embedding weights:", size(w%token_embedding_table)
+    end if
 
     allocate(w%rms_att_weight(E, n_layers), w%rms_ffn_weight(E, n_layers), w%rms_final_weight(E))
     do l = 1, n_layers
@@ -190,7 +218,9 @@ contains
     call read_vector("output_norm.weight", w%rms_final_weight, E)
     if (v) print *, "loaded rms weights:", size(w%rms_att_weight), size(w%rms_ffn_weight), size(w%rms_final_weight)
 
-    if (mt == GT_F32) then
+    if (deferred) then
+       if (v) print *, "matrices stay in the file (streamed to the device), ggml type", mt
+    else if (mt == GT_F32) then
        allocate(w%wqkv(E, E + 2*KV, n_layers), w%wo(E, E, n_layers), w%w13(E, 2*H, n_layers), &
                 w%w2(H, E, n_layers), w%wcls(E, vocab_size))
        do l = 1, n_layers
@@ -227,7 +257,7 @@ contains
           w%wcls_type = GT_F32
        end if
     end if
-    if (v) print *, "loaded matmul weights, ggml type", mt
+    if (v .and. .not. deferred) print *, "loaded matmul weights, ggml type", mt
 
     ! ---- vocabulary (second visit of the tokens array) ---------------------------------------
     if (tokens_pos == 0 .or. .not. allocated(scores)) then
@@ -261,19 +291,116 @@ contains
        print *, "maximum token length ", maxval(token_lengths)
     end if
 
+    if (.not. deferred) then
+       close(u)
+       deallocate(dir)
+    end if
+
+  end subroutine load_ggml
+
+  function layer_name(l1, suffix) result(nm)
+    integer, intent(in) :: l1
+    character(len=*), intent(in) :: suffix
+    character(len=NAME_LEN) :: nm
+    write (nm, "(A,I0,A,A)") "blk.", l1 - 1, ".", suffix
+  end function
+
+  ! Second half of a deferred load: the embedding table, the norm gains (already in w) and the matrices go to the llmk
+  ! context `ctx` -- tensor by tensor through llmk_upload_rows, whose row numbers are those of the FULL fused tensors
+  ! (wqkv = Q | K | V rows, w13 = gate | up rows: read_ggml.f90:272-376).  Rank tp_rank of tp_size reads from the file only
+  ! what its shard keeps: its query heads' rows of attn_q, its kv heads' rows of attn_k / attn_v, its hidden rows of
+  ! ffn_gate / ffn_up, its vocabulary rows of output.weight; attn_output and ffn_down are split along the contraction, so
+  ! their rows are read whole and the shim keeps the column slice.  The largest buffer is one ffn_down tensor (or 4096
+  ! embedding rows).  Replaces the array assignments of read_ggml.f90:238-410 for hosts that opt in.
+  subroutine stream_ggml_weights(sink, w, c, tp_rank, tp_size, v)
+    procedure(tensor_sink) :: sink
+    type(TransformerWeights), intent(inout), target :: w
+    type(Config), intent(in) :: c
+    integer, intent(in) :: tp_rank, tp_size
+    logical, intent(in) :: v
+    integer :: E, H, KV, hs, L, V_, mt, l1, Eq, KVl, Hl, Vl, r0, nr, chunk
+    integer(c_int8_t), allocatable, target :: raw(:)
+    real(kind=wp), allocatable, target :: f32buf(:, :)
+    integer(8) :: peak
+
+    if (.not. deferred) then
+       print *, "stream_ggml_weights: load_ggml was not called with defer=.true."
+       stop 1
+    end if
+    E = c%emb_dim; H = c%hidden_dim; L = c%n_layers; V_ = c%vocab_size
+    hs = E / c%n_heads; KV = c%n_kv_heads * hs; mt = w%wtype
+    Eq = E / tp_size; KVl = KV / tp_size; Hl = H / tp_size; Vl = V_ / tp_size
+    peak = 0
+
+    ! replicated f32 tensors: the embedding table in chunks of rows, the gains from w
+    chunk = min(V_, 4096)
+    allocate(f32buf(E, chunk))
+    r0 = 0
+    do while (r0 < V_)
+       nr = min(chunk, V_ - r0)
+       call read_rows_as_f32("token_embd.weight", f32buf, E, V_, r0, nr)
+       call sink(TID_TOKEN_EMBEDDING_TABLE, 0, r0, nr, c_loc(f32buf), 4_c_size_t * E * nr, GT_F32)
+       r0 = r0 + nr
+    end do
+    do l1 = 1, L
+       call sink(TID_RMS_ATT_WEIGHT, l1 - 1, 0, 1, c_loc(w%rms_att_weight(1, l1)), 4_c_size_t * E, GT_F32)
+       call sink(TID_RMS_FFN_WEIGHT, l1 - 1, 0, 1, c_loc(w%rms_ffn_weight(1, l1)), 4_c_size_t * E, GT_F32)
+    end do
+    call sink(TID_RMS_FINAL_WEIGHT, 0, 0, 1, c_loc(w%rms_final_weight), 4_c_size_t * E, GT_F32)
+
+    ! classifier: this rank's vocabulary rows; dequantised in chunks when the file keeps it in another type (q6_K)
+    if (w%wcls_type == mt) then
+       call stream_rows("output.weight", TID_WCLS, 0, E, V_, tp_rank * Vl, Vl, tp_rank * Vl)
+    else
+       r0 = tp_rank * Vl
+       do while (r0 < (tp_rank + 1) * Vl)
+          nr = min(chunk, (tp_rank + 1) * Vl - r0)
+          call read_rows_as_f32("output.weight", f32buf, E, V_, r0, nr)
+          call sink(TID_WCLS, 0, r0, nr, c_loc(f32buf), 4_c_size_t * E * nr, GT_F32)
+          r0 = r0 + nr
+       end do
+    end if
+    deallocate(f32buf)
+
+    do l1 = 1, L
+       call stream_rows(layer_name(l1, "attn_q.weight"), TID_WQKV, l1 - 1, E, E, tp_rank * Eq, Eq, tp_rank * Eq)
+       call stream_rows(layer_name(l1, "attn_k.weight"), TID_WQKV, l1 - 1, E, KV, tp_rank * KVl, KVl, E + tp_rank * KVl)
+       call stream_rows(layer_name(l1, "attn_v.weight"), TID_WQKV, l1 - 1, E, KV, tp_rank * KVl, KVl, E + KV + tp_rank * KVl)
+       call stream_rows(layer_name(l1, "attn_output.weight"), TID_WO, l1 - 1, E, E, 0, E, 0)
+       call stream_rows(layer_name(l1, "ffn_gate.weight"), TID_W13, l1 - 1, E, H, tp_rank * Hl, Hl, tp_rank * Hl)
+       call stream_rows(layer_name(l1, "ffn_up.weight"), TID_W13, l1 - 1, E, H, tp_rank * Hl, Hl, H + tp_rank * Hl)
+       call stream_rows(layer_name(l1, "ffn_down.weight"), TID_W2, l1 - 1, H, E, 0, E, 0)
+    end do
+    if (v) print *, "streamed matmul weights, ggml type", mt, " largest host buffer (bytes)", peak
     close(u)
     deallocate(dir)
+    deferred = .false.
 
   contains
 
-    function layer_name(l1, suffix) result(nm)
-      integer, intent(in) :: l1
-      character(len=*), intent(in) :: suffix
-      character(len=NAME_LEN) :: nm
-      write (nm, "(A,I0,A,A)") "blk.", l1 - 1, ".", suffix
-    end function
+    ! rows [frow, frow + n) of file tensor `name` (cols x rows_total) -> rows grow.. of layer `layer0` of fused tensor `tid`
+    subroutine stream_rows(name, tid, layer0, cols, rows_total, frow, n, grow)
+      character(len=*), intent(in) :: name
+      integer, intent(in) :: tid, layer0, cols, rows_total, frow, n, grow
+      integer :: idx
+      integer(8) :: nb
+      idx = find(name)
+      call check_shape(idx, cols, rows_total)
+      if (dir(idx)%ttype /= mt) then
+         print *, "Type not supported", dir(idx)%ttype, " (mixed matrix types) for ", trim(name)
+         stop 1
+      end if
+      nb = n * rowbytes(mt, cols)
+      if (allocated(raw)) then
+         if (size(raw, kind=8) < nb) deallocate(raw)
+      end if
+      if (.not. allocated(raw)) allocate(raw(nb))
+      peak = max(peak, nb)
+      read(u, pos=data_pos + dir(idx)%offset + frow * rowbytes(mt, cols)) raw(1:nb)
+      call sink(tid, layer0, grow, n, c_loc(raw), int(nb, c_size_t), mt)
+    end subroutine
 
-  end subroutine load_ggml
+  end subroutine stream_ggml_weights
 
   ! ---------------------------------------------------------------------------------------------
   subroutine read_string(s)
@@ -428,19 +555,30 @@ contains
     character(len=*), intent(in) :: name
     integer, intent(in) :: cols, rows
     real(kind=wp), intent(out) :: dst(cols, rows)
-    integer :: idx, r, b, k, sc
+    call read_rows_as_f32(name, dst, cols, rows, 0, rows)
+  end subroutine
+
+  ! rows [row0, row0 + nrows) of a cols x rows_total file tensor of any supported type, widened to f32
+  subroutine read_rows_as_f32(name, dst, cols, rows_total, row0, nrows)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: cols, rows_total, row0, nrows
+    real(kind=wp), intent(out) :: dst(cols, *)
+    integer :: idx, r, b, k, sc, rows
     integer(2), allocatable :: hrow(:)
     integer(1), allocatable :: qrow(:)
     real(kind=wp) :: d
     integer :: q
+    integer(8) :: first
+    rows = nrows
     idx = find(name)
-    call check_shape(idx, cols, rows)
+    call check_shape(idx, cols, rows_total)
     select case (dir(idx)%ttype)
     case (GT_F32)
-       read(u, pos=data_pos + dir(idx)%offset) dst
+       first = data_pos + dir(idx)%offset + int(row0, 8) * 4_8 * cols
+       read(u, pos=first) dst(1:cols, 1:rows)
     case (GT_F16)
        allocate(hrow(cols))
-       read(u, pos=data_pos + dir(idx)%offset)
+       call seek_to(data_pos + dir(idx)%offset + int(row0, 8) * 2_8 * cols)
        do r = 1, rows
           read(u) hrow
           do k = 1, cols
@@ -449,7 +587,7 @@ contains
        end do
     case (GT_Q4_0)                 ! ggml block_q4_0: f16 d, 16 bytes; lo nibbles = 0..15, hi = 16..31
        allocate(qrow(cols / 32 * 18))
-       read(u, pos=data_pos + dir(idx)%offset)
+       call seek_to(data_pos + dir(idx)%offset + int(row0, 8) * (cols / 32 * 18))
        do r = 1, rows
           read(u) qrow
           do b = 0, cols / 32 - 1
@@ -466,7 +604,7 @@ contains
        ! f16 d; weight = d * scale * (q - 32)  (public ggml format, dequantize_row_q6_K; third-party knowledge, not
        ! citable in /root/reference)
        allocate(qrow(cols / 256 * 210))
-       read(u, pos=data_pos + dir(idx)%offset)
+       call seek_to(data_pos + dir(idx)%offset + int(row0, 8) * (cols / 256 * 210))
        do r = 1, rows
           read(u) qrow
           do b = 0, cols / 256 - 1
@@ -481,6 +619,12 @@ contains
        print *, "Type not supported", dir(idx)%ttype
        stop 1
     end select
+  end subroutine
+
+  ! position the stream at byte `p` (1-based) without transferring data: the next sequential read starts there
+  subroutine seek_to(p)
+    integer(8), intent(in) :: p
+    read(u, pos=p)
   end subroutine
 
   ! element k (0..255) of a q6_K block: its 6-bit value minus 32 and its sub-block scale

@@ -6,7 +6,7 @@
 ! llama2.f90:102-108).  There is no CPU forward pass in this program.
 !
 !   ./llm -m model.gguf [-p prompt] [-n tokens] [-t temperature] [-s tokenizer.bin] [-v]
-!         [--ak] [-d device] [--device-argmax] [--prefill] [--timings] [--seed N]
+!         [--ak] [-d device] [--device-argmax] [--prefill] [--timings] [--seed N] [--stream-load] [--ngpu N]
 !         [--ngpu N [--tp-rccl]] [--gguf-eps] [--gguf-rope-base]
 !
 ! --ngpu N (the 70B configuration, SURVEY.md section 8e): this process becomes rank 0 of N, starts N-1 copies of itself
@@ -26,6 +26,7 @@ module arg_parse
      integer :: device            ! extension: HIP device ordinal
      logical :: device_argmax     ! extension: greedy pick on the GPU (SURVEY.md 8f rank 1)
      logical :: prefill           ! extension: the prompt goes through the model as ONE batched pass (llmk_prefill)
+     logical :: stream_load       ! extension: matrices go from the file to the device tensor by tensor (always with --ngpu)
      logical :: timings           ! extension: fill the five "Timings" lines from hipEvent section timers (slow path)
      integer :: seed              ! extension: >= 0 seeds the sampler (the reference's is unseeded, llama2.f90:433)
      integer :: ngpu              ! extension: tensor-parallel ranks, one process per GPU
@@ -53,6 +54,7 @@ contains
     a%device = 0
     a%device_argmax = .false.
     a%prefill = .false.
+    a%stream_load = .false.
     a%timings = .false.
     a%seed = -1
     a%ngpu = 1
@@ -79,6 +81,7 @@ contains
        case ("--ak");                a%ak = .true.;            i = i + 1
        case ("--device-argmax");     a%device_argmax = .true.; i = i + 1
        case ("--prefill");           a%prefill = .true.;       i = i + 1
+       case ("--stream-load");       a%stream_load = .true.;   i = i + 1
        case ("--timings");           a%timings = .true.;       i = i + 1
        case ("--seed");              read (val, *) a%seed;        i = i + 2
        case ("--ngpu");              read (val, *) a%ngpu;        i = i + 2
@@ -95,6 +98,23 @@ contains
   end subroutine parse_args
 
 end module arg_parse
+
+
+! The sink stream_ggml_weights hands its tensors to (read_ggml's tensor_sink): straight to the device context.
+module device_sink
+  use iso_c_binding
+  use llmk_binding
+  implicit none
+  type(c_ptr) :: sink_ctx = c_null_ptr
+contains
+  subroutine upload_sink(tensor_id, layer, row_offset, rows, host, nbytes, ggml_type)
+    integer, intent(in) :: tensor_id, layer, row_offset, rows, ggml_type
+    type(c_ptr), intent(in) :: host
+    integer(c_size_t), intent(in) :: nbytes
+    call llmk_check(llmk_upload_rows(sink_ctx, int(tensor_id, c_int), int(layer, c_int), int(row_offset, c_int), int(rows, c_int), &
+         host, nbytes, int(ggml_type, c_int)), "llmk_upload_rows")
+  end subroutine
+end module device_sink
 
 
 ! Tokens of llmk_decode_greedy reach the terminal as they are resolved, like the reference's own loop prints them
@@ -123,10 +143,11 @@ end module token_stream
 program llm
   use iso_c_binding
   use token_stream
+  use device_sink
   use precision_module
   use weight_module
   use arg_parse
-  use read_ggml, only: load_ggml
+  use read_ggml, only: load_ggml, stream_ggml_weights
   use ak_loader, only: load_ak
   use llmk_binding
   implicit none
@@ -165,7 +186,10 @@ program llm
         stop 1
      end if
   else
-     call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose .and. lead)
+     ! --ngpu N (and --stream-load): the matrices stay in the file until the device context exists, then each rank streams
+     ! the rows of its own shard to its GPU -- no rank ever holds the model, or even a layer, in host memory
+     if (opts%ngpu > 1) opts%stream_load = .true.
+     call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose .and. lead, defer=opts%stream_load)
   end if
   if (opts%verbose .and. lead) print *, "Loaded weights"
   if (opts%tokenizer /= "") call read_tokenizer_bin(opts%tokenizer)
@@ -188,7 +212,12 @@ program llm
   end if
   if (weights%wcls_type /= weights%wtype) &
        call llmk_check(llmk_set_tensor_type(ctx, LLMK_WCLS, int(weights%wcls_type, c_int)), "llmk_set_tensor_type")
-  call upload_weights()
+  if (opts%stream_load .and. .not. opts%ak) then
+     sink_ctx = ctx
+     call stream_ggml_weights(upload_sink, weights, conf, opts%tp_rank, max(opts%ngpu, 1), opts%verbose .and. lead)
+  else
+     call upload_weights()
+  end if
   if (opts%ngpu > 1) call tp_connect()
   if (opts%gguf_eps .and. conf%rms_eps > 0) call llmk_check(llmk_set_rms_eps(ctx, conf%rms_eps), "llmk_set_rms_eps")
 
@@ -540,14 +569,21 @@ contains
 
   ! rank 0: make the rendezvous directory and start ranks 1..N-1 as copies of this command line
   subroutine tp_launch_workers()
+    character(kind=c_char) :: tmpl(32)
     character(len=4096) :: arg
     character(len=:), allocatable :: cmd, base
     character(len=32) :: num
     integer :: i, r, seed, ticks
     if (opts%tp_rank > 0) return                       ! a worker: everything was handed down
-    write (num, "(I0)") c_getpid()
-    opts%tp_dir = "/tmp/llmk_tp_" // trim(num)
-    call execute_command_line("mkdir -p " // opts%tp_dir)
+    ! a fresh private directory (mkdtemp: unpredictable name, mode 0700, fails rather than reuse): nothing stale from a
+    ! crashed run with the same pid, nothing another local user could have planted
+    tmpl(1:22) = transfer("/tmp/llmk_tp_XXXXXX" // c_null_char // "  ", tmpl(1:22))
+    if (.not. c_associated(c_mkdtemp(tmpl))) then
+       print *, "cannot create the tensor-parallel rendezvous directory under /tmp"
+       stop 1
+    end if
+    opts%tp_dir = transfer(tmpl(1:19), repeat(" ", 19))
+    call execute_command_line("touch " // opts%tp_dir // "/alive")
     call get_command_argument(0, arg)
     base = shell_quote(trim(arg))
     do i = 1, command_argument_count()
@@ -588,10 +624,15 @@ contains
     do
        inquire(file=opts%tp_dir // "/" // name, exist=there)
        if (there) exit
+       inquire(file=opts%tp_dir // "/alive", exist=there)
+       if (.not. there .and. opts%tp_rank > 0) stop 1   ! rank 0 is gone (it removes the directory on every exit path it controls)
        rc = c_usleep(20000_c_int)
        waited = waited + 1
        if (waited > 15000) then                        ! 5 minutes: a peer died while loading
           print *, "tensor-parallel rendezvous timed out waiting for ", name
+          if (opts%tp_rank == 0) then                  ! what the workers said, then nothing left behind
+             call execute_command_line("cat " // opts%tp_dir // "/rank*.err 1>&2; rm -rf " // opts%tp_dir)
+          end if
           stop 1
        end if
     end do
@@ -602,10 +643,11 @@ contains
 
   ! exchange the inbox handles (or the RCCL id) through the rendezvous directory
   subroutine tp_connect()
-    character(kind=c_char) :: h(64), uid(128)
+    character(kind=c_char) :: h(64), uid(128), verdict(1)
     character(kind=c_char), allocatable :: all(:)
     character(len=32) :: num
     integer :: r
+    logical :: all_ok
     if (opts%tp_rccl) then
        if (opts%tp_rank == 0) then
           call llmk_check(llmk_tp_unique_id(uid), "llmk_tp_unique_id")
@@ -625,6 +667,29 @@ contains
        call tp_get("inbox" // trim(num), all(64 * r + 1:64 * r + 64))
     end do
     call llmk_check(llmk_tp_p2p_connect(ctx, all), "llmk_tp_p2p_connect")
+    ! The peer-memory path proves itself on THIS hardware before the first token (64 rounds of every collective on known
+    ! integers).  Unless every rank passes, all ranks drop it together and the token pass runs over RCCL.
+    verdict(1) = "y"
+    if (llmk_tp_p2p_selftest(ctx, 64_c_int) /= 0) verdict(1) = "n"
+    write (num, "(I0)") opts%tp_rank
+    call tp_put("p2p" // trim(num), verdict)
+    all_ok = .true.
+    do r = 0, opts%ngpu - 1
+       write (num, "(I0)") r
+       call tp_get("p2p" // trim(num), verdict)
+       if (verdict(1) /= "y") all_ok = .false.
+    end do
+    if (.not. all_ok) then
+       if (lead) write (0, *) "llmk: the peer-memory collectives failed their self-test on this node: using RCCL"
+       call llmk_check(llmk_tp_p2p_disable(ctx), "llmk_tp_p2p_disable")
+       if (opts%tp_rank == 0) then
+          call llmk_check(llmk_tp_unique_id(uid), "llmk_tp_unique_id")
+          call tp_put("uid", uid)
+       else
+          call tp_get("uid", uid)
+       end if
+       call llmk_check(llmk_tp_init_comm(ctx, uid), "llmk_tp_init_comm")
+    end if
   end subroutine tp_connect
 
   ! rank 0 leaves last and removes the directory

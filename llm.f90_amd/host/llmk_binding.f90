@@ -48,6 +48,16 @@ module llmk_binding
        type(c_ptr), value :: ctx
        character(kind=c_char), intent(in) :: handles(*)     ! tp_size * 64 bytes, rank order
      end function
+     ! all ranks together, after the connect: 0 = this rank's peer-memory exchanges gave exact sums on this hardware
+     integer(c_int) function llmk_tp_p2p_selftest(ctx, iters) bind(C, name="llmk_tp_p2p_selftest")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), value :: iters
+     end function
+     integer(c_int) function llmk_tp_p2p_disable(ctx) bind(C, name="llmk_tp_p2p_disable")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function
      integer(c_int) function llmk_upload(ctx, tensor_id, host, nbytes, ggml_type) bind(C, name="llmk_upload")
        import :: c_int, c_ptr, c_size_t
        type(c_ptr), value :: ctx
@@ -137,6 +147,10 @@ module llmk_binding
      ! libc, for the multi-process rendezvous of `llm --ngpu N`
      integer(c_int) function c_getpid() bind(C, name="getpid")
        import :: c_int
+     end function
+     type(c_ptr) function c_mkdtemp(template) bind(C, name="mkdtemp")       ! creates the directory, mode 0700
+       import :: c_ptr, c_char
+       character(kind=c_char), intent(inout) :: template(*)
      end function
      integer(c_int) function c_usleep(us) bind(C, name="usleep")
        import :: c_int

@@ -22,7 +22,7 @@ TENSOR_IDS = {
 FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 # every symbol include/llmk.h declares
 SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_p2p_handle", "llmk_tp_p2p_connect",
-           "llmk_tp_p2p_connect_local", "llmk_tp_begin", "llmk_tp_segment",
+           "llmk_tp_p2p_connect_local", "llmk_tp_p2p_selftest", "llmk_tp_p2p_disable", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
            "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_decode_greedy", "llmk_reset", "llmk_timings",
            "llmk_time_kernel", "llmk_peek", "llmk_path", "llmk_destroy", "llmk_strerror", "llmk_version"]
@@ -68,6 +68,8 @@ def lib():
         L.llmk_tp_p2p_handle.argtypes = [vp, C.c_char_p]
         L.llmk_tp_p2p_connect.argtypes = [vp, C.c_char_p]
         L.llmk_tp_p2p_connect_local.argtypes = [vp, C.POINTER(vp)]
+        L.llmk_tp_p2p_selftest.argtypes = [vp, ci]
+        L.llmk_tp_p2p_disable.argtypes = [vp]
         L.llmk_tp_begin.argtypes = [vp, ci, ci]
         L.llmk_tp_segment.argtypes = [vp, ci, ci]
         L.llmk_tp_read_partial.argtypes = [vp, cf]
@@ -211,6 +213,13 @@ class Llmk:
         arr = (C.c_void_p * len(ranks))(*[m._h for m in ranks])
         for m in ranks:
             _ck(lib().llmk_tp_p2p_connect_local(m._h, arr))
+
+    def tp_p2p_selftest(self, iters: int = 64) -> int:
+        """0 when this rank's peer-memory exchanges all gave exact sums (every rank must call it); else the LLMK_E_* code"""
+        return lib().llmk_tp_p2p_selftest(self._h, iters)
+
+    def tp_p2p_disable(self):
+        _ck(lib().llmk_tp_p2p_disable(self._h))
 
     def tp_begin(self, token: int, pos: int):
         _ck(lib().llmk_tp_begin(self._h, token, pos))

@@ -176,14 +176,25 @@ def quantize_q4_0(w: np.ndarray) -> np.ndarray:
 
 
 def dequantize_q4_0(raw: np.ndarray, cols: int) -> np.ndarray:
-    """uint8 [..., cols/32*18] -> f32 [..., cols]."""
+    """uint8 [..., cols/32*18] -> f32 [..., cols]: (nibble - 8) * d, low nibbles = elements 0..15 of the block, high
+    nibbles = elements 16..31 (ggml block_q4_0).  Large arrays are decoded in parallel slices (numpy releases the GIL)."""
     b = raw.reshape(-1, Q4_0_BLOCK_BYTES)
-    d = b[:, 0:2].copy().view(np.float16).astype(np.float32)  # [nb,1]
-    qs = b[:, 2:]
-    lo = (qs & 0x0F).astype(np.int32) - 8
-    hi = (qs >> 4).astype(np.int32) - 8
-    vals = np.concatenate([lo, hi], axis=1).astype(np.float32) * d
-    return vals.reshape(*raw.shape[:-1], cols)
+    nb = b.shape[0]
+    out = np.empty((nb, QK4_0), np.float32)
+
+    def part(s0, e0):
+        d = b[s0:e0, 0:2].copy().view(np.float16).astype(np.float32)  # [n,1]
+        qs = b[s0:e0, 2:]
+        out[s0:e0, :16] = ((qs & 0x0F).astype(np.int8) - np.int8(8)).astype(np.float32) * d
+        out[s0:e0, 16:] = ((qs >> 4).astype(np.int8) - np.int8(8)).astype(np.float32) * d
+    chunk = 1 << 19
+    if nb <= 2 * chunk:
+        part(0, nb)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda s0: part(s0, min(nb, s0 + chunk)), range(0, nb, chunk)))
+    return out.reshape(*raw.shape[:-1], cols)
 
 
 def quantize_q6_K(w: np.ndarray) -> np.ndarray:
@@ -256,10 +267,12 @@ def decode(raw: np.ndarray, ggml_type: int, cols: int) -> np.ndarray:
     raise ValueError(ggml_type)
 
 
-def synth_q4_rows(seed: int, stream: int, rows: int, K: int) -> np.ndarray:
+def synth_q4_rows(seed: int, stream: int, rows: int, K: int, scale_jitter: bool = False) -> np.ndarray:
     """Synthetic q4_0 rows generated DIRECTLY in the block format (for the 7B/70B shapes, where
     materialising f32 weights first would need hundreds of GB): nibbles from the integer hash, one f16
-    scale per block chosen so the dequantised weights have variance 1/K.  uint8 [rows, K/32*18]."""
+    scale per block chosen so the dequantised weights have variance 1/K.  uint8 [rows, K/32*18].
+    scale_jitter: every block gets its OWN scale, d * (0.5 .. 1.5) (sign included now and then) -- what a parity test
+    needs to see a mis-indexed scale; the benchmarks keep the constant one."""
     nb = rows * (K // QK4_0)
     out = np.empty((nb, Q4_0_BLOCK_BYTES), np.uint8)
     base = np.uint64((seed * 0x9E3779B1 + stream * 0x85EBCA77) & 0xFFFFFFFF) << np.uint64(32)
@@ -269,7 +282,13 @@ def synth_q4_rows(seed: int, stream: int, rows: int, K: int) -> np.ndarray:
     def fill(s0):
         e0 = min(nb, s0 + chunk)
         idx = (np.arange(s0 * 2, e0 * 2, dtype=np.uint64) + base)
-        out[s0:e0, 2:] = _splitmix64(idx).view(np.uint8).reshape(e0 - s0, 16)
+        h = _splitmix64(idx)
+        out[s0:e0, 2:] = h.view(np.uint8).reshape(e0 - s0, 16)
+        if scale_jitter:
+            u = _splitmix64(h[0::2] ^ np.uint64(0xD1B54A32D192ED03))
+            f = (np.float32(0.5) + (u >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))) * np.float32(d)
+            f = np.where((u & np.uint64(7)) == 0, -f, f)                   # one block in eight carries a negative scale
+            out[s0:e0, 0:2] = f.astype(np.float16).view(np.uint8).reshape(-1, 2)
     spans = list(range(0, nb, chunk))
     if len(spans) <= 2:
         for s0 in spans:
@@ -310,6 +329,26 @@ class FusedWeights:
                             self.rms_final_weight, decode(self.wqkv, t, s.emb_dim), decode(self.wo, t, s.emb_dim),
                             decode(self.w13, t, s.emb_dim), decode(self.w2, t, s.hidden_dim),
                             decode(self.wcls, self.cls_type, s.emb_dim))
+
+
+def synth_fused_q4_direct(shape: LlamaShape, seed: int, scale_jitter: bool = True) -> FusedWeights:
+    """q4_0 FusedWeights with every matrix generated directly in block format (synth_q4_rows): seconds where
+    synth_fused + quantisation takes minutes at 70B geometry.  Embedding and norm gains as in synth_fused."""
+    E, H, L, KV, V = shape.emb_dim, shape.hidden_dim, shape.n_layers, shape.kv_dim, shape.vocab_size
+    fw = FusedWeights(shape, GGML_Q4_0)
+    idx = {n: i for i, (n, _, _) in enumerate(tensor_names(shape))}
+    q4 = lambda name, rows, K: synth_q4_rows(seed, idx[name], rows, K, scale_jitter)
+    fw.token_embedding_table = synth_tensor(shape, seed, idx["token_embd.weight"], (V, E), "emb")
+    fw.rms_final_weight = synth_tensor(shape, seed, idx["output_norm.weight"], (E,), "norm")
+    fw.wcls = q4("output.weight", V, E)
+    fw.rms_att_weight = np.stack([synth_tensor(shape, seed, idx[f"blk.{l}.attn_norm.weight"], (E,), "norm") for l in range(L)])
+    fw.rms_ffn_weight = np.stack([synth_tensor(shape, seed, idx[f"blk.{l}.ffn_norm.weight"], (E,), "norm") for l in range(L)])
+    fw.wqkv = np.stack([np.concatenate([q4(f"blk.{l}.attn_q.weight", E, E), q4(f"blk.{l}.attn_k.weight", KV, E),
+                                        q4(f"blk.{l}.attn_v.weight", KV, E)]) for l in range(L)])
+    fw.wo = np.stack([q4(f"blk.{l}.attn_output.weight", E, E) for l in range(L)])
+    fw.w13 = np.stack([np.concatenate([q4(f"blk.{l}.ffn_gate.weight", H, E), q4(f"blk.{l}.ffn_up.weight", H, E)]) for l in range(L)])
+    fw.w2 = np.stack([q4(f"blk.{l}.ffn_down.weight", E, H) for l in range(L)])
+    return fw
 
 
 def synth_fused(shape: LlamaShape, seed: int, ggml_type: int = GGML_F32) -> FusedWeights:
@@ -429,6 +468,12 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
     if rope_freq_base is not None:
         kvs.append(("llama.rope.freq_base", T_F32, rope_freq_base))
     src = lambda name: out_raw if (output_q6k and name == "output.weight") else _tensor_source(fw, name)
+    cls_tt = GGML_Q6_K if output_q6k else fw.cls_type
+    _write_gguf_file(path, shape, ggml_type, cls_tt, kvs, vocab, scores, names, src, lambda name: src(name).nbytes, alignment, version)
+
+
+def _write_gguf_file(path, shape, ggml_type, cls_tt, kvs, vocab, scores, names, src, nbytes_of, alignment, version):
+    """header + KV pairs + tensor directory + data; `src(name)` is called ONCE per tensor, when its bytes are written"""
     with open(path, "wb") as f:
         f.write(struct.pack("<IIqq", GGUF_MAGIC, version, len(names), len(kvs) + 2))
         for k, t, v in kvs:
@@ -450,8 +495,8 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
         for name, dims, kind in names:
             tt = ggml_type if kind == "mat" else GGML_F32
             if name == "output.weight":
-                tt = GGML_Q6_K if output_q6k else fw.cls_type
-            nbytes = src(name).nbytes
+                tt = cls_tt
+            nbytes = nbytes_of(name)
             infos.append((tt, offset, nbytes))
             _w_str(f, name.encode())
             f.write(struct.pack("<I", len(dims)))
@@ -463,8 +508,39 @@ def write_gguf(path: str, fw: "FusedWeights", alignment: int = 32, version: int 
         data_start = f.tell()
         for (name, dims, kind), (tt, off, nbytes) in zip(names, infos):
             assert f.tell() == data_start + off
-            f.write(np.ascontiguousarray(src(name)).data)
+            a = np.ascontiguousarray(src(name))
+            assert a.nbytes == nbytes, name
+            f.write(a.data)
             f.write(b"\0" * ((-nbytes) % alignment))
+
+
+def write_synth_q4_gguf_streamed(path: str, shape: LlamaShape, seed: int, alignment: int = 32, scale_jitter: bool = False) -> int:
+    """A q4_0 GGUF of ANY size written tensor by tensor (synth_q4_rows: blocks generated directly, the values bench.py's
+    build_streamed uploads): the 38.7 GB Llama-2-70B file never exists in memory.  Returns the file size."""
+    names = tensor_names(shape)
+    idx = {n: i for i, (n, _, _) in enumerate(names)}
+    dims_of = {n: d for n, d, _ in names}
+    kind_of = {n: k for n, _, k in names}
+
+    def nbytes_of(name):
+        d = dims_of[name]
+        return int(np.prod(d)) * 4 if kind_of[name] != "mat" else int(np.prod(d[:-1])) * (d[-1] // QK4_0) * Q4_0_BLOCK_BYTES
+
+    def src(name):
+        d = dims_of[name]
+        if kind_of[name] != "mat":
+            return synth_tensor(shape, seed, idx[name], d, kind_of[name])
+        return synth_q4_rows(seed, idx[name], int(np.prod(d[:-1])), d[-1], scale_jitter)
+    vocab = vocab_strings(shape.vocab_size)
+    scores = -np.arange(len(vocab), dtype="<f4")
+    kvs = [("general.architecture", T_STR, b"llama"), ("general.name", T_STR, b"synthetic"),
+           ("llama.context_length", T_U32, shape.seq_len), ("llama.embedding_length", T_U32, shape.emb_dim),
+           ("llama.block_count", T_U32, shape.n_layers), ("llama.feed_forward_length", T_U32, shape.hidden_dim),
+           ("llama.attention.head_count", T_U32, shape.n_heads), ("llama.attention.head_count_kv", T_U32, shape.n_kv_heads),
+           ("llama.attention.layer_norm_rms_epsilon", T_F32, 1e-5), ("general.alignment", T_U32, alignment),
+           ("tokenizer.ggml.model", T_STR, b"llama")]
+    _write_gguf_file(path, shape, GGML_Q4_0, GGML_Q4_0, kvs, vocab, scores, names, src, nbytes_of, alignment, 3)
+    return os.path.getsize(path)
 
 
 def write_ak(path: str, fw: "FusedWeights") -> None:

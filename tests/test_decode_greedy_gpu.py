@@ -58,7 +58,9 @@ def test_decode_greedy_resumes_after_forward_and_prefill(gguf):
     kv = m.peek(4, fw.shape.kv_dim, 1, n)
     m.reset()
     m.generate(n, want_logits=False)
-    np.testing.assert_array_equal(kv, m.peek(4, fw.shape.kv_dim, 1, n))
+    # (the pipelined variant is its own instantiation of the kernel: hipcc may contract an epilogue's multiply-adds
+    # differently, so the rows agree to rounding, like every other KV check in the suite, not bit for bit)
+    np.testing.assert_allclose(kv, m.peek(4, fw.shape.kv_dim, 1, n), rtol=0, atol=1e-5)
     with pytest.raises(llmk.LlmkError):
         m.decode_greedy(2, fw.shape.seq_len, 2)                   # runs past the context
     m.close()

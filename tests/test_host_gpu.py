@@ -163,3 +163,33 @@ def test_cli_ngpu_two_ranks_over_peer_memory_on_one_gpu(gguf, tmp_path):
     out = r.stdout.split(b"\n")
     ref = bytes(g["stdout"]).split(b"\n")
     assert out[0] == ref[0] and out[1] == ref[1]
+
+
+@pytest.mark.parametrize("wtype", [0, 1, 2], ids=["f32", "f16", "q4_0"])
+def test_cli_stream_load_prints_what_the_whole_file_load_prints(wtype, gguf, tmp_path):
+    """`--stream-load`: load_ggml(defer) + stream_ggml_weights -- the embedding table in row chunks, every matrix tensor
+    straight from the file to the device through llmk_upload_rows.  f32: the real reference's transcript; f16 / q4_0: byte
+    for byte what the whole-file load prints (which test_cli_runs_f16_and_q4_files pins to the python binding)."""
+    g = load_golden("tiny-hs64")
+    s = gguf.SHAPES["tiny-hs64"]
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, s, int(g["seed"]), wtype)
+    args = ["-m", path, "-n", str(int(g["n"])), "-t", "0"]
+    whole = _run(args, str(tmp_path)).split(b"\n")
+    streamed = _run(args + ["--stream-load"], str(tmp_path)).split(b"\n")
+    assert streamed[0] == whole[0] and streamed[1] == whole[1]
+    if wtype == 0:
+        ref = bytes(g["stdout"]).split(b"\n")
+        assert streamed[1] == ref[1]
+    out = _run(args + ["--stream-load", "-v"], str(tmp_path))
+    assert b"streamed matmul weights" in out
+
+
+def test_cli_stream_load_q6k_output_weight(gguf, tmp_path):
+    """a stock-layout q4_0 file (output.weight in q6_K) streamed: the classifier rows are dequantised in chunks"""
+    s = gguf.SHAPES["tiny-hs128"]          # E = 256: one q6_K super-block per row
+    fw = gguf.synth_fused(s, 3, 2)
+    path = str(tmp_path / "m.gguf")
+    gguf.write_gguf(path, fw, output_q6k=True)
+    args = ["-m", path, "-n", "16", "-t", "0"]
+    assert _run(args, str(tmp_path)).split(b"\n")[1] == _run(args + ["--stream-load"], str(tmp_path)).split(b"\n")[1]

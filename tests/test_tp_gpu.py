@@ -84,6 +84,56 @@ def test_virtual_ranks_quantised_match_oracle(wtype, gguf):
         m.close()
 
 
+def test_ranks_fed_only_their_own_rows_hold_the_same_shards(gguf):
+    """llmk_upload_rows on a tensor-parallel ctx takes row numbers of the FULL tensor and keeps the part its shard holds:
+    a rank handed only its own rows (what host/gguf_loader.f90 stream_ggml_weights reads from the file), in pieces, ends
+    with the same shard as a rank handed whole layers -- same logits bit for bit."""
+    import ctypes as C
+    s = gguf.LlamaShape(128, 384, 2, 4, 4, 512, 32)
+    fw = gguf.synth_fused(s, 99, 2)
+    P = 2
+    whole = [llmk.Llmk(fw, tp_rank=r, tp_size=P) for r in range(P)]
+    E, H, KV, V, L = s.emb_dim, s.hidden_dim, s.kv_dim, s.vocab_size, s.n_layers
+    T = llmk.TENSOR_IDS
+    own = []
+    for r in range(P):
+        m = llmk.Llmk.__new__(llmk.Llmk)
+        m.shape, m.V, m.tp_rank, m.tp_size = s, V, r, P
+        m._h = C.c_void_p()
+        cfg = llmk.Config(E, H, L, s.n_heads, s.n_kv_heads, V, s.seq_len, 2, 0, 0)
+        llmk._ck(llmk.lib().llmk_create_tp(C.byref(cfg), r, P, C.byref(m._h)))
+        m._logits = np.empty(V, np.float32)
+
+        def up(tid, layer, row0, arr, typ):
+            arr = np.ascontiguousarray(arr)
+            llmk._ck(llmk.lib().llmk_upload_rows(m._h, tid, layer, row0, arr.shape[0] if arr.ndim > 1 else 1, arr.ctypes.data, arr.nbytes, typ))
+        for v0 in range(0, V, 100):                                   # replicated, in ragged chunks
+            up(T["token_embedding_table"], 0, v0, fw.token_embedding_table[v0:v0 + 100], 0)
+        up(T["rms_final_weight"], 0, 0, fw.rms_final_weight, 0)
+        Vl, Eq, KVl, Hl = V // P, E // P, KV // P, H // P
+        up(T["wcls"], 0, r * Vl, fw.wcls[r * Vl:(r + 1) * Vl], 2)
+        up(T["wcls"], 0, ((r + 1) % P) * Vl, fw.wcls[((r + 1) % P) * Vl:((r + 1) % P) * Vl + 7], 2)   # foreign rows: ignored
+        for l in range(L):
+            up(T["rms_att_weight"], l, 0, fw.rms_att_weight[l], 0)
+            up(T["rms_ffn_weight"], l, 0, fw.rms_ffn_weight[l], 0)
+            for base, n in ((r * Eq, Eq), (E + r * KVl, KVl), (E + KV + r * KVl, KVl)):
+                half = n // 2
+                up(T["wqkv"], l, base, fw.wqkv[l, base:base + half], 2)
+                up(T["wqkv"], l, base + half, fw.wqkv[l, base + half:base + n], 2)
+            up(T["wo"], l, 0, fw.wo[l, :E // 2], 2)
+            up(T["wo"], l, E // 2, fw.wo[l, E // 2:], 2)
+            for base in (r * Hl, H + r * Hl):
+                up(T["w13"], l, base, fw.w13[l, base:base + Hl], 2)
+            up(T["w2"], l, 0, fw.w2[l], 2)
+        own.append(m)
+    n = 6
+    a_t, a_l = tp_generate(whole, n, s)
+    b_t, b_l = tp_generate(own, n, s)
+    assert np.array_equal(a_l, b_l) and np.array_equal(a_t, b_t)
+    for m in whole + own:
+        m.close()
+
+
 def test_shards_hold_only_their_share_and_bad_splits_are_rejected(gguf):
     s = gguf.SHAPES["tiny-gqa"]                   # nkv = 2
     fw = gguf.synth_fused(s, 1)
