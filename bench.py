@@ -144,15 +144,9 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
     block format.  With tp_size > 1 the ranks meet over torch.distributed (a side channel only): the 64-byte inbox
     handles of the one-shot peer-memory collectives are all-gathered (collective "p2p"), or rank 0's RCCL unique id is
     broadcast (collective "rccl", the library baseline)."""
-    import ctypes as C
     s = shape
     E, H, L, KV, V = s.emb_dim, s.hidden_dim, s.n_layers, s.kv_dim, s.vocab_size
-    cfg = llmk.Config(E, H, L, s.n_heads, s.n_kv_heads, V, s.seq_len, wtype, device, flags)
-    m = llmk.Llmk.__new__(llmk.Llmk)
-    m.shape, m.V, m.tp_rank, m.tp_size = s, V, tp_rank, tp_size
-    m._h = C.c_void_p()
-    llmk._ck(llmk.lib().llmk_create_tp(C.byref(cfg), tp_rank, tp_size, C.byref(m._h)))
-    m._logits = np.empty(V, np.float32)
+    m = llmk.Llmk.create_empty(s, wtype, device, flags, tp_rank, tp_size)
     if (tp_size > 1 or rep is not None) and collective == "p2p" and tp_size > 1:
         handles = [None] * tp_size
         rep.dist.all_gather_object(handles, m.tp_p2p_handle())
@@ -167,6 +161,8 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
             uids = [None] * tp_size
             rep.dist.all_gather_object(uids, llmk.Llmk.tp_unique_id() if tp_rank == 0 else None)
             m.tp_init_comm(uids[0])
+    elif collective == "none":
+        pass            # an unconnected rank: kernel timing only (tests/host_tools/tp_rank_time.py)
     elif tp_size > 1 or rep is not None:
         uid = llmk.Llmk.tp_unique_id() if tp_rank == 0 else bytes(128)
         if rep is not None and rep.dist is not None:
@@ -176,11 +172,10 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
             uid = bytes(t.cpu().tolist())
         m.tp_init_comm(uid)
 
-    def up(tid, layer, arr, typ):
-        arr = np.ascontiguousarray(arr)
-        llmk._ck(llmk.lib().llmk_upload_rows(m._h, tid, layer, 0, arr.shape[0] if arr.ndim > 1 else 1, arr.ctypes.data,
-                                             arr.nbytes, typ))
-    T = llmk.TENSOR_IDS
+    T = {k: k for k in llmk.TENSOR_IDS}
+
+    def up(name, layer, arr, typ):
+        m.upload_rows(name, layer, 0, arr, typ)
     names = gguf.tensor_names(s)
     idx = {n: i for i, (n, _, _) in enumerate(names)}
     if fw is not None:

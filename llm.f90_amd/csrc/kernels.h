@@ -378,7 +378,33 @@ __device__ __forceinline__ float cvt_ubyte(unsigned v) {
 // One dword = bytes 4i..4i+3 of a block: low nibbles are elements 4i.., high nibbles elements 16+4i...
 // lo += sum n_lo x ;  hi16 += sum (16 n_hi) x   -- the high nibbles are converted in place (q & 0xF0F0F0F0 = 16 n),
 // the exact factor 1/16 is applied once per block by the caller.
+// Round 3: no conversion -- the nibbles are used where they lie as f16 SUBNORMALS (0x000n = n * 2^-24, 0x00n0 = 16 n * 2^-24)
+// through v_fma_mix_f32 (f16 source half selected by op_sel, f32 multiplicand and accumulator): 1 shift + 4 ands + 8
+// fma_mix per dword instead of 2 ands + 8 half-rate v_cvt_f32_ubyteN + 8 fmas; chains in element order, every partial sum
+// is the old one times 2^-24 exactly, so q4_block_fold's rescale gives bit-identical results (probes/q4_mix_probe.hip).
+#ifndef LLMK_Q4_MIX
+#define LLMK_Q4_MIX 1
+#endif
 __device__ __forceinline__ void q4_dword_dot(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
+#if LLMK_Q4_MIX
+    unsigned l0, h0, l1, h1, s;
+    asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
+        "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
+        "v_lshrrev_b32 %[s], 8, %[q]\n\t"
+        "v_and_b32 %[l1], 0x000f000f, %[s]\n\t"
+        "v_fma_mix_f32 %[lo], %[l0], %[a0], %[lo] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h0], %[b0], %[hi] op_sel_hi:[1,0,0]\n\t"
+        "v_and_b32 %[h1], 0x00f000f0, %[s]\n\t"
+        "v_fma_mix_f32 %[lo], %[l1], %[a1], %[lo] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h1], %[b1], %[hi] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[lo], %[l0], %[a2], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h0], %[b2], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[lo], %[l1], %[a3], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h1], %[b3], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : [lo] "+v"(lo), [hi] "+v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
+        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
+          [b2] "v"(xh.z), [b3] "v"(xh.w));
+#else
     const unsigned l = q & 0x0F0F0F0Fu, h = q & 0xF0F0F0F0u;
     lo = fmaf(cvt_ubyte<0>(l), xl.x, lo);
     lo = fmaf(cvt_ubyte<1>(l), xl.y, lo);
@@ -388,9 +414,15 @@ __device__ __forceinline__ void q4_dword_dot(unsigned q, const float4& xl, const
     hi16 = fmaf(cvt_ubyte<1>(h), xh.y, hi16);
     hi16 = fmaf(cvt_ubyte<2>(h), xh.z, hi16);
     hi16 = fmaf(cvt_ubyte<3>(h), xh.w, hi16);
+#endif
+}
+// the two chains of a block (tl: low nibbles, th: 16 x high nibbles) -> sum n x, on the old recipe's scale
+__device__ __forceinline__ float q4_block_fold(float tl, float th) {
+    const float t = fmaf(th, 0.0625f, tl);
+    return LLMK_Q4_MIX ? t * 16777216.0f : t;       // exact (a power of two)
 }
 
-template <int EPI, bool NORM, int NP>
+template <int EPI, bool NORM, int NP, int KS = 1>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* red = reinterpret_cast<float*>(smem_raw);          // [4]
@@ -404,7 +436,10 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     const int xp = nblk + 1;
     float* xsum = reinterpret_cast<float*>(xs + 8 * xp);      // [nblk] block sums of the staged x
     const int npairs = (EPI == EPI_SWIGLU) ? a.H : (a.rows >> 1);
-    const int g0 = (blockIdx.x * GEMV_WAVES + wid) * NP;      // first pair of this wave
+    constexpr int NGRP = GEMV_WAVES / KS;                     // row groups per block
+    const int ksl = wid % KS;                                 // this wave's column slice
+    const int g0 = (blockIdx.x * NGRP + wid / KS) * NP;       // first pair of this wave
+    const int cb = nblk / KS, cb0 = ksl * cb;                 // its block columns [cb0, cb0 + cb)
     const char* Wb = reinterpret_cast<const char*>(a.W);
     const size_t RS = (size_t)a.row_stride;
     const int soff = K >> 1;                                  // a row's scales follow its K/2 nibble bytes
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     uint4 wq[NR];
     __half wd[NR];
     {
-        const int b = min(lane, nblk - 1);
+        const int b = min(cb0 + lane, nblk - 1);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const char* rp = Wb + (size_t)rows[i] * RS;
@@ -474,14 +509,14 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     float acc[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[i] = 0.f;
-    for (int b0 = 0; b0 < nblk; b0 += WAVE) {
+    for (int b0 = cb0; b0 < cb0 + cb; b0 += WAVE) {
         const int bl = b0 + lane;
-        const bool live = bl < nblk;
+        const bool live = bl < cb0 + cb;
         const int b = live ? bl : nblk - 1;
         // next column's loads go out before this column's math
         uint4 nq[NR];
         __half nd[NR];
-        const bool more = b0 + WAVE < nblk;   // wave-uniform
+        const bool more = b0 + WAVE < cb0 + cb;   // wave-uniform
         if (more) {
             const int nb = min(bl + WAVE, nblk - 1);
 #pragma unroll
@@ -505,7 +540,7 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
             q4_dword_dot(wq[i].y, xl[1], xh[1], tl, th);
             q4_dword_dot(wq[i].z, xl[2], xh[2], tl, th);
             q4_dword_dot(wq[i].w, xl[3], xh[3], tl, th);
-            const float t = fmaf(th, 0.0625f, tl);
+            const float t = q4_block_fold(tl, th);
             const float d = live ? __half2float(wd[i]) : 0.f;
             acc[i] = fmaf(d, t - xs8, acc[i]);
         }
@@ -516,6 +551,23 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[i] = wave_sum(acc[i]);
+    if constexpr (KS > 1) {   // the row's KS column-slice sums, added in slice order by the group's first wave
+        float* ksum = xsum;   // (the staged block sums are dead once every wave has left the loop)
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) ksum[wid * NR + i] = acc[i];
+        }
+        __syncthreads();
+        if (ksl != 0) return;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            float t = ksum[wid * NR + i];
+#pragma unroll
+            for (int k = 1; k < KS; ++k) t += ksum[(wid + k) * NR + i];
+            acc[i] = t;
+        }
+    }
     if (NORM) {
 #pragma unroll
         for (int i = 0; i < NR; ++i) acc[i] = acc[i] / xn;

@@ -181,16 +181,27 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
             const int npairs = (EPI == EPI_SWIGLU) ? a.H : a.rows / 2;
             const size_t smem = 16 + (size_t)a.K * sizeof(float) + 8 * 16 + (size_t)(a.K / 32) * sizeof(float);   // x (pitch nblk+1) + block sums
             const int want = 2 * n_cu;
-#define Q4_LAUNCH(NP_)                                                                                           \
+#define Q4_LAUNCH(NP_, KS_)                                                                                      \
             do {                                                                                                 \
-                const int blocks = (npairs + GEMV_WAVES * NP_ - 1) / (GEMV_WAVES * NP_);                         \
+                const int blocks = (npairs + (GEMV_WAVES / KS_) * NP_ - 1) / ((GEMV_WAVES / KS_) * NP_);         \
                 hipError_t pe;                                                                                   \
-                if (prepare_only(gemv_q4_kernel<EPI, NORM, NP_>, smem, &pe)) return pe;                          \
-                hipLaunchKernelGGL((gemv_q4_kernel<EPI, NORM, NP_>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a); \
+                if (prepare_only(gemv_q4_kernel<EPI, NORM, NP_, KS_>, smem, &pe)) return pe;                     \
+                hipLaunchKernelGGL((gemv_q4_kernel<EPI, NORM, NP_, KS_>), dim3(blocks), dim3(GEMV_THREADS), smem, st, a); \
             } while (0)
-            if (npairs / (GEMV_WAVES * 4) >= want) Q4_LAUNCH(4);
-            else if (npairs / (GEMV_WAVES * 2) >= want) Q4_LAUNCH(2);
-            else Q4_LAUNCH(1);
+            // wide rows (K a multiple of 8192: the Llama-2-70B rank shapes): column slices across the block's waves
+            static const int ks_env = getenv("LLMK_Q4_KS") ? atoi(getenv("LLMK_Q4_KS")) : -1;     // measurement aid: 0 = never
+            // ... and only where even one pair per wave leaves CUs without a block (measured on rank 0 of 8 of the 70B shape,
+            // tests/host_tools/tp_rank_time.py: QKV, 640 pairs, 7.9 -> 6.8 us; w1|w3 13.3 -> 18.8 us and the classifier shard
+            // 9.3 -> 12.0 us the OTHER way: four times the blocks each stage the whole x)
+            const bool wide = (a.K % 8192) == 0 && ks_env != 0 && (npairs / GEMV_WAVES < n_cu || ks_env > 0);
+            if (wide) {
+                if (npairs / 4 >= want) Q4_LAUNCH(4, 4);
+                else if (npairs / 2 >= want) Q4_LAUNCH(2, 4);
+                else Q4_LAUNCH(1, 4);
+            }
+            else if (npairs / (GEMV_WAVES * 4) >= want) Q4_LAUNCH(4, 1);
+            else if (npairs / (GEMV_WAVES * 2) >= want) Q4_LAUNCH(2, 1);
+            else Q4_LAUNCH(1, 1);
 #undef Q4_LAUNCH
             return hipGetLastError();
         }
@@ -1506,9 +1517,15 @@ int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) {
     HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
     const int n = std::max(c->E, c->V);
     int rc = LLMK_OK;
+    // The serial that makes the epochs unique is bumped ON THE DEVICE between rounds (the host's copy is brought in step at
+    // the end): an async copy out of the pinned h_tokpos per round would read whatever the host loop, running ahead, had
+    // already written there -- ranks would disagree on the epochs (seen: 4 rounds pass, 64 time out).
+    hipError_t e0 = hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream);
+    if (e0 == hipSuccess) e0 = hipStreamSynchronize(c->stream);
+    if (e0 != hipSuccess) rc = LLMK_E_HIP + (int)e0;
     for (int it = 0; it < iters && rc == LLMK_OK; ++it) {
-        c->h_tokpos[2] += 1;                     // fresh epochs, as for a token
-        hipError_t e = hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream);
+        hipLaunchKernelGGL(bump_serial_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tokpos);
+        hipError_t e = hipGetLastError();
         if (e == hipSuccess) {
             hipLaunchKernelGGL(tp_selftest_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_part, c->d_x, c->d_logits, c->E,
                                c->V, c->tp_rank, c->tp_size, it);
@@ -1524,6 +1541,7 @@ int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) {
         }
         if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
     }
+    c->h_tokpos[2] += iters;                     // every rank ran the same number of rounds: the serials stay in step
     unsigned bad = 0, err = 0;
     if (rc == LLMK_OK) {
         hipError_t e = hipStreamSynchronize(c->stream);

@@ -528,7 +528,39 @@ __device__ __forceinline__ float4 tk_h2f_hi(const float4& w) {   // halves 4..7
 // Measured (probes/q4_alu_probe.hip, 2 waves per SIMD): 50 cycles per dword per SIMD -- v_cvt_f32_ubyteN issues at half
 // rate (3.6 cycles), and so does v_cvt_pk_f32_fp8 (a byte 0x0n read as OCP e4m3 is exactly n * 2^-9: two nibbles per
 // instruction, but 4.4 cycles each plus a use stall: 57 cycles per dword, slower in the kernel too).
+// Round 3: NO conversion at all.  A 16-bit half whose only set bits are a nibble at bits 0-3 IS the f16 subnormal
+// n * 2^-24 (at bits 4-7: 16 n * 2^-24), and v_fma_mix_f32 multiplies an f16 source -- the low or the high half of a
+// register, by op_sel -- with an f32 multiplicand into an f32 accumulator, exactly: q & 0x000F000F holds elements 4i and
+// 4i+2, q & 0x00F000F0 elements 16+4i and 16+4i+2 (x16), the same masks on q >> 8 the odd ones (the chains still run in
+// element order: a different order is a different, equally good, sum -- and would not be bit-identical any more).  1 shift + 4 ands +
+// 8 fma_mix = 13 full-rate operations per dword against 2 ands + 8 half-rate conversions + 8 fmas; every product and
+// every partial sum is the old recipe's times 2^-24 (a power of two commutes with rounding), so after the exact rescale
+// in tk_q4_block the results are BIT-IDENTICAL (probes/q4_mix_probe.hip: 65,536 random dword chains, zero differences;
+// cycles per dword there).  lo += 2^-24 sum n_lo x, hi16 += 2^-24 sum (16 n_hi) x.
+#ifndef LLMK_Q4_MIX
+#define LLMK_Q4_MIX 1
+#endif
+constexpr float TK_Q4_RESCALE = LLMK_Q4_MIX ? 16777216.0f : 1.0f;
 __device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
+#if LLMK_Q4_MIX
+    unsigned l0, h0, l1, h1, s;
+    asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
+        "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
+        "v_lshrrev_b32 %[s], 8, %[q]\n\t"
+        "v_and_b32 %[l1], 0x000f000f, %[s]\n\t"
+        "v_fma_mix_f32 %[lo], %[l0], %[a0], %[lo] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h0], %[b0], %[hi] op_sel_hi:[1,0,0]\n\t"
+        "v_and_b32 %[h1], 0x00f000f0, %[s]\n\t"
+        "v_fma_mix_f32 %[lo], %[l1], %[a1], %[lo] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h1], %[b1], %[hi] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[lo], %[l0], %[a2], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h0], %[b2], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[lo], %[l1], %[a3], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h1], %[b3], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : [lo] "+v"(lo), [hi] "+v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
+        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
+          [b2] "v"(xh.z), [b3] "v"(xh.w));
+#else
     unsigned l, h;
     float t0, t1;
     asm("v_and_b32 %[l], 0x0f0f0f0f, %[q]\n\t"
@@ -552,6 +584,13 @@ __device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const 
         : [lo] "+v"(lo), [hi] "+v"(hi16), [l] "=&v"(l), [h] "=&v"(h), [t0] "=&v"(t0), [t1] "=&v"(t1)
         : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
           [b2] "v"(xh.z), [b3] "v"(xh.w));
+#endif
+}
+// one block's contribution d * (sum n x - 8 sum x) from the two chains of tk_q4_dword (tl, th) and xs8 = 8 sum x
+__device__ __forceinline__ float tk_q4_block(float tl, float th, float d, float xs8, float acc) {
+    const float t = fmaf(th, 0.0625f, tl);
+    if constexpr (LLMK_Q4_MIX) return fmaf(d, fmaf(t, TK_Q4_RESCALE, -xs8), acc);   // t * 2^24 is exact: == d * (t_old - xs8) + acc
+    else return fmaf(d, t - xs8, acc);
 }
 
 template <class SH>
@@ -570,10 +609,9 @@ __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, fl
                 float tl = 0.f, th = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
-                const float t = fmaf(th, 0.0625f, tl);
                 const unsigned short hs = e.sc[s * SH::LPT + jj];
                 const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
-                acc = fmaf(d, t - x.xs8[jj], acc);
+                acc = tk_q4_block(tl, th, d, x.xs8[jj], acc);
             }
             out[s] = acc;
         }
@@ -900,7 +938,22 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     }
     unsigned long long* tr = (TK_DEBUG && tk_trace(a)) ? tk_trace(a) + (size_t)c * TK_TRACE_N : nullptr;
     const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
+// LLMK_TK_STAMP_MODE (product build; an experiment knob of round 3's A/B): what a stamp site leaves behind when the
+// stamps are compiled out -- 0 nothing, 1 a scheduling barrier, 2 a compiler memory barrier
+// loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it)
+#ifndef LLMK_TK_HB_NL
+#define LLMK_TK_HB_NL 32
+#endif
+#ifndef LLMK_TK_STAMP_MODE
+#define LLMK_TK_STAMP_MODE 0
+#endif
+#if defined(LLMK_TK_DEBUG) || LLMK_TK_STAMP_MODE == 0
 #define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
+#elif LLMK_TK_STAMP_MODE == 1
+#define TK_STAMP(i) __builtin_amdgcn_sched_barrier(0)
+#else
+#define TK_STAMP(i) asm volatile("" ::: "memory")
+#endif
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
@@ -1038,7 +1091,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
         if constexpr (SH::COOP) ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
-        else ok = tk_gather<SH::H, TR_H, 32>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        else ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -1187,10 +1240,9 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
             float tl = 0.f, th = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
-            const float t = fmaf(th, 0.0625f, tl);
             const unsigned short hs = e.sc[s_ * 2 + jj];
             const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
-            acc = fmaf(d, t - x.xs8[jj], acc);
+            acc = tk_q4_block(tl, th, d, x.xs8[jj], acc);
         }
         return acc;
     };

@@ -126,12 +126,34 @@ class Llmk:
             is_mat = name in ("wqkv", "wo", "w13", "w2", "wcls")
             _ck(lib().llmk_upload(self._h, tid, a.ctypes.data, a.nbytes,
                                   (cls_type if name == "wcls" else fw.ggml_type) if is_mat else 0))
+        self._finish_init()
+
+    def _finish_init(self):
         # the reference's own f32 expression for the RoPE frequencies (llama2.f90:544-545)
-        hs = s.head_size
+        hs = self.shape.head_size
         fr = np.float32(1.0) / np.power(np.float32(10000.0), (np.arange(1, hs, 2, dtype=np.float32) / np.float32(hs)),
                                         dtype=np.float32)
         self.set_rope_freqs(fr)
         self._logits = np.empty(self.V, np.float32)
+
+    @classmethod
+    def create_empty(cls, shape, ggml_type: int, device: int = 0, flags: int = 0, tp_rank: int = 0, tp_size: int = 1,
+                     seq_len: int | None = None) -> "Llmk":
+        """A context WITHOUT weights: the caller streams them in with upload_rows (bench.build_streamed, the loader tests)."""
+        m = cls.__new__(cls)
+        m.shape, m.V, m.tp_rank, m.tp_size = shape, shape.vocab_size, tp_rank, tp_size
+        cfg = Config(shape.emb_dim, shape.hidden_dim, shape.n_layers, shape.n_heads, shape.n_kv_heads, shape.vocab_size,
+                     seq_len or shape.seq_len, ggml_type, device, flags)
+        m._h = C.c_void_p()
+        _ck(lib().llmk_create_tp(C.byref(cfg), tp_rank, tp_size, C.byref(m._h)))
+        m._finish_init()
+        return m
+
+    def upload_rows(self, name: str, layer: int, row0: int, arr, ggml_type: int):
+        """rows row0.. of layer `layer` of the FULL tensor `name` (a tensor-parallel ctx keeps what its shard holds)"""
+        arr = np.ascontiguousarray(arr)
+        _ck(lib().llmk_upload_rows(self._h, TENSOR_IDS[name], layer, row0, arr.shape[0] if arr.ndim > 1 else 1, arr.ctypes.data,
+                                   arr.nbytes, ggml_type))
 
     def set_rope_freqs(self, fr):
         fr = np.ascontiguousarray(fr, np.float32)

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
 """Peak resident memory of `llm` while it loads a big q4_0 GGUF (shard-only loading).
-Writes a synthetic file of the chosen shape tensor by tensor, then runs the CLI under /usr/bin/time -v:
+Writes a synthetic file of the chosen shape tensor by tensor, then runs the CLI and reads the children's rusage:
     python tests/host_tools/tp_load_rss.py llama2-7b                 whole-file load vs --stream-load, one GPU
     python tests/host_tools/tp_load_rss.py llama2-70b --ngpu 8       eight rank processes sharing this box's GPU
-`Maximum resident set size` of the process tree's largest member (rank 0 waits for its workers, so their usage is in its
-rusage).  One JSON line per run."""
+ru_maxrss of RUSAGE_CHILDREN = the largest member of the waited-for process tree (with --ngpu the workers are started
+through the shell in the background and are NOT waited for: their own peak is read from /proc/<pid>/status VmHWM while
+they run).  One JSON line per run."""
 import json
 import os
 import re
+import resource
 import shutil
+import threading
 import subprocess
 import sys
 import tempfile
@@ -38,12 +41,33 @@ with tempfile.TemporaryDirectory(dir=base, prefix="llmk_rss_") as td:
         if ngpu > 1:
             env["LLMK_TP_SAME_DEVICE"] = "1"
         t0 = time.time()
-        r = subprocess.run(["/usr/bin/time", "-v", LLM, "-m", path, "-n", "8", "-t", "0"] + extra, capture_output=True, cwd=td, env=env,
-                           timeout=3000)
-        m = re.search(rb"Maximum resident set size \(kbytes\): (\d+)", r.stderr)
+        before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+        p = subprocess.Popen([LLM, "-m", path, "-n", "8", "-t", "0"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=td, env=env)
+        hwm = {}          # pid -> peak resident kB of every `llm` process seen (rank 0 and its workers)
+
+        def watch():
+            while p.poll() is None:
+                for pid in os.listdir("/proc"):
+                    if not pid.isdigit():
+                        continue
+                    try:
+                        if os.readlink(f"/proc/{pid}/exe") != LLM:
+                            continue
+                        m = re.search(r"VmHWM:\s+(\d+) kB", open(f"/proc/{pid}/status").read())
+                        if m:
+                            hwm[pid] = max(hwm.get(pid, 0), int(m.group(1)))
+                    except OSError:
+                        pass
+                time.sleep(0.05)
+        th = threading.Thread(target=watch)
+        th.start()
+        out, err = p.communicate(timeout=3000)
+        th.join()
+        after = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
         print(json.dumps({"shape": shape_name, "file_GB": round(size / 1e9, 2), "write_s": round(t_write, 1), "args": extra,
-                          "rc": r.returncode, "wall_s": round(time.time() - t0, 1),
-                          "max_rss_GB": round(int(m.group(1)) / 1e6, 3) if m else None,
-                          "tokens_line": r.stdout.split(b"\n")[1][:60].decode(errors="replace") if r.stdout.count(b"\n") > 1 else ""}))
-        if r.returncode:
-            sys.stderr.write(r.stderr.decode(errors="replace")[-2000:])
+                          "rc": p.returncode, "wall_s": round(time.time() - t0, 1),
+                          "max_rss_GB_rusage_children": round(max(after, before) / 1e6, 3),
+                          "peak_rss_GB_per_process": sorted(round(v / 1e6, 3) for v in hwm.values()),
+                          "tokens_line": out.split(b"\n")[1][:60].decode(errors="replace") if out.count(b"\n") > 1 else ""}))
+        if p.returncode:
+            sys.stderr.write(err.decode(errors="replace")[-2000:])

@@ -17,7 +17,7 @@ s70 = gguf.SHAPES["llama2-70b"]
 s = gguf.LlamaShape(s70.emb_dim, s70.hidden_dim, L, s70.n_heads, s70.n_kv_heads, s70.vocab_size, 512)
 llmk.Llmk.tp_init_comm = lambda self, uid: None          # no communicator: kernels only
 t0 = time.time()
-m = bench.build_streamed(s, 2, None, 0, llmk.FLAG_NO_GRAPH, 0, P, None)
+m = bench.build_streamed(s, 2, None, 0, llmk.FLAG_NO_GRAPH, 0, P, None, "none")
 print(f"built rank 0/{P} of a 70B-shaped {L}-layer model in {time.time()-t0:.0f} s")
 names = ["qkv", "attention", "wo (partial)", "w1|w3", "w2 (partial)", "classifier shard"]
 tot = 0.0

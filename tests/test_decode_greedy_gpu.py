@@ -89,7 +89,7 @@ def test_decode_greedy_f16_kernel(wtype, shape, gguf):
     fw = gguf.synth_fused(gguf.SHAPES[shape], 4242, wtype)
     m = llmk.Llmk(fw)
     assert m.path() == 1
-    n = 96
+    n = fw.shape.seq_len
     ids = m.decode_greedy(2, 1, n)
     m.reset()
     toks, _ = m.generate(n, want_logits=False)

@@ -19,6 +19,20 @@ P = 8
 FIELDS = ("token_embedding_table", "rms_att_weight", "rms_ffn_weight", "rms_final_weight", "wqkv", "wo", "w13", "w2", "wcls")
 
 
+class _Side:
+    """the ranks' side channel over the test's pipes: all_gather_object as torch.distributed spells it (what bench.py's
+    build_streamed expects of `rep.dist`); the parent relays (see _run_ranks)"""
+    device = None
+
+    def __init__(self, conn):
+        self.conn = conn
+        self.dist = self
+
+    def all_gather_object(self, out, obj):
+        self.conn.send(("gather", obj))
+        out[:] = self.conn.recv()
+
+
 def _rank_oracle_case(rank, dirpath, n, prompt, conn):
     """one rank process: its shard of the weights the parent left in dirpath, handles over the pipe, n positions"""
     import llm_f90_amd     # noqa: F401
@@ -29,11 +43,14 @@ def _rank_oracle_case(rank, dirpath, n, prompt, conn):
     for f in FIELDS:
         setattr(fw, f, np.load(os.path.join(dirpath, f + ".npy"), mmap_mode="r"))
     m = lk.Llmk(fw, device=0, tp_rank=rank, tp_size=P)
-    conn.send(m.tp_p2p_handle())
-    m.tp_p2p_connect(conn.recv())
+    side = _Side(conn)
+    handles, verdicts = [None] * P, [None] * P
+    side.all_gather_object(handles, m.tp_p2p_handle())
+    m.tp_p2p_connect(handles)
+    side.all_gather_object(verdicts, m.tp_p2p_selftest(16))      # every collective on known integers, all ranks together
     _, logits = m.generate(n, prompt=prompt)
     greedy, _ = m.generate(8, want_logits=False, greedy_on_device=True)
-    conn.send((logits, greedy, m.path()))
+    conn.send(("result", (logits, greedy, m.path(), verdicts)))
     m.close()
 
 
@@ -41,24 +58,16 @@ def _rank_full_size(rank, n, conn):
     import bench
     import llm_f90_amd     # noqa: F401
     from llm_f90_amd.tools import gguf as gg
-
-    class Side:            # build_streamed's side channel, over the test's pipes instead of torch.distributed
-        device = None
-
-        class dist:
-            @staticmethod
-            def all_gather_object(out, obj):
-                conn.send(obj)
-                out[:] = conn.recv()
-    m = bench.build_streamed(gg.SHAPES["llama2-70b"], 2, None, 0, 0, rank, P, Side, "p2p")
+    m = bench.build_streamed(gg.SHAPES["llama2-70b"], 2, None, 0, 0, rank, P, _Side(conn), "p2p")
     t1, l1 = m.generate(n)
     t2, l2 = m.generate(n)
     t3, _ = m.generate(n, want_logits=False, greedy_on_device=True)
-    conn.send((t1, l1, bool(np.array_equal(l1, l2) and np.array_equal(t1, t2)), t3, m.path()))
+    conn.send(("result", (t1, l1, bool(np.array_equal(l1, l2) and np.array_equal(t1, t2)), t3, m.path(), m.p2p_selftest)))
     m.close()
 
 
 def _run_ranks(target, args_of, timeout):
+    """P rank processes; the parent relays their all-gathers until every rank has delivered its result"""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(P)]
@@ -66,20 +75,24 @@ def _run_ranks(target, args_of, timeout):
     for p in procs:
         p.start()
 
-    def get(r, what, t):
-        if not pipes[r][0].poll(t):
+    def get(r):
+        if not pipes[r][0].poll(timeout):
             for p in procs:
                 p.terminate()
-            pytest.fail(f"rank {r} never delivered its {what}")
+            pytest.fail(f"rank {r} went silent")
         return pipes[r][0].recv()
-    handles = [get(r, "inbox handle", timeout) for r in range(P)]
-    for r in range(P):
-        pipes[r][0].send(handles)
-    res = [get(r, "result", timeout) for r in range(P)]
+    while True:
+        msgs = [get(r) for r in range(P)]
+        kinds = {k for k, _ in msgs}
+        assert len(kinds) == 1, kinds                 # the ranks move in lock step
+        if kinds == {"result"}:
+            break
+        for r in range(P):
+            pipes[r][0].send([obj for _, obj in msgs])
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    return res
+    return [obj for _, obj in msgs]
 
 
 def test_llama2_70b_geometry_8_rank_processes_match_oracle(gguf, tmp_path_factory):
@@ -95,10 +108,13 @@ def test_llama2_70b_geometry_8_rank_processes_match_oracle(gguf, tmp_path_factor
         ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
         del fw
         res = _run_ranks(_rank_oracle_case, lambda r: (r, td, n, ot.tolist()), 600)
+    assert np.all(np.isfinite(ol))
     margin = np.sort(ol, axis=1)
     safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
-    for r, (logits, greedy, path) in enumerate(res):
+    for r, (logits, greedy, path, verdicts) in enumerate(res):
+        assert np.all(np.isfinite(logits)), (r, np.argwhere(~np.isfinite(logits))[:4].tolist())
         assert path == 2                                           # tensor-parallel rank over the peer-memory collectives
+        assert verdicts == [0] * P                                 # llmk_tp_p2p_selftest: exact sums on every rank
         err = rel_err(logits, ol)
         assert err.max() <= REL_TOL, (r, err.max(), int(np.argmax(err)))
         assert np.array_equal((np.argmax(logits, axis=1) + 1)[safe], ot[safe])
@@ -113,8 +129,8 @@ def test_llama2_70b_full_size_8_rank_processes_properties():
     res = _run_ranks(_rank_full_size, lambda r: (r, n), 900)
     t1, l1 = res[0][0], res[0][1]
     assert np.all(np.isfinite(l1)) and np.abs(l1).max() > 1e-3
-    for r, (t, l, rerun_same, tg, path) in enumerate(res):
-        assert path == 2
+    for r, (t, l, rerun_same, tg, path, verdicts) in enumerate(res):
+        assert path == 2 and verdicts == [0] * P
         assert np.array_equal(l, l1) and np.array_equal(t, t1), r
         assert rerun_same, r
         assert np.array_equal(tg, t1), r

@@ -88,25 +88,18 @@ def test_ranks_fed_only_their_own_rows_hold_the_same_shards(gguf):
     """llmk_upload_rows on a tensor-parallel ctx takes row numbers of the FULL tensor and keeps the part its shard holds:
     a rank handed only its own rows (what host/gguf_loader.f90 stream_ggml_weights reads from the file), in pieces, ends
     with the same shard as a rank handed whole layers -- same logits bit for bit."""
-    import ctypes as C
     s = gguf.LlamaShape(128, 384, 2, 4, 4, 512, 32)
     fw = gguf.synth_fused(s, 99, 2)
     P = 2
     whole = [llmk.Llmk(fw, tp_rank=r, tp_size=P) for r in range(P)]
     E, H, KV, V, L = s.emb_dim, s.hidden_dim, s.kv_dim, s.vocab_size, s.n_layers
-    T = llmk.TENSOR_IDS
+    T = {k: k for k in llmk.TENSOR_IDS}
     own = []
     for r in range(P):
-        m = llmk.Llmk.__new__(llmk.Llmk)
-        m.shape, m.V, m.tp_rank, m.tp_size = s, V, r, P
-        m._h = C.c_void_p()
-        cfg = llmk.Config(E, H, L, s.n_heads, s.n_kv_heads, V, s.seq_len, 2, 0, 0)
-        llmk._ck(llmk.lib().llmk_create_tp(C.byref(cfg), r, P, C.byref(m._h)))
-        m._logits = np.empty(V, np.float32)
+        m = llmk.Llmk.create_empty(s, 2, tp_rank=r, tp_size=P)
 
-        def up(tid, layer, row0, arr, typ):
-            arr = np.ascontiguousarray(arr)
-            llmk._ck(llmk.lib().llmk_upload_rows(m._h, tid, layer, row0, arr.shape[0] if arr.ndim > 1 else 1, arr.ctypes.data, arr.nbytes, typ))
+        def up(name, layer, row0, arr, typ, m=m):
+            m.upload_rows(name, layer, row0, arr, typ)
         for v0 in range(0, V, 100):                                   # replicated, in ragged chunks
             up(T["token_embedding_table"], 0, v0, fw.token_embedding_table[v0:v0 + 100], 0)
         up(T["rms_final_weight"], 0, 0, fw.rms_final_weight, 0)
@@ -195,6 +188,7 @@ def test_one_shot_peer_memory_collectives_virtual_ranks(shape, P, gguf):
     ranks = [llmk.Llmk(fw, tp_rank=r, tp_size=P) for r in range(P)]
     llmk.Llmk.tp_p2p_connect_local(ranks)
     n = int(g["n"])
+    assert _in_threads(ranks, lambda m: m.tp_p2p_selftest(8)) == [0] * P      # every collective on known integers first
     res = _in_threads(ranks, lambda m: m.generate(n))
     for toks, logits in res:
         assert rel_err(logits, g["logits"]).max() <= REL_TOL
@@ -205,6 +199,23 @@ def test_one_shot_peer_memory_collectives_virtual_ranks(shape, P, gguf):
         assert np.array_equal(toks, g["tokens"])
     for m in ranks:
         m.close()
+
+
+def test_failed_self_test_falls_back_to_rccl(gguf):
+    """What a host does when the peer-memory self-test fails on its node: llmk_tp_p2p_disable + llmk_tp_init_comm, and the
+    same ctx decodes over RCCL (1 rank here: a multi-rank communicator needs one GPU per rank)."""
+    g = load_golden("tiny-hs64")
+    fw = gguf.synth_fused(gguf.SHAPES["tiny-hs64"], int(g["seed"]))
+    m = llmk.Llmk(fw, tp_rank=0, tp_size=1)
+    assert m.tp_p2p_selftest(1) != 0                  # not connected: an error code, never a pass
+    with pytest.raises(llmk.LlmkError):
+        llmk.Llmk.tp_p2p_connect_local([m])           # one rank has nobody to exchange with
+    m.tp_p2p_disable()
+    m.tp_init_comm(llmk.Llmk.tp_unique_id())
+    assert m.path() == 3
+    toks, logits = m.generate(12)
+    assert rel_err(logits, g["logits"][:12]).max() <= REL_TOL and np.array_equal(toks, g["tokens"][:12])
+    m.close()
 
 
 def test_one_shot_collectives_q4_0_virtual_ranks(gguf):
