@@ -30,6 +30,29 @@
 
 #include "kernels.h"
 
+// ---- measurement knobs (defaults = the product; -D... builds a variant library for an A/B) ---------------------------
+// loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it).  H = 5632 is
+// 44 loads per lane: 32 -> two pieces of 22.  Round-3 sweep (profiles/r03_gather_piece_sweep.jsonl, kernel us, f16 / f32):
+// one piece of 44: 570 / 723; 22+22: 556 / 719; 15+15+14: 555 / 717 (spills 20 bytes in the f32 kernel); 4 x 11: 553 / 738;
+// 6 x 8: 561 / 743; E-vectors in pieces of 8: 563 / 724.  Nothing beats two pieces by more than the box-to-box noise.
+#ifndef LLMK_TK_HB_NL
+#define LLMK_TK_HB_NL 32
+#endif
+// the same for the E-vectors x / xa (rmsnorm gains are held across these) and xb
+#ifndef LLMK_TK_E_NL
+#define LLMK_TK_E_NL 24
+#endif
+#ifndef LLMK_TK_XB_NL
+#define LLMK_TK_XB_NL 32
+#endif
+// s_sleep argument between two polling passes of a gather (units of 64 clocks)
+#ifndef LLMK_TK_POLL_SLEEP
+#define LLMK_TK_POLL_SLEEP 1
+#endif
+#ifndef LLMK_TK_STAMP_MODE
+#define LLMK_TK_STAMP_MODE 0
+#endif
+
 namespace llmk {
 
 constexpr int TK_NCU = 256;               // one workgroup per CU
@@ -287,7 +310,24 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
+    }
+}
+// pieces of at most MAXNL loads per lane, one after the other (compile-time recursion): piece k+1 is only polled once piece
+// k has arrived.  Smaller pieces make the passes that FAIL cheaper (a pass costs about as much whether or not its tags match,
+// and the first pass after a phase almost always fails) but add dependent round trips: see LLMK_TK_HB_NL for the sweep.
+template <int NL, int NBP, int MAXNL, int FIRST = 0>
+__device__ __forceinline__ bool tk_gather_pieces(__amdgpu_buffer_rsrc_t rs, unsigned epoch, float* dst, unsigned* err, int lane,
+                                                 bool nowait, unsigned long long* dbg) {
+    constexpr int NP = (NL + MAXNL - 1) / MAXNL;          // pieces still to go
+    constexpr int THIS = (NL + NP - 1) / NP;              // as even as possible
+    const bool a = tk_gather_part<THIS, NBP>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg);
+    if constexpr (NL > THIS) {
+        const bool b = tk_gather_pieces<NL - THIS, NBP, MAXNL, FIRST + THIS>(rs, epoch, dst, err, lane, nowait,
+                                                                             (dbg && FIRST == 0) ? dbg + 2 : nullptr);
+        return a && b;
+    } else {
+        return a;
     }
 }
 template <int N, int NBP = 0, int MAXNL = 24>
@@ -296,23 +336,8 @@ __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned 
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
-    // all of a piece's loads are in flight at once (a pass is latency-bound: ~1.4 us per 16 loads per lane under load), so
-    // pieces are as large as the service wave's registers allow at the call site: MAXNL loads = 4 MAXNL VGPRs (32 where no
-    // rmsnorm gains are held across the gather)
-    if constexpr (NL <= MAXNL) {
-        return tk_gather_part<NL, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
-    } else if constexpr (NL <= 2 * MAXNL) {      // long vectors in register-sized pieces
-        constexpr int H0 = NL / 2, H1 = NL - H0;
-        const bool a = tk_gather_part<H0, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
-        const bool b = tk_gather_part<H1, NBP>(rs, H0 * WAVE, epoch, dst, err, lane, nowait, dbg ? dbg + 2 : nullptr);
-        return a && b;
-    } else {
-        constexpr int Q0 = NL / 3, Q2 = NL - 2 * Q0;
-        const bool a = tk_gather_part<Q0, NBP>(rs, 0, epoch, dst, err, lane, nowait, dbg);
-        const bool b = tk_gather_part<Q0, NBP>(rs, Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
-        const bool c = tk_gather_part<Q2, NBP>(rs, 2 * Q0 * WAVE, epoch, dst, err, lane, nowait, nullptr);
-        return a && b && c;
-    }
+    // all of a piece's loads are in flight at once (a pass is latency-bound: ~1.4 us per 16 loads per lane under load)
+    return tk_gather_pieces<NL, NBP, MAXNL>(rs, epoch, dst, err, lane, nowait, dbg);
 }
 
 // ---- cooperative gather (TkShape::COOP): wave w of 8 takes a contiguous eighth of the vector's 16-byte loads ----------
@@ -363,7 +388,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                     return false;
                 }
             }
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
         }
     }
 }
@@ -940,13 +965,6 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
 // LLMK_TK_STAMP_MODE (product build; an experiment knob of round 3's A/B): what a stamp site leaves behind when the
 // stamps are compiled out -- 0 nothing, 1 a scheduling barrier, 2 a compiler memory barrier
-// loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it)
-#ifndef LLMK_TK_HB_NL
-#define LLMK_TK_HB_NL 32
-#endif
-#ifndef LLMK_TK_STAMP_MODE
-#define LLMK_TK_STAMP_MODE 0
-#endif
 #if defined(LLMK_TK_DEBUG) || LLMK_TK_STAMP_MODE == 0
 #define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
 #elif LLMK_TK_STAMP_MODE == 1
@@ -971,7 +989,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
             } else {
-                ok = tk_gather<SH::E>(tk_g_x<SH>(a), e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+                ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_x<SH>(a), e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
             }
             TK_STAMP(1);
             if (!coop0) xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
@@ -1027,7 +1045,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                         ok = false; break;
                     }
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
             }
             TK_STAMP(5);
             tk_barrier();
@@ -1054,7 +1072,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if constexpr (SH::COOP) {
             if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         } else {
-            if (!att_cu) ok = tk_gather<SH::E, TR_E, 32>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+            if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         }
         TK_STAMP(7);
         tk_barrier();
@@ -1074,7 +1092,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
         } else {
             nrm.prefetch(tk_rms_ffn(a, l, SH::E), lane);
-            ok = tk_gather<SH::E>(tk_g_xa<SH>(a), e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+            ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_xa<SH>(a), e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
             TK_STAMP(9);
             xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
             tk_barrier();
