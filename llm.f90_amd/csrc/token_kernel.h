@@ -38,6 +38,16 @@
 #ifndef LLMK_TK_HB_NL
 #define LLMK_TK_HB_NL 32
 #endif
+// hb as 16-byte {v0, v1, v2, tag} granules (f32 / f16 kernels): 1 = on; loads per lane per pass of that gather.
+// MEASURED AND LEFT OFF (round 3, profiles/r03_hb3_granule16_ab.jsonl; parity green with it on): kernel 555 -> 595 us on
+// TinyLlama f16, 713 -> 740 us on f32, whatever the piece size (32 / 16 / 11 loads per pass).  A third fewer sweep bytes do
+// not pay for the 16-byte sc1 stores and the three predicated LDS writes per load: the flat 8-byte {value, tag} sweep stays.
+#ifndef LLMK_TK_HB3
+#define LLMK_TK_HB3 0
+#endif
+#ifndef LLMK_TK_HB3_NL
+#define LLMK_TK_HB3_NL 16
+#endif
 // the same for the E-vectors x / xa (rmsnorm gains are held across these) and xb
 #ifndef LLMK_TK_E_NL
 #define LLMK_TK_E_NL 24
@@ -338,6 +348,66 @@ __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned 
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     // all of a piece's loads are in flight at once (a pass is latency-bound: ~1.4 us per 16 loads per lane under load)
     return tk_gather_pieces<NL, NBP, MAXNL>(rs, epoch, dst, err, lane, nowait, dbg);
+}
+
+// ---- 16-byte granules {v0, v1, v2, tag} for the hb vector (round 3; probes/granule16_probe: a 16-byte sc1 store is never
+// seen torn by a 16-byte sc1 load) ------------------------------------------------------------------------------------------
+// The hb exchange is the longest edge of a layer (H = 2.75 E values: 44 loads per lane as {v, tag} pairs): three values per
+// 16 bytes instead of two make it 32.  Every CU publishes its UPC = H / 256 hidden units as GPC = ceil(UPC / 3) granules
+// (the last one padded), granule G = c * GPC + i holds units 3i .. 3i+2 of CU c.  GPC divides 64, so the granules a lane
+// reads in one pass (G, G + 64, ...) all have the same i: their LDS destinations differ by a compile-time stride and the
+// "which of the three values are real" mask is per lane, as in tk_gather_part.
+__device__ __forceinline__ void tk_publish3(void* g, int index, unsigned epoch, float v0, float v1, float v2) {
+    const tk_v4u d = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), epoch};
+    __builtin_amdgcn_raw_buffer_store_b128(d, tk_rsrc(g, (index + 1) * 16), index * 16, 0, 16);   // aux 16 = sc1 (agent scope, write-through)
+}
+template <int NL, int GPC, int UPC>
+__device__ __forceinline__ bool tk_gather3_part(__amdgpu_buffer_rsrc_t rs, int first, unsigned epoch, float* dst, unsigned* err,
+                                                int lane, bool nowait, unsigned long long* dbg) {
+    static_assert(WAVE % GPC == 0, "granules of one lane share their position inside a CU's group");
+    const int G = first + lane, i = G % GPC;
+    const int dst0 = (G / GPC) * UPC + 3 * i;
+    const bool m1 = 3 * i + 1 < UPC, m2 = 3 * i + 2 < UPC;
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long tp0 = (TK_DEBUG && dbg) ? wall_clock64() : 0;
+        tk_v4u r[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, G * 16, k * WAVE * 16, 16);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            ok = ok & (r[k].w == epoch);
+            float* d = dst + dst0 + k * (WAVE / GPC) * UPC;
+            d[0] = __uint_as_float(r[k].x);
+            if (m1) d[1] = __uint_as_float(r[k].y);
+            if (m2) d[2] = __uint_as_float(r[k].z);
+        }
+        if (__all(ok) || nowait) {
+            if (TK_DEBUG && dbg && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
+            return true;
+        }
+        if ((spin & 63) == 63) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spin > TK_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(err, 0x500u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
+    }
+}
+template <int NL, int GPC, int UPC, int MAXNL, int FIRST = 0>
+__device__ __forceinline__ bool tk_gather3_pieces(__amdgpu_buffer_rsrc_t rs, unsigned epoch, float* dst, unsigned* err, int lane,
+                                                  bool nowait, unsigned long long* dbg) {
+    constexpr int NP = (NL + MAXNL - 1) / MAXNL, THIS = (NL + NP - 1) / NP;
+    const bool a = tk_gather3_part<THIS, GPC, UPC>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg);
+    if constexpr (NL > THIS) {
+        const bool b = tk_gather3_pieces<NL - THIS, GPC, UPC, MAXNL, FIRST + THIS>(rs, epoch, dst, err, lane, nowait,
+                                                                                   (dbg && FIRST == 0) ? dbg + 2 : nullptr);
+        return a && b;
+    } else {
+        return a;
+    }
 }
 
 // ---- cooperative gather (TkShape::COOP): wave w of 8 takes a contiguous eighth of the vector's 16-byte loads ----------
@@ -944,6 +1014,9 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // q4_0: the streaming input is staged transposed (TkLds); 0 = natural order
     constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
+    // hb as {v0, v1, v2, tag} granules: the f32 / f16 kernels (the q4_0 kernel gathers with all eight waves, tk_coop_gather)
+    constexpr int GPC_A = (SH::R_A / 2 + 2) / 3;
+    constexpr bool HB3 = LLMK_TK_HB3 && !SH::COOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
     const int L = a.L;
     const int tok = tk_token<GR>(a, c, lane);
     const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
@@ -1100,15 +1173,24 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         TK_STAMP(10);
         tk_barrier();
         TK_STAMP(11);
+        float hbv = 0.f;
         if (lane < SH::R_A / 2) {
             float gsum = part[2 * lane], usum = part[2 * lane + 1];
             gsum = gsum / xn_ffn;
             usum = usum / xn_ffn;
             const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
-            tk_publish(tk_g_hb<SH>(a) + c * (SH::R_A / 2) + lane, e_a, hb * usum);
+            if constexpr (!HB3) tk_publish(tk_g_hb<SH>(a) + c * (SH::R_A / 2) + lane, e_a, hb * usum);
+            else hbv = hb * usum;
+        }
+        if constexpr (HB3) {   // three units per 16-byte granule: lane i < GPC collects units 3i .. 3i+2 (pads: 0)
+            const float v0 = __shfl(hbv, 3 * lane, WAVE), v1 = __shfl(hbv, 3 * lane + 1, WAVE), v2 = __shfl(hbv, 3 * lane + 2, WAVE);
+            if (lane < GPC_A) tk_publish3(tk_g_hb<SH>(a), c * GPC_A + lane, e_a, v0, 3 * lane + 1 < SH::R_A / 2 ? v1 : 0.f, 3 * lane + 2 < SH::R_A / 2 ? v2 : 0.f);
         }
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
         if constexpr (SH::COOP) ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+        else if constexpr (HB3)
+            ok = tk_gather3_pieces<TK_NCU * GPC_A / WAVE, GPC_A, SH::R_A / 2, LLMK_TK_HB3_NL>(tk_rsrc(tk_g_hb<SH>(a), TK_NCU * GPC_A * 16), e_a, xs, a.err, lane,
+                                                                                             nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         else ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         TK_STAMP(12);
         tk_barrier();
