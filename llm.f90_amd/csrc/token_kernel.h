@@ -62,6 +62,12 @@
 #ifndef LLMK_TK_STAMP_MODE
 #define LLMK_TK_STAMP_MODE 0
 #endif
+// s_sleep units (64 clocks each, at most 127 per instruction) a non-attention CU lets pass before its FIRST poll of xb: the
+// attention output cannot exist earlier than the q hand-off plus one head's attention, and every pass before that is 16 KB
+// of fabric reads per CU (x 224 CUs) competing with the attention CUs' own K / V rows
+#ifndef LLMK_TK_XB_DELAY
+#define LLMK_TK_XB_DELAY 0
+#endif
 
 namespace llmk {
 
@@ -249,6 +255,11 @@ struct TkLds {
     static constexpr int ATT_S = ATT_P + TK_WAVES * 32 * 4;                // scores [S], then exp(score - max) [S]
 };
 
+__device__ __forceinline__ void tk_xb_delay() {
+#pragma unroll
+    for (int i = 0; i < LLMK_TK_XB_DELAY / 127; ++i) __builtin_amdgcn_s_sleep(127);
+    if constexpr (LLMK_TK_XB_DELAY % 127 > 0) __builtin_amdgcn_s_sleep(LLMK_TK_XB_DELAY % 127);
+}
 __device__ __forceinline__ void tk_barrier() {
     // LDS traffic ordered by lgkmcnt; outstanding global LOADS deliberately stay in flight across it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1143,8 +1154,9 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
         if constexpr (SH::COOP) {
-            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+            if (!att_cu) { tk_xb_delay(); ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok; }
         } else {
+            if (!att_cu) tk_xb_delay();
             if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
         }
         TK_STAMP(7);
@@ -1494,7 +1506,7 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
             tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
             tk_barrier();
         }
-        if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        if (!att_cu) { tk_xb_delay(); tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync); }
         tk_phase_body<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
         tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
