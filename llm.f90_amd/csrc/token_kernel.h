@@ -62,9 +62,30 @@
 #ifndef LLMK_TK_STAMP_MODE
 #define LLMK_TK_STAMP_MODE 0
 #endif
-// s_sleep units (64 clocks each, at most 127 per instruction) a non-attention CU lets pass before its FIRST poll of xb: the
-// attention output cannot exist earlier than the q hand-off plus one head's attention, and every pass before that is 16 KB
-// of fabric reads per CU (x 224 CUs) competing with the attention CUs' own K / V rows
+// "Gather first" (f32 / f16 kernels).  A CU's memory pipeline is a FIFO: the refill burst a phase ends with (up to NB tiles
+// x 7 waves = 224-280 KB) is issued right after barrier B, the service wave's gather of the NEXT phase's input a moment
+// later -- and waits behind all of it (round-3 traces with every inter-CU wait disabled: the hb sweep alone takes 5.7 us
+// of an 18 us f16 layer).  With LLMK_TK_GF the streaming waves issue only LLMK_TK_GF_NOW tiles each at once and the rest of
+// the burst when the service wave has ISSUED (not completed) the first pass of that gather: the sweep then leads the
+// burst through the pipeline, the dots run on tiles that are already resident while the burst streams.
+// LLMK_TK_GF_DELAY: s_sleep units before the first pass of the hb / x / xa gathers (a pass issued before the last producer
+// has published fails and the retry queues behind the released burst, as before).
+#ifndef LLMK_TK_GF
+#define LLMK_TK_GF 1
+#endif
+// Round-3 sweeps on TinyLlama (profiles/r03_gather_first_sweep.jsonl; kernel us at KV length 256, f16 / f32; off: 555 / 720):
+//   tiles per wave issued at once 1, delay 0: 539 / 727;  delay 16: 531 / 705;  40: 516 / 689-696;  48: 515 / 694;
+//   64: 517 / 701;  96: 567 / 747;  127: 620 / 797;   2 tiles, delay 48-64: 516-526 / 683-687;   3 tiles, 64: 523 / 684;
+//   0 tiles, delay 16: 544 / 735;   per-gather delays (hb 24 / 80, x 16 / 80, xa 16 around a common 48): all within +-1 % or worse.
+// => f16: 1 tile, delay 48; f32: 2 tiles, delay 56.  (-1 = these per-type defaults.)
+#ifndef LLMK_TK_GF_NOW
+#define LLMK_TK_GF_NOW -1
+#endif
+#ifndef LLMK_TK_GF_DELAY
+#define LLMK_TK_GF_DELAY -1
+#endif
+// s_sleep units a non-attention CU lets pass before its FIRST poll of xb (it polls 7 times on average while attention runs:
+// 16 KB of fabric reads per CU and pass).  Measured round 3: 0 ... -1.5 % for 32 / 64 / 100 / 150 units: left at 0.
 #ifndef LLMK_TK_XB_DELAY
 #define LLMK_TK_XB_DELAY 0
 #endif
@@ -185,6 +206,10 @@ struct TkShape {
     // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills
     // that the next phase does not need until its input vector has been gathered (1,675).
     static constexpr bool COOP = Q4;
+    // "gather first" (LLMK_TK_GF): tiles per wave a phase's refill burst issues before the next sweep is in the pipeline, and
+    // s_sleep units the service wave lets the producers have before the first pass of the x / xa / hb sweeps
+    static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : (WT == WT_F16 ? 1 : 2);
+    static constexpr int GF_DELAY = LLMK_TK_GF_DELAY >= 0 ? LLMK_TK_GF_DELAY : (WT == WT_F16 ? 48 : 56);
     static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
     static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
     // rows per CU and tiles per CU for each phase
@@ -267,6 +292,26 @@ __device__ __forceinline__ void tk_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// the "gather issued" sequence number of a CU (LDS word behind the COOP partial sums): see LLMK_TK_GF.  Read and written
+// with explicit ds instructions: through a `volatile int*` hipcc loses the address space and emits FLAT loads, which count
+// in vmcnt -- every poll would wait for the whole prefetch ring (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ unsigned tk_lds_addr(const volatile void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const volatile char*)p;
+}
+__device__ __forceinline__ void tk_flag_set(volatile int* flag, int seq, int lane) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) asm volatile("ds_write_b32 %0, %1" : : "v"(tk_lds_addr(flag)), "v"(seq) : "memory");   // issued after the pass's buffer loads
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void tk_flag_wait(volatile int* flag, int seq) {
+    const unsigned addr = tk_lds_addr(flag);
+    for (int spin = 0; spin < (1 << 16); ++spin) {     // bounded: a wedged service wave must not hang the streaming waves too
+        int v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+        if (v - seq >= 0) return;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 __device__ __forceinline__ void tk_publish(unsigned long long* g, unsigned epoch, float v) {
     __hip_atomic_store(g, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -301,7 +346,8 @@ __device__ __forceinline__ int tk_xoff(int e) {
 }
 template <int NL, int NBP>
 __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* dst,
-                                               unsigned* err, int lane, bool nowait, unsigned long long* dbg) {
+                                               unsigned* err, int lane, bool nowait, unsigned long long* dbg,
+                                               volatile int* flag = nullptr, int seq = 0) {
     const int dst0 = tk_xoff<NBP>(2 * (first_pair + lane));
     for (unsigned spin = 0;; ++spin) {
         const unsigned long long tp0 = (TK_DEBUG && dbg) ? wall_clock64() : 0;
@@ -311,6 +357,7 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
 #pragma unroll
         for (int k = 0; k < NL; ++k)
             r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);   // k in the scalar offset: one VGPR address
+        if (LLMK_TK_GF && flag && spin == 0) tk_flag_set(flag, seq, lane);   // the first pass is in the pipeline: release the burst
         bool ok = true;
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
@@ -339,10 +386,10 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
 // and the first pass after a phase almost always fails) but add dependent round trips: see LLMK_TK_HB_NL for the sweep.
 template <int NL, int NBP, int MAXNL, int FIRST = 0>
 __device__ __forceinline__ bool tk_gather_pieces(__amdgpu_buffer_rsrc_t rs, unsigned epoch, float* dst, unsigned* err, int lane,
-                                                 bool nowait, unsigned long long* dbg) {
+                                                 bool nowait, unsigned long long* dbg, volatile int* flag = nullptr, int seq = 0) {
     constexpr int NP = (NL + MAXNL - 1) / MAXNL;          // pieces still to go
     constexpr int THIS = (NL + NP - 1) / NP;              // as even as possible
-    const bool a = tk_gather_part<THIS, NBP>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg);
+    const bool a = tk_gather_part<THIS, NBP>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg, FIRST == 0 ? flag : nullptr, seq);
     if constexpr (NL > THIS) {
         const bool b = tk_gather_pieces<NL - THIS, NBP, MAXNL, FIRST + THIS>(rs, epoch, dst, err, lane, nowait,
                                                                              (dbg && FIRST == 0) ? dbg + 2 : nullptr);
@@ -353,12 +400,13 @@ __device__ __forceinline__ bool tk_gather_pieces(__amdgpu_buffer_rsrc_t rs, unsi
 }
 template <int N, int NBP = 0, int MAXNL = 24>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
-                                          int lane, bool nowait = false, unsigned long long* dbg = nullptr) {
+                                          int lane, bool nowait = false, unsigned long long* dbg = nullptr,
+                                          volatile int* flag = nullptr, int seq = 0) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     // all of a piece's loads are in flight at once (a pass is latency-bound: ~1.4 us per 16 loads per lane under load)
-    return tk_gather_pieces<NL, NBP, MAXNL>(rs, epoch, dst, err, lane, nowait, dbg);
+    return tk_gather_pieces<NL, NBP, MAXNL>(rs, epoch, dst, err, lane, nowait, dbg, flag, seq);
 }
 
 // ---- 16-byte granules {v0, v1, v2, tag} for the hb vector (round 3; probes/granule16_probe: a 16-byte sc1 store is never
@@ -1026,6 +1074,9 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
     // hb as {v0, v1, v2, tag} granules: the f32 / f16 kernels (the q4_0 kernel gathers with all eight waves, tk_coop_gather)
+    volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF: gathers issued so far on this CU
+    constexpr bool GF = LLMK_TK_GF && !SH::COOP;
+    if (GF) tk_flag_set(gflag, -1, lane);
     constexpr int GPC_A = (SH::R_A / 2 + 2) / 3;
     constexpr bool HB3 = LLMK_TK_HB3 && !SH::COOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
     const int L = a.L;
@@ -1066,6 +1117,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         const bool coop0 = SH::COOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
         if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane);
         float xn_att = 1.f;
+        if (GF && att_cu) tk_flag_set(gflag, 4 * l + 1, lane);   // no x and no xb gather on this CU: nothing for its bursts to wait for
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
             if (coop0) {
                 ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_q - 1, xraw, xs, tk_rms_att(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
@@ -1073,7 +1125,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
             } else {
-                ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_x<SH>(a), e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr) && ok;
+                if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+                ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_x<SH>(a), e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr, gflag, 4 * l) && ok;
             }
             TK_STAMP(1);
             if (!coop0) xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
@@ -1157,7 +1210,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             if (!att_cu) { tk_xb_delay(); ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok; }
         } else {
             if (!att_cu) tk_xb_delay();
-            if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr) && ok;
+            if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr, gflag, 4 * l + 1) && ok;
         }
         TK_STAMP(7);
         tk_barrier();
@@ -1177,7 +1230,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
         } else {
             nrm.prefetch(tk_rms_ffn(a, l, SH::E), lane);
-            ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_xa<SH>(a), e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr) && ok;
+            if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+            ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_xa<SH>(a), e_o, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 4 : nullptr, gflag, 4 * l + 2) && ok;
             TK_STAMP(9);
             xn_ffn = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
             tk_barrier();
@@ -1203,7 +1257,10 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         else if constexpr (HB3)
             ok = tk_gather3_pieces<TK_NCU * GPC_A / WAVE, GPC_A, SH::R_A / 2, LLMK_TK_HB3_NL>(tk_rsrc(tk_g_hb<SH>(a), TK_NCU * GPC_A * 16), e_a, xs, a.err, lane,
                                                                                              nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
-        else ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
+        else {
+            if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+            ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr, gflag, 4 * l + 3) && ok;
+        }
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
@@ -1228,7 +1285,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     } else {
         TkNorm<SH::E> nrmf;
         nrmf.prefetch(tk_rms_final(a, SH::E), lane);
-        ok = tk_gather<SH::E>(tk_g_x<SH>(a), ebase + 5u * L, xraw, a.err, lane, nosync) && ok;
+        if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+        ok = tk_gather<SH::E>(tk_g_x<SH>(a), ebase + 5u * L, xraw, a.err, lane, nosync, nullptr, gflag, 4 * L) && ok;
         xn_fin = nrmf.template apply<TR_E>(xraw, xs, lane, a.eps);
         tk_barrier();
     }
@@ -1311,7 +1369,7 @@ __device__ __forceinline__ void tk_refill(TkRing<SH>& r, const TokenArgs& a, int
 // (consume), [barrier B], late refills
 template <class SH, int K0, int S, bool CLS, bool WIDE = false>
 __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
-                                         float* part, int lane) {
+                                         float* part, int lane, volatile int* gflag = nullptr, int seq = 0) {
     constexpr int LATE = S < SH::NB ? S : SH::NB, EARLY = S - LATE;
     tk_barrier();
     TkX<SH> x;
@@ -1325,7 +1383,15 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
     tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
     tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
     tk_barrier();
-    tk_refill<SH, K0 + EARLY, LATE, CLS>(r, a, l, c, sw, lane);
+    if constexpr (LLMK_TK_GF && !SH::COOP && !CLS) {
+        // LLMK_TK_GF: a first part of the burst now, the rest once the service wave's next sweep is in the pipeline ahead of it
+        constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
+        tk_refill<SH, K0 + EARLY, NOW, CLS>(r, a, l, c, sw, lane);
+        if (gflag) tk_flag_wait(gflag, seq);
+        tk_refill<SH, K0 + EARLY + NOW, LATE - NOW, CLS>(r, a, l, c, sw, lane);
+    } else {
+        tk_refill<SH, K0 + EARLY, LATE, CLS>(r, a, l, c, sw, lane);
+    }
 }
 
 // COOP: "lagged refill".  Slot K consumes ring entry K % NB and, INSIDE its ALU work, requests tile K + NB - 1 into the
@@ -1440,6 +1506,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
     const int my_head = c / HPC;
 
+    volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF
     TkRing<SH> r;
     tk_prime<SH, 0>(r, a, c, sw, lane);
 
@@ -1461,11 +1528,18 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
                 tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
                 tk_barrier();
             }
-            tk_refill<SH, SC::KQ + EARLY, LATE, false>(r, a, l, c, sw, lane);
+            if constexpr (LLMK_TK_GF && !SH::COOP) {
+                constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
+                tk_refill<SH, SC::KQ + EARLY, NOW, false>(r, a, l, c, sw, lane);
+                tk_flag_wait(gflag, 4 * l + 1);
+                tk_refill<SH, SC::KQ + EARLY + NOW, LATE - NOW, false>(r, a, l, c, sw, lane);
+            } else {
+                tk_refill<SH, SC::KQ + EARLY, LATE, false>(r, a, l, c, sw, lane);
+            }
         }
-        tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
-        tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
-        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);   // w2 slots + padding
+        tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 2);
+        tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 3);
+        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 4);   // w2 slots + padding
     }
     // classifier: the ring index is 0 again (SLP is a multiple of NB); refills run off the stream's end
     tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""VGPRs / SGPRs / scratch of every persistent-kernel instantiation (hipcc -Rpass-analysis=kernel-resource-usage).
-The persistent kernels sit at the register ceiling, so every edit is checked for spills here before it goes to a GPU.
+"""VGPRs / SGPRs / scratch of every persistent-kernel instantiation (hipcc -Rpass-analysis=kernel-resource-usage), and -- when
+a kernel has scratch at all -- how many of its scratch instructions sit INSIDE A LOOP (from the ISA: a spill in the layer
+loop drains the prefetch ring once per ring slot; one in the straight-line classifier tail costs one drain per token).
+The persistent kernels sit at the register ceiling, so every edit is checked here before it goes to a GPU.
     python tests/host_tools/tk_resources.py [-DNAME ...] [--all]"""
 import os
 import re
@@ -13,6 +15,26 @@ r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=
                     "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + defs, cwd=pkg, capture_output=True, text=True)
 if r.returncode:
     sys.exit(r.stderr[-3000:])
+def scratch_in_loops():
+    """kernel symbol -> (scratch instructions inside loops, scratch instructions in all)"""
+    a = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only",
+                        "csrc/llmk.hip", "-o", "-"] + defs, cwd=pkg, capture_output=True, text=True)
+    out, cur, inloop = {}, None, False
+    for line in a.stdout.split("\n"):
+        t = line.strip()
+        if line.startswith("_ZN") and t.endswith(":") is False and ":" in line and not line.startswith(" "):
+            cur = line.split(":")[0]
+            out[cur] = [0, 0]
+            inloop = False
+        elif re.match(r"^\.LBB\d+_\d+:", t):
+            inloop = "Loop" in line
+        elif cur and "scratch_" in t and not t.startswith(";"):
+            out[cur][1] += 1
+            out[cur][0] += 1 if inloop else 0
+    return out
+
+
+loops = None
 for blk in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
     name = blk.split("\n")[0]
     if "--all" not in sys.argv and "token_kernel" not in name and "tk2" not in name:
@@ -24,4 +46,9 @@ for blk in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
     demangled = subprocess.run(["c++filt", name.split()[0]], capture_output=True, text=True).stdout.strip()
     short = demangled.replace("llmk::", "").replace("void ", "")[:88]
     scratch, occ = g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")
-    print(f"{short:88s} VGPR {g(' VGPRs'):>3} AGPR {g('AGPRs'):>3} SGPR {g('SGPRs'):>3} scratch {scratch:>4} occ {occ}")
+    extra = ""
+    if scratch not in ("0", "?"):
+        loops = loops if loops is not None else scratch_in_loops()
+        il, al = loops.get(name.split()[0], [-1, -1])
+        extra = f" scratch_ops_in_loops {il} of {al}"
+    print(f"{short:88s} VGPR {g(' VGPRs'):>3} AGPR {g('AGPRs'):>3} SGPR {g('SGPRs'):>3} scratch {scratch:>4} occ {occ}{extra}")
