@@ -77,9 +77,17 @@
 //   tiles per wave issued at once 1, delay 0: 539 / 727;  delay 16: 531 / 705;  40: 516 / 689-696;  48: 515 / 694;
 //   64: 517 / 701;  96: 567 / 747;  127: 620 / 797;   2 tiles, delay 48-64: 516-526 / 683-687;   3 tiles, 64: 523 / 684;
 //   0 tiles, delay 16: 544 / 735;   per-gather delays (hb 24 / 80, x 16 / 80, xa 16 around a common 48): all within +-1 % or worse.
-// => f16: 1 tile, delay 48; f32: 2 tiles, delay 56.  (-1 = these per-type defaults.)
+//   burst released by the LAST piece's first pass instead of the first piece's (hb is two pieces: with the first piece's pass
+//   the second one queued behind the burst again, 2.1 us instead of 1.0): f16 1 tile 533, 2 tiles 509, 3 tiles delay 36 / 48 /
+//   64: 503-506 / 505-509 / 516, 4 tiles 507; f32 2 / 3 tiles 683 (first piece: 679).
+// => f16: last piece, 3 tiles, delay 36; f32: first piece, 2 tiles, delay 56.  (-1 = these per-type defaults.)
+// The q4_0 kernel has no bursts (its tiles are requested from inside the dots); leaving the LAST slot's request of a phase to
+// the gather that follows, behind its first pass's loads, was measured too: 783 -> 759 tok/s on Llama-2-7B, not kept.
 #ifndef LLMK_TK_GF_NOW
 #define LLMK_TK_GF_NOW -1
+#endif
+#ifndef LLMK_TK_GF_LAST          // which pass releases the burst: the first piece's (0) or the last piece's (1); -1 = per type
+#define LLMK_TK_GF_LAST -1
 #endif
 #ifndef LLMK_TK_GF_DELAY
 #define LLMK_TK_GF_DELAY -1
@@ -208,8 +216,9 @@ struct TkShape {
     static constexpr bool COOP = Q4;
     // "gather first" (LLMK_TK_GF): tiles per wave a phase's refill burst issues before the next sweep is in the pipeline, and
     // s_sleep units the service wave lets the producers have before the first pass of the x / xa / hb sweeps
-    static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : (WT == WT_F16 ? 1 : 2);
-    static constexpr int GF_DELAY = LLMK_TK_GF_DELAY >= 0 ? LLMK_TK_GF_DELAY : (WT == WT_F16 ? 48 : 56);
+    static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : (WT == WT_F16 ? 3 : 2);
+    static constexpr int GF_DELAY = LLMK_TK_GF_DELAY >= 0 ? LLMK_TK_GF_DELAY : (WT == WT_F16 ? 36 : 56);
+    static constexpr bool GF_LAST = LLMK_TK_GF_LAST >= 0 ? LLMK_TK_GF_LAST != 0 : WT == WT_F16;
     static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
     static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
     // rows per CU and tiles per CU for each phase
@@ -384,21 +393,23 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
 // pieces of at most MAXNL loads per lane, one after the other (compile-time recursion): piece k+1 is only polled once piece
 // k has arrived.  Smaller pieces make the passes that FAIL cheaper (a pass costs about as much whether or not its tags match,
 // and the first pass after a phase almost always fails) but add dependent round trips: see LLMK_TK_HB_NL for the sweep.
-template <int NL, int NBP, int MAXNL, int FIRST = 0>
+template <int NL, int NBP, int MAXNL, int FIRST = 0, bool GFLAST = false>
 __device__ __forceinline__ bool tk_gather_pieces(__amdgpu_buffer_rsrc_t rs, unsigned epoch, float* dst, unsigned* err, int lane,
                                                  bool nowait, unsigned long long* dbg, volatile int* flag = nullptr, int seq = 0) {
     constexpr int NP = (NL + MAXNL - 1) / MAXNL;          // pieces still to go
     constexpr int THIS = (NL + NP - 1) / NP;              // as even as possible
-    const bool a = tk_gather_part<THIS, NBP>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg, FIRST == 0 ? flag : nullptr, seq);
+    // LLMK_TK_GF: the burst is released by the first pass of the FIRST piece or (GFLAST) of the LAST piece: the whole sweep leads it
+    constexpr bool MINE = GFLAST ? (NL <= THIS) : (FIRST == 0);
+    const bool a = tk_gather_part<THIS, NBP>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg, MINE ? flag : nullptr, seq);
     if constexpr (NL > THIS) {
-        const bool b = tk_gather_pieces<NL - THIS, NBP, MAXNL, FIRST + THIS>(rs, epoch, dst, err, lane, nowait,
-                                                                             (dbg && FIRST == 0) ? dbg + 2 : nullptr);
+        const bool b = tk_gather_pieces<NL - THIS, NBP, MAXNL, FIRST + THIS, GFLAST>(rs, epoch, dst, err, lane, nowait,
+                                                                                     (dbg && FIRST == 0) ? dbg + 2 : nullptr, flag, seq);
         return a && b;
     } else {
         return a;
     }
 }
-template <int N, int NBP = 0, int MAXNL = 24>
+template <int N, int NBP = 0, int MAXNL = 24, bool GFLAST = false>
 __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned epoch, float* dst, unsigned* err,
                                           int lane, bool nowait = false, unsigned long long* dbg = nullptr,
                                           volatile int* flag = nullptr, int seq = 0) {
@@ -406,7 +417,7 @@ __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned 
     constexpr int NL = N / 128;   // 16-byte loads per lane
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     // all of a piece's loads are in flight at once (a pass is latency-bound: ~1.4 us per 16 loads per lane under load)
-    return tk_gather_pieces<NL, NBP, MAXNL>(rs, epoch, dst, err, lane, nowait, dbg, flag, seq);
+    return tk_gather_pieces<NL, NBP, MAXNL, 0, GFLAST>(rs, epoch, dst, err, lane, nowait, dbg, flag, seq);
 }
 
 // ---- 16-byte granules {v0, v1, v2, tag} for the hb vector (round 3; probes/granule16_probe: a 16-byte sc1 store is never
@@ -1259,7 +1270,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                                                                                              nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         else {
             if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
-            ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr, gflag, 4 * l + 3) && ok;
+            ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL, SH::GF_LAST>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr, gflag, 4 * l + 3) && ok;
         }
         TK_STAMP(12);
         tk_barrier();
