@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -85,6 +86,18 @@
 // the gather that follows, behind its first pass's loads, was measured too: 783 -> 759 tok/s on Llama-2-7B, not kept.
 #ifndef LLMK_TK_GF_NOW
 #define LLMK_TK_GF_NOW -1
+#endif
+// f16 kernel: ALL eight waves gather (an eighth of the vector each, like the q4_0 kernel), every streaming wave ordering its
+// own loads: sweep slice first, then its first tiles, the rest of its burst after the slice has arrived (or failed once)
+// MEASURED AND LEFT OFF (round 3, profiles/r03_gather_first_sweep.jsonl run "gc"; parity green with it on): 509 -> 565 us.  Seven
+// more gather slices, their gains and the refill descriptors inside the sweep take the f16 kernel from 214 to 256 VGPRs with
+// scratch traffic inside the layer loop; the service wave alone, with the bursts ordered behind its sweep (LLMK_TK_GF), wins.
+#ifndef LLMK_TK_F16_COOP
+#define LLMK_TK_F16_COOP 0
+#endif
+// 1: even the first tiles of a burst wait until the service wave has ISSUED the phase's publish stores (second LDS word)
+#ifndef LLMK_TK_GF_PUB
+#define LLMK_TK_GF_PUB 0
 #endif
 #ifndef LLMK_TK_GF_LAST          // which pass releases the burst: the first piece's (0) or the last piece's (1); -1 = per type
 #define LLMK_TK_GF_LAST -1
@@ -214,6 +227,9 @@ struct TkShape {
     // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills
     // that the next phase does not need until its input vector has been gathered (1,675).
     static constexpr bool COOP = Q4;
+    // GCOOP: gathers by all eight waves.  q4_0 (with the lagged refill, COOP) and, round 3, f16 (with bursts ordered behind
+    // each wave's own sweep slice: tk_stream_gc) -- the f32 kernel has no registers left for a slice per streaming wave
+    static constexpr bool GCOOP = Q4 || (WT == WT_F16 && LLMK_TK_F16_COOP);
     // "gather first" (LLMK_TK_GF): tiles per wave a phase's refill burst issues before the next sweep is in the pipeline, and
     // s_sleep units the service wave lets the producers have before the first pass of the x / xa / hb sweeps
     static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : (WT == WT_F16 ? 3 : 2);
@@ -1086,10 +1102,11 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
     // hb as {v0, v1, v2, tag} granules: the f32 / f16 kernels (the q4_0 kernel gathers with all eight waves, tk_coop_gather)
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF: gathers issued so far on this CU
-    constexpr bool GF = LLMK_TK_GF && !SH::COOP;
-    if (GF) tk_flag_set(gflag, -1, lane);
+    constexpr bool GF = LLMK_TK_GF && !SH::GCOOP;
+    constexpr bool GCD = SH::GCOOP && !SH::COOP && SH::GF_DELAY > 0;     // f16 coop: the same head start for the producers
+    if (GF) { tk_flag_set(gflag, -1, lane); tk_flag_set(gflag + 1, -1, lane); }
     constexpr int GPC_A = (SH::R_A / 2 + 2) / 3;
-    constexpr bool HB3 = LLMK_TK_HB3 && !SH::COOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
+    constexpr bool HB3 = LLMK_TK_HB3 && !SH::GCOOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
     const int L = a.L;
     const int tok = tk_token<GR>(a, c, lane);
     const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
@@ -1125,12 +1142,13 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
         TkNorm<SH::E> nrm;
-        const bool coop0 = SH::COOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
+        const bool coop0 = SH::GCOOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
         if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane);
         float xn_att = 1.f;
-        if (GF && att_cu) tk_flag_set(gflag, 4 * l + 1, lane);   // no x and no xb gather on this CU: nothing for its bursts to wait for
+        if (GF && att_cu) { tk_flag_set(gflag, 4 * l + 1, lane); if (LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 1, lane); }   // no x and no xb gather on this CU: nothing for its bursts to wait for
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
             if (coop0) {
+                if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
                 ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_q - 1, xraw, xs, tk_rms_att(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             } else if (l == 0) {
 #pragma unroll 8
@@ -1166,6 +1184,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
             tk_publish(a.g_qkv + r, e_q, outv);
         }
+        if (GF && LLMK_TK_GF_PUB && !att_cu) tk_flag_set(gflag + 1, 4 * l + 1, lane);
         TK_STAMP(4);
         // ---- P1: attention, one CU per head                                     llama2.f90:572-598
         if (att_cu) {
@@ -1217,7 +1236,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        if constexpr (SH::COOP) {
+        if constexpr (SH::GCOOP) {
             if (!att_cu) { tk_xb_delay(); ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok; }
         } else {
             if (!att_cu) tk_xb_delay();
@@ -1232,9 +1251,11 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = a.o0 + lane;
             tk_publish(tk_g_xa<SH>(a) + r, e_o, xraw[r] + v);
         }
+        if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 2, lane);
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
-        if constexpr (SH::COOP) {
+        if constexpr (SH::GCOOP) {
+            if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
             ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             TK_STAMP(9);
             tk_barrier();
@@ -1263,8 +1284,12 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const float v0 = __shfl(hbv, 3 * lane, WAVE), v1 = __shfl(hbv, 3 * lane + 1, WAVE), v2 = __shfl(hbv, 3 * lane + 2, WAVE);
             if (lane < GPC_A) tk_publish3(tk_g_hb<SH>(a), c * GPC_A + lane, e_a, v0, 3 * lane + 1 < SH::R_A / 2 ? v1 : 0.f, 3 * lane + 2 < SH::R_A / 2 ? v2 : 0.f);
         }
+        if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        if constexpr (SH::COOP) ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+        if constexpr (SH::GCOOP) {
+            if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+            ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+        }
         else if constexpr (HB3)
             ok = tk_gather3_pieces<TK_NCU * GPC_A / WAVE, GPC_A, SH::R_A / 2, LLMK_TK_HB3_NL>(tk_rsrc(tk_g_hb<SH>(a), TK_NCU * GPC_A * 16), e_a, xs, a.err, lane,
                                                                                              nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
@@ -1284,12 +1309,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = c * SH::R_D + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
+        if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
         TK_STAMP(15);
     }
 #undef TK_STAMP
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     float xn_fin;
-    if constexpr (SH::COOP) {
+    if constexpr (SH::GCOOP) {
+        if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
         ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
         tk_barrier();
         xn_fin = tk_coop_xn<SH::E>(red8, a.eps);
@@ -1394,9 +1421,10 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
     tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
     tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
     tk_barrier();
-    if constexpr (LLMK_TK_GF && !SH::COOP && !CLS) {
+    if constexpr (LLMK_TK_GF && !SH::GCOOP && !CLS) {
         // LLMK_TK_GF: a first part of the burst now, the rest once the service wave's next sweep is in the pipeline ahead of it
         constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
+        if (LLMK_TK_GF_PUB && gflag) tk_flag_wait(gflag + 1, seq);
         tk_refill<SH, K0 + EARLY, NOW, CLS>(r, a, l, c, sw, lane);
         if (gflag) tk_flag_wait(gflag, seq);
         tk_refill<SH, K0 + EARLY + NOW, LATE - NOW, CLS>(r, a, l, c, sw, lane);
@@ -1539,8 +1567,9 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
                 tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
                 tk_barrier();
             }
-            if constexpr (LLMK_TK_GF && !SH::COOP) {
+            if constexpr (LLMK_TK_GF && !SH::GCOOP) {
                 constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
+                if (LLMK_TK_GF_PUB) tk_flag_wait(gflag + 1, 4 * l + 1);
                 tk_refill<SH, SC::KQ + EARLY, NOW, false>(r, a, l, c, sw, lane);
                 tk_flag_wait(gflag, 4 * l + 1);
                 tk_refill<SH, SC::KQ + EARLY + NOW, LATE - NOW, false>(r, a, l, c, sw, lane);
@@ -1606,6 +1635,156 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
     tk_phase_body<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
+
+// ---- f16: streaming waves that gather (GCOOP without the q4_0 lagged refill) ------------------------------------------------
+// One wave's slice of a gather with the loads ORDERED: the first pass's loads, then `after_first()` (the wave's first refill
+// tiles -- straight-line code, so hipcc checks the tags with s_waitcnt vmcnt(<those tiles>), not vmcnt(0)), then the tags.
+// If the first pass fails, `on_fail()` (the rest of the burst: HBM must not idle while e.g. attention runs) and the ordinary
+// polling loop.  Returns true if on_fail ran.
+template <int NLW, int NBP, bool NORM, class F1, class F2>
+__device__ __forceinline__ bool tk_gc_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
+                                           const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait, F1 after_first,
+                                           F2 on_fail) {
+    if constexpr (NLW == 0) { after_first(); return false; }
+    else {
+        float2 gn[NORM ? NLW : 1];
+        if constexpr (NORM) {
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) gn[k] = *reinterpret_cast<const float2*>(gains + 2 * (first_pair + lane + k * WAVE));
+        }
+        const int e0 = 2 * (first_pair + lane);
+        const int d0 = tk_xoff<NBP>(e0);
+        auto pass = [&](auto first) -> bool {
+            tk_v4u r[NLW];
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);
+            if constexpr (decltype(first)::value) after_first();
+            bool ok = true;
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
+            if (!(__all(ok) || nowait)) return false;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < NLW; ++k) {
+                const float x0 = __uint_as_float(r[k].x), x1 = __uint_as_float(r[k].z);
+                if (xraw) *reinterpret_cast<float2*>(xraw + e0 + k * 2 * WAVE) = make_float2(x0, x1);
+                if constexpr (NORM) {
+                    acc = fmaf(x0, x0, acc);
+                    acc = fmaf(x1, x1, acc);
+                    *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0 * gn[k].x, x1 * gn[k].y);
+                } else {
+                    *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0, x1);
+                }
+            }
+            if constexpr (NORM) *ss += acc;
+            return true;
+        };
+        if (pass(std::true_type())) return false;
+        on_fail();
+        for (unsigned spin = 1;; ++spin) {
+            if ((spin & 63) == 63) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+                if (spin > TK_SPIN_LIMIT) {
+                    if (lane == 0) __hip_atomic_store(err, 0x600u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return true;
+                }
+            }
+            __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
+            if (pass(std::false_type())) return true;
+        }
+    }
+}
+// streaming wave sw's slice of vector g (N granules), ring slots K .. K+LATE-1 of the phase just finished to refill around it
+template <class SH, int N, bool NORM, int K, int LATE, bool CLS>
+__device__ __forceinline__ void tk_gc_gather(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const unsigned long long* g, unsigned epoch,
+                                             float* xraw, float* xs, const float* gains, float* red8, int lane, bool nowait) {
+    static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
+    constexpr int NL = N / 128, B = NL / TK_WAVES, X = NL % TK_WAVES;
+    constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
+    const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
+    float ss = 0.f;
+    auto first = [&]() { tk_refill<SH, K, NOW, CLS>(r, a, l, c, sw, lane); };
+    auto rest = [&]() { tk_refill<SH, K + NOW, LATE - NOW, CLS>(r, a, l, c, sw, lane); };
+    bool rest_done;
+    if (sw < X) rest_done = tk_gc_part<B + 1, 0, NORM>(rs, sw * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, a.err, lane, nowait, first, rest);
+    else rest_done = tk_gc_part<B, 0, NORM>(rs, (X * (B + 1) + (sw - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, a.err, lane, nowait, first, rest);
+    if (!rest_done) rest();
+    if constexpr (NORM) {
+        ss = wave_sum(ss);
+        if (lane == 0) red8[sw] = ss;
+    }
+}
+// barrier A, x fragment, the phase's slots, barrier B -- WITHOUT the late refills (tk_gc_gather orders them)
+template <class SH, int K0, int S, bool WIDE = false>
+__device__ __forceinline__ void tk_gc_phase(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4, float* part, int lane) {
+    constexpr int LATE = S < SH::NB ? S : SH::NB, EARLY = S - LATE;
+    tk_barrier();
+    TkX<SH> x;
+    if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
+    else x.load(xs4, 0, SH::LPR_E, lane);
+    tk_run<SH, K0, EARLY, false>(r, a, l, c, sw, x, part, lane);
+    tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
+    tk_barrier();
+}
+template <class SH>
+__device__ __forceinline__ void tk_stream_gc(const TokenArgs& a, char* lds, int c, int sw, int lane, int tid) {
+    typedef TkLds<SH> LD;
+    typedef TkSched<SH> SC;
+    static_assert(!SH::Q4, "natural-order staging");
+    float* xs = reinterpret_cast<float*>(lds + LD::XS);
+    float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
+    const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
+    float* part = reinterpret_cast<float*>(lds + LD::PART);
+    float* red8 = reinterpret_cast<float*>(lds + LD::RED8);
+    const int L = a.L;
+    const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
+    const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
+    const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
+    constexpr int HPC = TK_NCU / SH::NH;
+    const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
+    const int my_head = c / HPC;
+    constexpr int LQ = SH::SL_Q < SH::NB ? SH::SL_Q : SH::NB, LO = SH::SL_O < SH::NB ? SH::SL_O : SH::NB,
+                  LA = SH::SL_A < SH::NB ? SH::SL_A : SH::NB, SD = SC::SLP - SC::KD, LDD = SD < SH::NB ? SD : SH::NB;
+    constexpr int D = SH::GF_DELAY;
+
+    TkRing<SH> r;
+    tk_prime<SH, 0>(r, a, c, sw, lane);
+    for (int l = 0; l < L; ++l) {
+        const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
+        tk_gc_phase<SH, SC::KQ, SH::SL_Q>(r, a, l, c, sw, xs4, part, lane);
+        if (att_cu) {
+            TkAtt<SH> pa;
+            pa.prefetch(a, l, my_head, pos, tid);
+            tk_barrier();
+            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
+            tk_barrier();
+            tk_refill<SH, SC::KQ + SH::SL_Q - LQ, LQ, false>(r, a, l, c, sw, lane);
+        } else {
+            tk_xb_delay();
+            tk_gc_gather<SH, SH::E, false, SC::KQ + SH::SL_Q - LQ, LQ, false>(r, a, l, c, sw, tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, lane, nosync);
+        }
+        tk_gc_phase<SH, SC::KO, SH::SL_O>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
+        tk_gc_gather<SH, SH::E, true, SC::KO + SH::SL_O - LO, LO, false>(r, a, l, c, sw, tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, lane, nosync);
+        tk_gc_phase<SH, SC::KA, SH::SL_A>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
+        tk_gc_gather<SH, SH::H, false, SC::KA + SH::SL_A - LA, LA, false>(r, a, l, c, sw, tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, lane, nosync);
+        tk_gc_phase<SH, SC::KD, SD, true>(r, a, l, c, sw, xs4, part, lane);
+        if (l + 1 < L) {
+            if (!att_cu) {
+                if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
+                tk_gc_gather<SH, SH::E, true, SC::KD + SD - LDD, LDD, false>(r, a, l, c, sw, tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, lane, nosync);
+            } else {
+                tk_refill<SH, SC::KD + SD - LDD, LDD, false>(r, a, l, c, sw, lane);
+            }
+        } else {
+            if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
+            tk_gc_gather<SH, SH::E, true, SC::KD + SD - LDD, LDD, false>(r, a, l, c, sw, tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_final(a, SH::E), red8, lane, nosync);
+        }
+    }
+    tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
+}
+
 template <class SH, bool GR = false>
 __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1628,6 +1807,7 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
     else if constexpr (SH::COOP) tk_stream_coop<SH>(a, lds, c, wid, lane, tid);
+    else if constexpr (SH::GCOOP) tk_stream_gc<SH>(a, lds, c, wid, lane, tid);
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }
 
