@@ -376,6 +376,7 @@ def main():
                                     + (", ALL RANKS SHARING ONE GPU: protocol check, not a scaling number" if os.environ.get("LLMK_SHARE_GPU") else "") + ")")
                                    if a.tp else "replicas" if world > 1 else "single GPU"), "seed": SEED,
                    "path": m.path_name()},
+        "ranks_seen": m.tp_ranks_seen(),   # from the collective itself (ncclCommCount / mapped peer inboxes): 1 for replicas
     }
     if rank == 0:
         # Dominant kernel.  Default path for this shape: ONE persistent kernel per token (token_kernel.h):

@@ -224,6 +224,9 @@ int llmk_peek(llmk_ctx *ctx, int which, int layer, int pos, float *out, int n);
 #define LLMK_PATH_TP_RCCL 3          /* tensor-parallel rank: eager launches + ncclAllReduce / ncclAllGather         */
 #define LLMK_PATH_TP_UNCONNECTED 4   /* tensor-parallel rank without collectives yet (llmk_tp_segment stepping only) */
 int llmk_path(llmk_ctx *ctx);
+/* How many ranks this ctx's collective actually spans: ncclCommCount of its RCCL communicator, or the number of mapped
+ * peer inboxes (+ itself) on the peer-memory path, or 1.  For the benchmark line of a multi-GPU run (`ranks_seen`). */
+int llmk_tp_ranks_seen(llmk_ctx *ctx);
 
 int llmk_destroy(llmk_ctx *ctx);
 

@@ -1638,6 +1638,21 @@ int llmk_path(llmk_ctx* c) {
     return c->use_tk ? LLMK_PATH_TOKEN_KERNEL : LLMK_PATH_MULTI_KERNEL;
 }
 
+int llmk_tp_ranks_seen(llmk_ctx* c) {
+    if (!c) return -LLMK_E_ARG;
+    if (c->comm) {
+        int n = 0;
+        if (ncclCommCount(c->comm, &n) != ncclSuccess) return -LLMK_E_COMM;
+        return n;                       // what the RCCL communicator itself says
+    }
+    if (c->p2p) {                       // peers whose inboxes are mapped here (+ this rank)
+        int n = 0;
+        for (int r = 0; r < c->tp_size; ++r) n += c->peers.inbox[r] != nullptr;
+        return n;
+    }
+    return 1;
+}
+
 int llmk_destroy(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     hipSetDevice(c->cfg.device);

@@ -217,7 +217,10 @@ struct TkShape {
 #ifndef LLMK_NB_Q4
 #define LLMK_NB_Q4 3
 #endif
-    static constexpr int NB = Q4 ? LLMK_NB_Q4 : (WT == WT_F16 ? 4 : 5);
+#ifndef LLMK_NB_F16
+#define LLMK_NB_F16 4
+#endif
+    static constexpr int NB = Q4 ? LLMK_NB_Q4 : (WT == WT_F16 ? LLMK_NB_F16 : 5);
     // COOP (q4_0): all eight waves gather the phase's input vector, one eighth each, and the tiles are requested from
     // inside the dot products (tk_step).  The dequantise-and-dot of a q4_0 tile takes 1.9 us, so the loads' issue hides
     // behind ALU work instead of behind the exchange, and a wave that polls right after its phase has almost nothing of

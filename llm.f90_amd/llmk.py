@@ -25,7 +25,7 @@ SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_c
            "llmk_tp_p2p_connect_local", "llmk_tp_p2p_selftest", "llmk_tp_p2p_disable", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
            "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_decode_greedy", "llmk_reset", "llmk_timings",
-           "llmk_time_kernel", "llmk_peek", "llmk_path", "llmk_destroy", "llmk_strerror", "llmk_version"]
+           "llmk_time_kernel", "llmk_peek", "llmk_path", "llmk_tp_ranks_seen", "llmk_destroy", "llmk_strerror", "llmk_version"]
 PATH_NAMES = {0: "multi-kernel (5 launches per layer)", 1: "persistent whole-token kernel",
               2: "tensor-parallel rank: 6 launches per layer + one-shot peer-memory exchanges",
               3: "tensor-parallel rank: eager launches + RCCL collectives", 4: "tensor-parallel rank, collectives not connected"}
@@ -90,6 +90,7 @@ def lib():
         L.llmk_peek.argtypes = [vp, ci, ci, ci, cf, ci]
         L.llmk_destroy.argtypes = [vp]
         L.llmk_path.argtypes = [vp]
+        L.llmk_tp_ranks_seen.argtypes = [vp]
         L.llmk_strerror.argtypes = [ci]
         L.llmk_strerror.restype = C.c_char_p
         L.llmk_version.argtypes = []
@@ -283,6 +284,9 @@ class Llmk:
 
     def path(self) -> int:
         return lib().llmk_path(self._h)
+
+    def tp_ranks_seen(self) -> int:
+        return lib().llmk_tp_ranks_seen(self._h)
 
     def path_name(self) -> str:
         return PATH_NAMES.get(self.path(), "?")
