@@ -95,6 +95,13 @@
 #ifndef LLMK_TK_F16_COOP
 #define LLMK_TK_F16_COOP 0
 #endif
+// q4_0 kernel: s_sleep units every wave lets the producers have before the first pass of its x / xa / hb slice: the two
+// tiles each wave still has in flight drain meanwhile and the pass, now likely to succeed, finds a short queue.
+// Round 3 (profiles/r03_gather_first_sweep.jsonl run "cd", Llama-2-7B q4_0 kernel us): 0: 1,316-1,320; 12 / 24 / 40: 1,236-1,239;
+// 56: 1,252; 80: 1,298; 110: 1,373.  790 -> 843 tok/s.
+#ifndef LLMK_TK_COOP_DELAY
+#define LLMK_TK_COOP_DELAY 24
+#endif
 // 1: even the first tiles of a burst wait until the service wave has ISSUED the phase's publish stores (second LDS word)
 #ifndef LLMK_TK_GF_PUB
 #define LLMK_TK_GF_PUB 0
@@ -1106,7 +1113,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // hb as {v0, v1, v2, tag} granules: the f32 / f16 kernels (the q4_0 kernel gathers with all eight waves, tk_coop_gather)
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF: gathers issued so far on this CU
     constexpr bool GF = LLMK_TK_GF && !SH::GCOOP;
-    constexpr bool GCD = SH::GCOOP && !SH::COOP && SH::GF_DELAY > 0;     // f16 coop: the same head start for the producers
+    constexpr bool GCD = (SH::GCOOP && !SH::COOP && SH::GF_DELAY > 0) || (SH::COOP && LLMK_TK_COOP_DELAY > 0);   // coop: the same head start for the producers
+    constexpr int GCDN = SH::COOP ? LLMK_TK_COOP_DELAY : SH::GF_DELAY;
     if (GF) { tk_flag_set(gflag, -1, lane); tk_flag_set(gflag + 1, -1, lane); }
     constexpr int GPC_A = (SH::R_A / 2 + 2) / 3;
     constexpr bool HB3 = LLMK_TK_HB3 && !SH::GCOOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
@@ -1151,7 +1159,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (GF && att_cu) { tk_flag_set(gflag, 4 * l + 1, lane); if (LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 1, lane); }   // no x and no xb gather on this CU: nothing for its bursts to wait for
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
             if (coop0) {
-                if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+                if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
                 ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_q - 1, xraw, xs, tk_rms_att(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             } else if (l == 0) {
 #pragma unroll 8
@@ -1258,7 +1266,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
         if constexpr (SH::GCOOP) {
-            if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+            if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
             ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             TK_STAMP(9);
             tk_barrier();
@@ -1290,7 +1298,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
         if constexpr (SH::GCOOP) {
-            if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+            if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
             ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         }
         else if constexpr (HB3)
@@ -1319,7 +1327,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     float xn_fin;
     if constexpr (SH::GCOOP) {
-        if constexpr (GCD) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
+        if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
         ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
         tk_barrier();
         xn_fin = tk_coop_xn<SH::E>(red8, a.eps);
@@ -1625,10 +1633,13 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
         }
         if (!att_cu) { tk_xb_delay(); tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync); }
         tk_phase_body<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         if (l + 1 < L) {
             if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, a.err, sw, lane, nosync);
         } else {
