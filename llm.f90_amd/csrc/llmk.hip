@@ -94,7 +94,7 @@ struct llmk_ctx {
     bool tk_short_grid = false;   // libllmk_debug.so only (LLMK_TK_INJECT_TIMEOUT)
     bool tk_retired = false;   // the token kernel timed out once on this ctx: it stays on the multi-kernel path
     int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape, 5 Llama-2-7B q4_0
-    unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x
+    unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x | attention parts
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
     size_t tk_lds = 0;
@@ -381,7 +381,8 @@ int tk_setup(llmk_ctx* c, int id) {
     int per_cu = 0;
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, token_kernel<TK>, TK_THREADS, c->tk_lds));
     if (per_cu < 1 || (long long)per_cu * c->n_cu < TK_NCU) return LLMK_OK;
-    const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H;
+    // qkv | xb | xa | hb | x | per head: the (PMAX - 1) other parts of a long context's attention (HS values + maximum + sum each)
+    const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H + (size_t)TK::NH * (TkAttPlan<TK>::PMAX - 1) * (TK::HS + 2);
     HIPCHK(hipMalloc(&c->d_gran, ngran * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
     if (TK_DEBUG && getenv("LLMK_TK_TRACE")) HIPCHK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));   // libllmk_debug.so only

@@ -114,6 +114,9 @@
 #endif
 // s_sleep units a non-attention CU lets pass before its FIRST poll of xb (it polls 7 times on average while attention runs:
 // 16 KB of fabric reads per CU and pass).  Measured round 3: 0 ... -1.5 % for 32 / 64 / 100 / 150 units: left at 0.
+#ifndef LLMK_TK_ATT_SPLIT
+#define LLMK_TK_ATT_SPLIT 1          // contexts longer than 256 timesteps: a head's attention in parts on the CUs of its group (TkAttPlan)
+#endif
 #ifndef LLMK_TK_XB_DELAY
 #define LLMK_TK_XB_DELAY 0
 #endif
@@ -949,19 +952,56 @@ struct TkAtt {
     // (The 64 registers are the two ring entries the QKV phase has just consumed and not yet refilled; an attention
     // CU streams no QKV / wo tiles, so nothing else of its own is queued ahead of the q poll.)
     // Only contexts longer than TILE pay exposed round trips.
-    __device__ __forceinline__ void prefetch(const TokenArgs& a, int l, int h, int pos, int tid) {
+    __device__ __forceinline__ void prefetch(const TokenArgs& a, int l, int h, int pos, int tid, int t0 = 0) {
         const int lane = tid & 63, wid = tid >> 6;
         const int g = h / SH::KVMUL, sub = lane % LPT, tl = lane / LPT;
         const __amdgpu_buffer_rsrc_t rk = tk_rsrc(a.kc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
         const __amdgpu_buffer_rsrc_t rv = tk_rsrc(a.vc + (size_t)l * a.S * SH::KV, a.S * SH::KV * 4);
         const int col = (g * HS + sub * 4) * 4;
-        const int tb = wid * TPW + tl, tmax = max(pos - 2, 0);
+        const int tb = t0 + wid * TPW + tl, tmax = max(pos - 2, 0);
 #pragma unroll
         for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rk, min(u * TPB + tb, tmax) * (SH::KV * 4) + col);
 #pragma unroll
         for (int u = 0; u < U; ++u) vv[u] = tk_ldkv(rv, min(u * TPB + tb, tmax) * (SH::KV * 4) + col);
     }
 };
+
+// Long contexts: a head's timesteps in up to HPC = TK_NCU / NH parts, part 0 on the head's attention CU and part p on the
+// p-th other CU of the head's group of HPC (an ordinary row-owning CU, idle during the attention hop anyway).  One part per
+// TILE (256) timesteps, so a part's K/V rows are all requested before q arrives, as at short contexts; contexts of <= TILE
+// timesteps are one part: nothing changes for them.  Each part is a complete softmax over its own timesteps (its own
+// maximum and sum); the head's CU merges them (tk_service).  Part p covers [t0, t1) of the pos timesteps.
+template <class SH>
+struct TkAttPlan {
+    static constexpr int HPC = TK_NCU / SH::NH, TILE = TkAtt<SH>::TILE, TPB = TkAtt<SH>::TPB;
+    static constexpr int PMAX = HPC < 8 ? HPC : 8;       // parts per head at most
+    int P, chunk;
+    __device__ __forceinline__ TkAttPlan(int pos) {
+        P = min(PMAX, (pos + TILE - 1) / TILE);
+        if (LLMK_TK_ATT_SPLIT == 0 || (SH::GCOOP && !SH::COOP) || P < 1) P = 1;   // (tk_stream_gc, an experiment left off, knows no parts)
+        chunk = (((pos + P - 1) / P) + TPB - 1) / TPB * TPB;
+        while (P > 1 && (P - 1) * chunk >= pos) --P;          // (cannot happen for pos > TILE * (P - 1); kept as a guard)
+    }
+    __device__ __forceinline__ int t0(int p) const { return p * chunk; }
+    __device__ __forceinline__ int t1(int p, int pos) const { return min((p + 1) * chunk, pos); }
+};
+// this CU's part of its head's timesteps: false = none (recomputed per layer by the streaming waves rather than kept in
+// scalar registers across the layer loop: the kernels sit at the register ceiling)
+template <class SH>
+__device__ __forceinline__ bool tk_att_role(int c, int pos, int& t0, int& t1) {
+    constexpr int HPC = TK_NCU / SH::NH;
+    const int apart = ((c % HPC) - ((c / HPC / SH::KVMUL) % HPC) + HPC) % HPC;
+    if (pos <= TkAtt<SH>::TILE || LLMK_TK_ATT_SPLIT == 0) { t0 = 0; t1 = pos; return apart == 0; }
+    const TkAttPlan<SH> plan(pos);
+    t0 = plan.t0(apart);
+    t1 = plan.t1(apart, pos);
+    return apart < plan.P;
+}
+// granules of part p >= 1 of head h: HS output dims, then the part's maximum and sum
+template <class SH>
+__device__ __forceinline__ unsigned long long* tk_g_part(const TokenArgs& a, int h, int p) {
+    return tk_g_x<SH>(a) + SH::E + ((size_t)h * (TkAttPlan<SH>::PMAX - 1) + (p - 1)) * (SH::HS + 2);
+}
 
 // sum over the 16 lanes of a DPP row (= the HS/4 lanes that share a timestep); valid in lane 15 of the row
 __device__ __forceinline__ float row16_sum(float v) {
@@ -982,7 +1022,9 @@ __device__ __forceinline__ float tstep_sum(float v) {
 
 template <class SH>
 __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int l, int h, int pos, int tid, TkAtt<SH>& pa,
-                                             unsigned long long* dbg = nullptr) {
+                                             unsigned long long* dbg = nullptr, int t0 = 0, int t1 = -1, float* m_out = nullptr,
+                                             float* s_out = nullptr) {
+    if (t1 < 0) t1 = pos;           // timesteps [t0, t1) of the pos in all (TkAttPlan); t1 == pos includes this token's own
     constexpr int HS = SH::HS, LPT = HS / 4, TPW = 64 / LPT, TPB = TK_WAVES * TPW, U = TkAtt<SH>::U, TILE = TPB * U;
     static_assert(LPT == 16 || LPT == 32, "a timestep is one or two DPP rows");
     float4 (&kv)[U] = pa.kv;
@@ -1004,25 +1046,26 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     const int tb = wid * TPW + tl;
     const int npast = pos - 1;  // rows 0..pos-2 live in the cache; row pos-1 is this token's (LDS)
     const int tmax = max(npast - 1, 0);
+    const int tcache = min(npast, t1);
 
     float* ex = att + a.S;                                                      // exp(score - max), written per wave
     float* pw = reinterpret_cast<float*>(lds + TkLds<SH>::ATT_P) + wid * 32;    // this wave's U*TPW (<= 32) weights of a batch
-    for (int base = 0; base < pos; base += TILE) {
-        if (base > 0) {
+    for (int base = t0; base < t1; base += TILE) {
+        if (base > t0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) kv[u] = tk_ldkv(rk, min(base + u * TPB + tb, tmax) * rowb + col);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (base + u * TPB < pos) {   // block-uniform: short contexts skip the empty batches
+            if (base + u * TPB < t1) {   // block-uniform: short contexts skip the empty batches
                 const int t = base + u * TPB + tb;
                 // rows >= pos-1 read a clamped (wrong) row: t = pos-1 is redone from LDS below, later ones are never used
                 const float d = tstep_sum<LPT>(dot4(qv, kv[u], 0.f));
-                if (sub == LPT - 1 && t < npast) att[t] = d / scale;               // :582
+                if (sub == LPT - 1 && t < tcache) att[t] = d / scale;              // :582
             }
         }
     }
-    {   // this token's own key never went through the cache
+    if (t1 == pos) {   // this token's own key never went through the cache
         const float d = tstep_sum<LPT>(dot4(qv, kcur[sub], 0.f));
         if (wid == 0 && lane == LPT - 1) att[npast] = d / scale;
     }
@@ -1032,32 +1075,33 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
     // every wave folds max and sum over ALL scores itself: no cross-wave reduction, no extra barriers.  exp() is
     // evaluated once per score here (each wave keeps its own copy of what it wrote: same values, benign overlap)
     float m = -INFINITY;
-    for (int t = lane; t < pos; t += WAVE) m = fmaxf(m, att[t]);
+    for (int t = t0 + lane; t < t1; t += WAVE) m = fmaxf(m, att[t]);
     m = wave_max(m);
     if (TK_DEBUG && dbg) dbg[3] = wall_clock64();
     float s = 0.f;
-    for (int t = lane; t < pos; t += WAVE) {
+    for (int t = t0 + lane; t < t1; t += WAVE) {
         const float e = expf(att[t] - m);
         ex[t] = e;
         s += e;
     }
     s = wave_sum(s);
+    if (m_out) { *m_out = m; *s_out = s; }
     if (TK_DEBUG && dbg) dbg[4] = wall_clock64();
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = 0; base < pos; base += TILE) {
-        if (base > 0) {
+    for (int base = t0; base < t1; base += TILE) {
+        if (base > t0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) vv[u] = tk_ldkv(rv, min(base + u * TPB + tb, tmax) * rowb + col);
         }
         // xi/sum(xi) (:476) once per timestep: lane i < U*TPW owns timestep (u = i / TPW, tl = i % TPW) of this wave
         if (lane < U * TPW) {
             const int t = base + (lane / TPW) * TPB + wid * TPW + (lane % TPW);
-            pw[lane] = (t < pos) ? ex[t] / s : 0.f;
+            pw[lane] = (t < t1) ? ex[t] / s : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (base + u * TPB < pos) {
+            if (base + u * TPB < t1) {
                 const int t = base + u * TPB + tb;
                 const float4 v4 = (t == npast) ? vcur[sub] : vv[u];
                 const float p = pw[u * TPW + tl];
@@ -1198,11 +1242,16 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (GF && LLMK_TK_GF_PUB && !att_cu) tk_flag_set(gflag + 1, 4 * l + 1, lane);
         TK_STAMP(4);
         // ---- P1: attention, one CU per head                                     llama2.f90:572-598
-        if (att_cu) {
+        // long contexts: this CU's part of its head's timesteps (TkAttPlan; part 0 = the attention CU, one part at <= 256
+        // timesteps).  Recomputed per layer, as in the streaming waves: nothing of it lives across the layer loop.
+        int at0, at1;
+        if (tk_att_role<SH>(c, pos, at0, at1)) {
+            const TkAttPlan<SH> plan(pos);
+            const int apart = ((c % HPC) - ((c / HPC / SH::KVMUL) % HPC) + HPC) % HPC;
             float* qs = reinterpret_cast<float*>(lds + LD::ATT_Q);
             const int g = my_head / SH::KVMUL;
             TkAtt<SH> pa;
-            pa.prefetch(a, l, my_head, pos, tid);   // K/V rows cross the memory system while q is awaited
+            pa.prefetch(a, l, my_head, pos, tid, at0);   // K/V rows cross the memory system while q is awaited
             for (unsigned spin = 0;; ++spin) {
                 bool good = true;
 #pragma unroll
@@ -1227,13 +1276,17 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
             TK_STAMP(5);
             tk_barrier();
-            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 10 : nullptr);
+            float pm, ps;       // this part's maximum and sum of exponentials
+            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, (tr && lane == 0 && l < 22) ? tr + (32 + l) * 16 + 10 : nullptr, at0, at1, &pm, &ps);
             tk_barrier();
             TK_STAMP(6);
             // fold the waves*TPW partial output vectors: lane = output dim, one conflict-free ds_read_b32 per partial
             const float* redf = reinterpret_cast<const float*>(lds + LD::ATT_RED);
+            constexpr int ND = SH::HS / WAVE, NPH = TkAttPlan<SH>::PMAX - 1;
+            float o[ND];
 #pragma unroll
-            for (int d0 = 0; d0 < SH::HS; d0 += WAVE) {
+            for (int d = 0; d < ND; ++d) {
+                const int d0 = d * WAVE;
                 float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
                 for (int w = 0; w < TK_WAVES * (256 / SH::HS); w += 4) {
@@ -1242,8 +1295,68 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                     o2 += redf[(w + 2) * SH::HS + d0 + lane];
                     o3 += redf[(w + 3) * SH::HS + d0 + lane];
                 }
-                const float o = (o0 + o1) + (o2 + o3);
-                tk_publish(tk_g_xb<SH>(a) + my_head * SH::HS + d0 + lane, e_att, o);
+                o[d] = (o0 + o1) + (o2 + o3);
+            }
+            if (plan.P == 1) {
+#pragma unroll
+                for (int d = 0; d < ND; ++d) tk_publish(tk_g_xb<SH>(a) + my_head * SH::HS + d * WAVE + lane, e_att, o[d]);
+            } else if (apart > 0) {
+                // a part's softmax-weighted sum of V rows over ITS timesteps, with its maximum and sum: merged by the head's CU
+                unsigned long long* gp = tk_g_part<SH>(a, my_head, apart);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) tk_publish(gp + d * WAVE + lane, e_att, o[d]);
+                if (lane < 2) tk_publish(gp + SH::HS + lane, e_att, lane == 0 ? pm : ps);
+            } else {
+                // the head's CU: sum_p w_p o_p / sum_p w_p with w_p = s_p exp(m_p - M), M the maximum over all parts
+                // (llama2.f90:466-478 evaluated in parts: exp(x - m_p) exp(m_p - M) for exp(x - M))
+                // (the other parts are fetched G at a time: one round trip for up to G of them; head size 128 takes two rounds
+                // from 6 parts on -- the q4_0 kernel has no registers for all seven at once)
+                constexpr int G = ND == 1 ? NPH : 4;
+                float M = pm, W = ps;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[d] *= ps;
+                for (int p0 = 1; p0 < plan.P && ok; p0 += G) {
+                    float xv[G][ND], xm[G];
+                    for (unsigned spin = 0;; ++spin) {
+                        bool good = true;
+#pragma unroll
+                        for (int i = 0; i < G; ++i) {
+                            const bool live = p0 + i < plan.P;
+                            const unsigned long long* gq = tk_g_part<SH>(a, my_head, live ? p0 + i : 1);
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) {
+                                const unsigned long long x = __hip_atomic_load(gq + d * WAVE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                good = good && (!live || (unsigned)(x >> 32) == e_att);
+                                xv[i][d] = __uint_as_float((unsigned)x);
+                            }
+                            const unsigned long long y = __hip_atomic_load(gq + SH::HS + (lane & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            good = good && (!live || (unsigned)(y >> 32) == e_att);
+                            xm[i] = __uint_as_float((unsigned)y);
+                        }
+                        if (__all(good) || nosync) break;
+                        if ((spin & 63) == 63) {
+                            if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+                            if (spin > TK_SPIN_LIMIT) {
+                                if (lane == 0) __hip_atomic_store(a.err, 0x300u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                ok = false; break;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
+                    }
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        if (p0 + i < plan.P) {
+                            const float mp = __shfl(xm[i], 0, WAVE), sp = __shfl(xm[i], 1, WAVE);
+                            const float Mn = fmaxf(M, mp), f0 = expf(M - Mn), f1 = expf(mp - Mn) * sp;
+#pragma unroll
+                            for (int d = 0; d < ND; ++d) o[d] = o[d] * f0 + xv[i][d] * f1;
+                            W = W * f0 + f1;
+                            M = Mn;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < ND; ++d) tk_publish(tk_g_xb<SH>(a) + my_head * SH::HS + d * WAVE + lane, e_att, o[d] / W);
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
@@ -1553,8 +1666,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     constexpr int HPC = TK_NCU / SH::NH;
     // head h runs on CU h*HPC + (its kv group mod HPC): with the dispatcher placing block b on XCD b % 8 the heads
     // of one kv group share an XCD (one L2 copy of their K/V rows) and different groups use different XCDs
-    const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
-    const int my_head = c / HPC;
+    const int my_head = c / HPC;                    // (its attention CU, or a part of it at long contexts: tk_att_role)
 
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF
     TkRing<SH> r;
@@ -1571,11 +1683,12 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             tk_run<SH, SC::KQ, EARLY, false>(r, a, l, c, sw, x, part, lane);
             tk_eat<SH, SC::KQ + EARLY, LATE>(r, x, part, lane);
             tk_barrier();
-            if (att_cu) {
+            int at0, at1;
+            if (tk_att_role<SH>(c, pos, at0, at1)) {
                 TkAtt<SH> pa;
-                pa.prefetch(a, l, my_head, pos, tid);   // before the wait for q: K/V latency overlaps it
+                pa.prefetch(a, l, my_head, pos, tid, at0);   // before the wait for q: K/V latency overlaps it
                 tk_barrier();
-                tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
+                tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, nullptr, at0, at1);
                 tk_barrier();
             }
             if constexpr (LLMK_TK_GF && !SH::GCOOP) {
@@ -1624,11 +1737,12 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
         // QKV phase (its input was gathered at the end of the previous layer; layer 0: the service wave stages the embedding row)
         tk_phase_body<SH, SC::KQ, SH::SL_Q, false>(r, a, l, c, sw, xs4, part, lane);
-        if (att_cu) {
+        int at0, at1;
+        if (tk_att_role<SH>(c, pos, at0, at1)) {
             TkAtt<SH> pa;
-            pa.prefetch(a, l, my_head, pos, tid);
+            pa.prefetch(a, l, my_head, pos, tid, at0);
             tk_barrier();
-            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
+            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, nullptr, at0, at1);
             tk_barrier();
         }
         if (!att_cu) { tk_xb_delay(); tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync); }

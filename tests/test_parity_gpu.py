@@ -187,6 +187,33 @@ def test_tinyllama_f16_token_kernel_matches_oracle_over_300_positions(gguf):
     assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
 
 
+@pytest.mark.parametrize("shape,wtype", [("tk-small", 0), ("tk-small16", 1)], ids=["f32", "f16"])
+def test_token_kernel_attention_in_parts_matches_oracle_up_to_2048_timesteps(shape, wtype, gguf):
+    """Contexts past 256 timesteps: the persistent kernel runs a head's attention in up to 8 parts on the CUs of the head's
+    group and merges the parts' softmaxes (token_kernel.h TkAttPlan).  2,100 positions -- every part count from 1 to 8,
+    part boundaries that are and are not multiples of the 32-timestep row group, the last part holding this token's own
+    key -- against the oracle (f16: on the host-decoded weights), teacher-forced, every logit of every position."""
+    s0 = gguf.SHAPES[shape]
+    s = gguf.LlamaShape(s0.emb_dim, s0.hidden_dim, s0.n_layers, s0.n_heads, s0.n_kv_heads, s0.vocab_size, 2100)
+    fw = gguf.synth_fused(s, 4242, wtype)
+    ot, ol = Oracle(fw.as_f32() if wtype else fw, "omp").generate(s.seq_len)
+    m = llmk.Llmk(fw)
+    assert m.time_kernel(6, 1)[0] > 0              # the persistent kernel is what runs
+    m.reset()
+    _, l = m.generate(s.seq_len, prompt=ot.tolist())
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+    # the pipelined greedy decode (its own instantiation of the kernel) walks the same transcript up to the first near-tie
+    first_unsafe = int(np.argmin(safe)) if not safe.all() else s.seq_len
+    if first_unsafe > 300:
+        t3, _ = m.generate(first_unsafe, want_logits=False, greedy_on_device=True)
+        assert np.array_equal(t3, ot[:first_unsafe])
+    m.close()
+
+
 @pytest.mark.parametrize("shape,hs_tile", [("tiny-gqa", 1024), ("tiny-mha", 512)])
 def test_long_context_small_heads_match_oracle(shape, hs_tile, gguf):
     """head sizes 16 and 32: attn_kernel's timestep tile is 1024 / 512 there; contexts past it against the oracle (which is
@@ -335,8 +362,26 @@ def test_llama2_7b_full_shape_q4_0_properties():
     m.close()
     ref = bench.build_streamed(s, 2, None, 0, llmk.FLAG_MULTI_KERNEL, 0, 1, None)
     _, lr = ref.generate(n, prompt=t1.tolist())
-    ref.close()
     assert rel_err(l1, lr).max() <= 2e-5
+    # (5) long contexts (head size 128, attention in 6 and in 8 parts: two merge rounds): after the same 1,400- and then
+    # 2,000-token prompt the persistent kernel's next tokens carry the multi-kernel path's logits
+    m = bench.build_streamed(s, 2, None, 0, 0, 0, 1, None)
+    rng = np.random.default_rng(5)
+    pos = 0
+    for upto in (1400, 2000):
+        prompt = rng.integers(1, s.vocab_size, upto - pos).astype(np.int32)
+        la, lb = m.prefill(prompt, pos + 1), ref.prefill(prompt, pos + 1)
+        assert rel_err(la[None], lb[None]).max() <= 2e-5
+        pos = upto
+        tok = int(np.argmax(lb)) + 1
+        for _ in range(3):
+            pos += 1
+            la, lb = m.forward(tok, pos), ref.forward(tok, pos)
+            assert np.all(np.isfinite(la))
+            assert rel_err(la[None], lb[None]).max() <= 2e-5, pos
+            tok = int(np.argmax(lb)) + 1
+    m.close()
+    ref.close()
 
 
 def test_opt_in_rms_epsilon_matches_the_oracle_with_the_same_epsilon(gguf):
