@@ -117,6 +117,9 @@
 #ifndef LLMK_TK_ATT_SPLIT
 #define LLMK_TK_ATT_SPLIT 1          // contexts longer than 256 timesteps: a head's attention in parts on the CUs of its group (TkAttPlan)
 #endif
+#ifndef LLMK_TK_ATT_STEP
+#define LLMK_TK_ATT_STEP 0           // timesteps per attention part before another part is added (0: the prefetched tile, 256 or 128)
+#endif
 #ifndef LLMK_TK_XB_DELAY
 #define LLMK_TK_XB_DELAY 0
 #endif
@@ -975,9 +978,10 @@ template <class SH>
 struct TkAttPlan {
     static constexpr int HPC = TK_NCU / SH::NH, TILE = TkAtt<SH>::TILE, TPB = TkAtt<SH>::TPB;
     static constexpr int PMAX = HPC < 8 ? HPC : 8;       // parts per head at most
+    static constexpr int STEP = LLMK_TK_ATT_STEP > 0 ? LLMK_TK_ATT_STEP : TILE;   // one more part per STEP timesteps
     int P, chunk;
     __device__ __forceinline__ TkAttPlan(int pos) {
-        P = min(PMAX, (pos + TILE - 1) / TILE);
+        P = min(PMAX, (pos + STEP - 1) / STEP);
         if (LLMK_TK_ATT_SPLIT == 0 || (SH::GCOOP && !SH::COOP) || P < 1) P = 1;   // (tk_stream_gc, an experiment left off, knows no parts)
         chunk = (((pos + P - 1) / P) + TPB - 1) / TPB * TPB;
         while (P > 1 && (P - 1) * chunk >= pos) --P;          // (cannot happen for pos > TILE * (P - 1); kept as a guard)
@@ -991,7 +995,7 @@ template <class SH>
 __device__ __forceinline__ bool tk_att_role(int c, int pos, int& t0, int& t1) {
     constexpr int HPC = TK_NCU / SH::NH;
     const int apart = ((c % HPC) - ((c / HPC / SH::KVMUL) % HPC) + HPC) % HPC;
-    if (pos <= TkAtt<SH>::TILE || LLMK_TK_ATT_SPLIT == 0) { t0 = 0; t1 = pos; return apart == 0; }
+    if (pos <= TkAttPlan<SH>::STEP || LLMK_TK_ATT_SPLIT == 0) { t0 = 0; t1 = pos; return apart == 0; }
     const TkAttPlan<SH> plan(pos);
     t0 = plan.t0(apart);
     t1 = plan.t1(apart, pos);
