@@ -114,6 +114,8 @@ struct llmk_ctx {
     int* pf_tok = nullptr;
     hipEvent_t pf_start = nullptr;         // tokens are on the device (and everything before the prefill call is done)
     bool pf_ready = false;                 // pf_setup ran to its end
+    bool pf_hm = false;                    // f16 weights: GEMMs on v_mfma_f32_16x16x32_f16 with the activations as two f16 pieces (prefill.h)
+    unsigned* pf_flag = nullptr;           // device word: an activation did not fit f16 (the call is redone on the f32 instruction)
 };
 typedef llmk_ctx::PfLane PfLane;
 
@@ -590,6 +592,10 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
 // is priced with the measured step times (tests/host_tools/pf_trace.py, round 2): a step of NR row groups at 128
 // positions keeps a SIMD's matrix core busy for 1.7*NR us per resident wave, plus ~0.5 us of barrier / staging per step;
 // the first weights take ~4 us to arrive and every partial tile costs a write and a read in the epilogue.
+#ifndef LLMK_PF_H_STEP1
+#define LLMK_PF_H_STEP1 0.55         // measured step times of pf_gemm_h_kernel at 128 positions, one / two row groups per wave (us)
+#define LLMK_PF_H_STEP2 0.80
+#endif
 struct PfPlan { int nr, nk, total, U, grid; };
 PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
     // ONE workgroup per CU (pinned by the LDS request), one or two 16-row groups per wave.  Step times measured at 128
@@ -599,7 +605,9 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
     // the pairs drift apart and the kernel waits for the slower one) and eight waves per workgroup (two per SIMD in step).
     // Four row groups per wave (128 accumulator registers, 256-row strips): step 8.2 us for 512 MFMAs -- 87 % of the matrix rate
     // in the loop against 84 % with two, eaten by the coarser units (TinyLlama w1|w3 67.9 vs 62.2 us; Llama-2-7B q4_0 +0.4 %).
-    static const double step_us[2] = {2.45, 4.25};
+    // f16 weights on the f16 instruction (pf_gemm_h_kernel): a step is 8x less matrix work
+    static const double step_f32[2] = {2.45, 4.25}, step_h[2] = {LLMK_PF_H_STEP1, LLMK_PF_H_STEP2};
+    const double* step_us = c->pf_hm ? step_h : step_f32;
     PfPlan best{};
     double best_t = 1e30;
     for (int nr = 1; nr <= 2; ++nr) {
@@ -634,6 +642,7 @@ void pf_teardown(llmk_ctx* c) {
     c->pf[0].stream = nullptr;
     if (c->pf_start) { hipEventDestroy(c->pf_start); c->pf_start = nullptr; }
     if (c->pf_tok) { hipFree(c->pf_tok); c->pf_tok = nullptr; }
+    if (c->pf_flag) { hipFree(c->pf_flag); c->pf_flag = nullptr; }
     c->pf_ready = false;
 }
 // Workspaces, the second lane's stream, the KV events and the kernels' dynamic-LDS limits.  pf_ready is set only after
@@ -641,6 +650,8 @@ void pf_teardown(llmk_ctx* c) {
 // of launching on null buffers.
 int pf_setup_inner(llmk_ctx* c) {
     const size_t T = PF_TMAX;
+    HIPCHK(hipMalloc(&c->pf_flag, sizeof(unsigned)));
+    HIPCHK(hipMemset(c->pf_flag, 0, sizeof(unsigned)));
     const int rows[4] = {c->E + 2 * c->KV, c->E, 2 * c->H, c->E};
     size_t pcap = 0;
     const int Ks[4] = {c->E, c->E, c->E, c->H};
@@ -679,6 +690,11 @@ constexpr size_t pf_gemm_smem() {
     const size_t need = ((size_t)2 * NG * 16 * PF_LDW + (size_t)NG * 16 * (64 * NR + PF_TPAD)) * sizeof(float);
     return need > (size_t)84 * 1024 ? need : (size_t)84 * 1024;
 }
+template <int NG, int NR>
+constexpr size_t pf_gemm_h_smem() {
+    const size_t need = (size_t)4 * NG * 16 * PF_HP * sizeof(_Float16) + (size_t)NG * 16 * (64 * NR + PF_TPAD) * sizeof(float);
+    return need > (size_t)84 * 1024 ? need : (size_t)84 * 1024;
+}
 constexpr size_t pf_attn_smem(int hs) { return ((size_t)PF_ATT_WAVES * 16 * hs + 2 * PF_ATT_WAVES * 16) * sizeof(float); }
 // The limits are raised ONCE, in pf_setup (as g_prepare does for the decode kernels): a launch is a launch, with no
 // runtime call in the 5 us gaps between the prefill's dependent kernels, and an LDS failure surfaces at setup.
@@ -686,6 +702,16 @@ template <int NG, int WT>
 hipError_t pf_gemm_prepare_one() {
     HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_smem<NG, 1>()));
     return hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_smem<NG, 2>());
+}
+template <int NG>
+hipError_t pf_gemm_h_prepare_one() {
+    HIPRET(hipFuncSetAttribute((const void*)pf_gemm_h_kernel<NG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<NG, 1>()));
+    return hipFuncSetAttribute((const void*)pf_gemm_h_kernel<NG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<NG, 2>());
+}
+hipError_t pf_gemm_h_prepare() {
+    HIPRET(pf_gemm_h_prepare_one<1>()); HIPRET(pf_gemm_h_prepare_one<2>()); HIPRET(pf_gemm_h_prepare_one<3>()); HIPRET(pf_gemm_h_prepare_one<4>());
+    HIPRET(pf_gemm_h_prepare_one<5>()); HIPRET(pf_gemm_h_prepare_one<6>()); HIPRET(pf_gemm_h_prepare_one<7>());
+    return pf_gemm_h_prepare_one<8>();
 }
 template <int WT>
 hipError_t pf_gemm_prepare() {
@@ -697,7 +723,7 @@ hipError_t pf_gemm_prepare() {
 hipError_t pf_prepare(const llmk_ctx* c) {
     switch (c->cfg.weight_type) {
         case LLMK_TYPE_Q4_0: HIPRET(pf_gemm_prepare<WT_Q4_0>()); break;
-        case LLMK_TYPE_F16: HIPRET(pf_gemm_prepare<WT_F16>()); break;
+        case LLMK_TYPE_F16: HIPRET(pf_gemm_prepare<WT_F16>()); HIPRET(pf_gemm_h_prepare()); break;
         default: HIPRET(pf_gemm_prepare<WT_F32>()); break;
     }
     const int smem = (int)pf_attn_smem(c->hs);
@@ -713,6 +739,11 @@ template <int NG, int NR>
 hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, const PfPlan& p) {
     constexpr size_t smem = pf_gemm_smem<NG, NR>();
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
+    if (c->cfg.weight_type == LLMK_TYPE_F16 && c->pf_hm) {
+        constexpr size_t smem_h = pf_gemm_h_smem<NG, NR>();
+        hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR>), grid, block, smem_h, w.stream, a, c->pf_flag);
+        return hipGetLastError();
+    }
     if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
     else if (c->cfg.weight_type == LLMK_TYPE_F16) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F16, NR>), grid, block, smem, w.stream, a);
     else hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_F32, NR>), grid, block, smem, w.stream, a);
@@ -724,7 +755,7 @@ hipError_t pf_gemm(llmk_ctx* c, const PfLane& w, const void* W, int row_stride, 
     a.W = W; a.X = X; a.P = w.P; a.rows = rows; a.K = K; a.T = T; a.RS = row_stride;
     a.nk = p.nk; a.U = p.U; a.total = p.total;
 #ifdef LLMK_PF_TRACE
-    a.trace = (unsigned long long*)w.HB;         // debug build: stamps land in the SwiGLU buffer (llmk_peek 7)
+    a.trace = (unsigned long long*)(X == w.HB ? w.Q : w.HB);   // debug build: stamps land in the SwiGLU buffer (llmk_peek 7); the w2 GEMM reads that one: its stamps go to the (dead) q buffer
 #endif
     e->U = p.U; e->nk = p.nk; e->sh = p.nr == 2 ? 7 : 6;
 #define PF_CASE(NG_)                                                                         \
@@ -1178,6 +1209,7 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
         return LLMK_OK;
     }
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (!c->pf_ready) c->pf_hm = c->cfg.weight_type == LLMK_TYPE_F16 && !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
     rc = pf_setup(c);
     if (rc) return rc;
     std::vector<int> tok0(tokens, tokens + n);
@@ -1201,7 +1233,19 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     if (k >= 2) HIPCHK(hipStreamWaitEvent(c->stream, c->pf[1].done, 0));
     HIPCHK(launch_cls(c));                          // final rmsnorm + classifier of the last position   :627-636
     HIPCHK(hipMemcpyAsync(c->h_logits, c->d_logits, (size_t)c->V * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    unsigned* h_flag = reinterpret_cast<unsigned*>(c->h_logits + c->V + 1);
+    *h_flag = 0;
+    if (c->pf_hm) HIPCHK(hipMemcpyAsync(h_flag, c->pf_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pf_hm && *h_flag) {
+        // an activation of this prompt does not fit an f16 (|x| >= 65504): this context's GEMMs go back to the f32 matrix
+        // instruction for good, and the call is redone (the K/V rows it wrote are rewritten)
+        pf_teardown(c);
+        c->pf_hm = false;
+        rc = pf_setup(c);
+        if (rc) return rc;
+        return llmk_prefill(c, tokens, n, pos0, logits_out);
+    }
     memcpy(logits_out, c->h_logits, (size_t)c->V * sizeof(float));
     return LLMK_OK;
 }

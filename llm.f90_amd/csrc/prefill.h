@@ -19,6 +19,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace llmk {
@@ -294,6 +296,221 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
 #undef PF_XNEXT
 #undef wkl
 #undef PF_XSTORE
+}
+
+// ---- f16 weights on the f16 matrix instruction (round 3) ------------------------------------------------------------------
+// v_mfma_f32_16x16x32_f16 does 16x16x32 in 16 clocks where v_mfma_f32_16x16x4_f32 needs 8 x 32: an f16 weight matrix is
+// ALREADY the A operand (a lane's 16 bytes = 8 consecutive columns of its row: no conversion), and the f32 activation is
+// fed as TWO f16 pieces, x = hi + lo with hi = f16(x), lo = f16(x - hi): two instructions per 32 columns instead of eight,
+// every product exact in f32 (11 x 11 significand bits), |x - hi - lo| <= 2^-20 |x| (2^-24 absolute where lo is an f16
+// subnormal, |x| < 2^-3: the instruction honours subnormal inputs, csrc/probes/mfma_f16_denorm_probe.hip) -- the f32
+// accumulation order is the matrix core's either way.  Activations of 65504 and above do not fit hi: the staging raises
+// `flag` and llmk_prefill redoes the call on the f32 instruction (pf_gemm_kernel<.., WT_F16, ..>).
+// Same units / strips / partial tiles as pf_gemm_kernel; a step (64 columns) is 4 x NR x NG instructions = 1,024 matrix
+// clocks at 128 positions with two row groups, so the weights run PF_HST - 1 steps ahead (ring of register stages).
+typedef _Float16 pf_v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 pf_v4h __attribute__((ext_vector_type(4)));
+// LDS image of a step's activations: [hi, lo][position][64 halfs], 128-byte rows, the 16-byte slot s of position t stored at
+// slot s ^ ((t >> 1) & 7).  ds_read_b128 is served in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, ...:
+// MI355X_MICROARCH.md, LDS): a group holds all 16 positions of a fragment, half of them with the neighbouring column slot,
+// and with this swizzle its 16 addresses fall into 16 different 4-bank slots (a padded pitch of 144 bytes left 7 of the 16
+// pairs on one slot: two LDS cycles per group, and the LDS, not the matrix core, set the step time).
+constexpr int PF_HP = PF_KSTEP;
+constexpr int PF_HST = 6;                    // weight stages
+
+template <int Q, int N, class F>
+__device__ __forceinline__ void pf_prologue(F& wload) {
+    if constexpr (Q < N) { wload(std::integral_constant<int, Q>()); pf_prologue<Q + 1, N>(wload); }
+}
+// N steps written out over a ring of R stages: step s+Q multiplies stage Q % R and refills the stage step s+Q-1 used.  The
+// steps nest (a step past the block's last unit skips everything behind it: forward branches only, no join at a step's top
+// for hipcc's waitcnt pass to merge pending loads at).
+template <int Q, int N, int R, class F>
+__device__ __forceinline__ void pf_ring(F& step, int s, int nsteps) {      // (N and the trip stride are even: Q & 1 is the step's parity)
+    if constexpr (Q < N) {
+        if (s + Q < nsteps) {
+            step(s + Q, std::integral_constant<int, Q % R>(), std::integral_constant<int, (Q + R - 1) % R>(), std::integral_constant<int, Q & 1>());
+            pf_ring<Q + 1, N, R>(step, s, nsteps);
+        }
+    }
+}
+template <int NG, int NR>
+__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag) {
+    constexpr int NW = PF_WAVES, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
+    constexpr int ST = PF_HST;
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    _Float16* xh = reinterpret_cast<_Float16*>(pf_smem);                                  // [2 buffers][hi, lo][TP][PF_HP]
+    float* tb = reinterpret_cast<float*>(pf_smem + (size_t)4 * TP * PF_HP * sizeof(_Float16));   // [TP][SR + PF_TPAD]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int u0 = blockIdx.x * a.U, nsteps = min(a.U, a.total - u0);
+    if (nsteps <= 0) return;
+    const int li = lane & 15, kg = lane >> 4;
+    const size_t rowb = (size_t)a.K * 2;
+    const char* wbase = static_cast<const char*>(a.W) + (size_t)kg * 16;
+    constexpr int STEPB = PF_KSTEP * 2;
+    int cs = u0 / a.nk, ck = u0 % a.nk;
+    int ws = cs, wk = ck, wi = 0, xk = ck, xi = 0;
+    const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * STEPB;
+    constexpr int XV = TP * (PF_KSTEP / 4) / NT;          // float4 per thread per step (= NG)
+    static_assert(XV * NT == TP * (PF_KSTEP / 4), "whole vectors per thread");
+    const float* xg[XV];
+    int xo[XV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int idx = tid + i * NT, t = idx / (PF_KSTEP / 4), c4 = idx % (PF_KSTEP / 4);
+        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + c4 * 4;
+        xo[i] = t * PF_HP + (((c4 >> 1) ^ ((t >> 1) & 7)) << 3) + (c4 & 1) * 4;
+    }
+    pf_v4f acc[NR][NG];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[r][g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+    float4 w[ST][NR * NJ];
+    pf_v4f xr[2][XV];               // activations of two steps in flight: requested a whole step before they are published
+#ifdef LLMK_PF_TRACE
+    unsigned long long* tr = a.trace + (size_t)blockIdx.x * 20;
+    if (tid == 0) { tr[0] = wall_clock64(); tr[18] = __builtin_readcyclecounter(); }
+#define PF_STAMP(I_) if (tid == 0 && (I_) < 17) tr[I_] = wall_clock64()
+#else
+#define PF_STAMP(I_)
+#endif
+
+    auto wload = [&](auto stage) {
+        constexpr int Q = decltype(stage)::value;
+#pragma unroll
+        for (int q = 0; q < NR * NJ; ++q) w[Q][q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * 64));
+        const int adv = wi < nsteps - 1 ? 1 : 0;
+        wi += adv;
+        wk += adv;
+        const bool wrap = wk == a.nk;
+        wk = wrap ? 0 : wk;
+        ws += wrap ? 1 : 0;
+        const char* nxt = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb;
+        wp = wrap ? nxt : wp + adv * STEPB;
+    };
+    auto xload = [&](auto par) {
+        constexpr int B_ = decltype(par)::value;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) xr[B_][i] = *reinterpret_cast<const pf_v4f*>(xg[i] + xk * PF_KSTEP);
+        const int adv = xi < nsteps - 1 ? 1 : 0;
+        xi += adv;
+        xk += adv;
+        xk = xk == a.nk ? 0 : xk;
+    };
+    // vectors [LO, HI) of a step's activations: split and published.  Five VALU operations per PAIR of elements (the split
+    // of a step's tile was 256 of a wave's ~500 VALU operations per step, against 64 matrix instructions that cover 190):
+    // hi = both halves in one v_cvt_pkrtz (toward zero: the remainder then has up to 11 significant bits and the same sign),
+    // x - hi through v_fma_mix_f32 with the f16 half as a source (no conversion back), lo = v_cvt_pkrtz of the two remainders
+    // (|x - hi - lo| <= 2^-20 |x|), and the running max |x| for the range check.
+    float amax = 0.f;
+    auto xstore = [&](auto par, int buf, int lo_i, int hi_i) {
+        constexpr int B_ = decltype(par)::value;
+        _Float16* hi = xh + (size_t)(buf * 2) * TP * PF_HP;
+        _Float16* lo = hi + (size_t)TP * PF_HP;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            if (i < lo_i || i >= hi_i) continue;
+            typedef __fp16 pf_h2 __attribute__((ext_vector_type(2)));
+            union { pf_h2 h2[2]; unsigned u[2]; pf_v4h v; } H, L;
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const float x0 = xr[B_][i][e], x1 = xr[B_][i][e + 1];
+                H.h2[e / 2] = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                float d0, d1;
+                asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+                    "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                    : "=&v"(d0), "=&v"(d1) : "v"(H.u[e / 2]), "v"(x0), "v"(x1));
+                L.h2[e / 2] = __builtin_amdgcn_cvt_pkrtz(d0, d1);
+                amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+            }
+            *reinterpret_cast<pf_v4h*>(hi + xo[i]) = H.v;
+            *reinterpret_cast<pf_v4h*>(lo + xo[i]) = L.v;
+        }
+    };
+    // A step = four pieces (32-column chunk j, hi or lo): A = the stage's 16 bytes as they came from memory, B = 8 halfs of
+    // each position's row.  The B fragments of piece p+1 are requested before the instructions of piece p are issued, and a
+    // quarter of the NEXT step's activations is split and published between them (VALU and LDS writes issue in the shadow
+    // of the matrix instructions; the two LDS buffers alternate).
+    auto bread = [&](pf_v8h (&B)[NG], int buf, int p) {
+        const _Float16* src = xh + (size_t)(buf * 2 + (p & 1)) * TP * PF_HP + li * PF_HP + ((((p >> 1) * 4 + kg) ^ ((li >> 1) & 7)) << 3);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#if defined(LLMK_PF_EXP) && (LLMK_PF_EXP & 8)
+            B[g] = (pf_v8h){0, 0, 0, 0, 0, 0, 0, 0};
+#else
+            B[g] = *reinterpret_cast<const pf_v8h*>(src + g * 16 * PF_HP);
+#endif
+        }
+    };
+    auto step = [&](int S, auto cur, auto nxt, auto par) {
+        constexpr int CUR = decltype(cur)::value, PAR = decltype(par)::value;      // PAR = S & 1
+        const int buf = S & 1;
+        xload(std::integral_constant<int, PAR>());          // X(S+2) -> xr[S&1] (published during step S-1: free)
+        pf_v8h B0[NG], B1[NG];
+        bread(B0, buf, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            pf_v8h (&Bc)[NG] = (p & 1) ? B1 : B0;
+            pf_v8h (&Bn)[NG] = (p & 1) ? B0 : B1;
+            if (p < 3) bread(Bn, buf, p + 1);
+            xstore(std::integral_constant<int, PAR ^ 1>(), buf ^ 1, p * XV / 4, (p + 1) * XV / 4);     // X(S+1) from xr[(S+1)&1]
+            pf_v8h A[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) A[r] = *reinterpret_cast<const pf_v8h*>(&w[CUR][r * NJ + (p >> 1)]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#if defined(LLMK_PF_EXP) && (LLMK_PF_EXP & 4)
+                    asm volatile("" :: "v"(Bc[g]), "v"(A[r]));
+#else
+                    acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], Bc[g], acc[r][g], 0, 0, 0);
+#endif
+                }
+        }
+#if defined(LLMK_PF_EXP) && (LLMK_PF_EXP & 16)
+        if (S < 0)
+#endif
+        wload(nxt);
+        if (++ck == a.nk || S == nsteps - 1) {
+            const int slot = (int)blockIdx.x - pf_first_block(cs, a.nk, a.U);
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    *reinterpret_cast<pf_v4f*>(tb + (g * 16 + li) * (SR + PF_TPAD) + wid * (16 * NR) + r * 16 + (lane >> 4) * 4) = acc[r][g];
+                    acc[r][g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
+                }
+            __syncthreads();
+            float* dst = a.P + (size_t)slot * TP * a.rows + cs * SR;
+#pragma unroll
+            for (int k = 0; k < TP * SR / 4 / NT; ++k) {
+                const int idx = tid + k * NT, t = idx / (SR / 4), c = idx % (SR / 4) * 4;
+                const pf_v4f v = *reinterpret_cast<const pf_v4f*>(tb + t * (SR + PF_TPAD) + c);
+                if (cs * SR + c < a.rows) *reinterpret_cast<pf_v4f*>(dst + (size_t)t * a.rows + c) = v;
+            }
+            ck = 0;
+            ++cs;
+        }
+        __syncthreads();
+        PF_STAMP(2 + S);
+    };
+    // prologue: weights of steps 0 .. ST-2; activations of step 0 published, of step 1 in xr[1] (step 0 requests step 2 into xr[0])
+    pf_prologue<0, ST - 1>(wload);
+    xload(std::integral_constant<int, 0>());
+    xstore(std::integral_constant<int, 0>(), 0, 0, XV);
+    xload(std::integral_constant<int, 1>());
+    __syncthreads();
+    PF_STAMP(1);
+    // two ring cycles per trip: the loop's back edge costs a drain of the weight prefetch (hipcc's waitcnt pass merges the
+    // loop's two entries conservatively: s_waitcnt vmcnt(0) in the first step of a trip), and this path's GEMMs have <= 12 units per block
+    for (int s = 0; s < nsteps; s += 2 * ST) pf_ring<0, 2 * ST, ST>(step, s, nsteps);
+    if (__any(!(amax < 65504.0f)) && lane == 0) atomicOr(flag, 1u);     // (NaN counts)
+#ifdef LLMK_PF_TRACE
+    if (tid == 0) { tr[17] = wall_clock64(); tr[19] = __builtin_readcyclecounter(); }
+#endif
+#undef PF_STAMP
 }
 
 // x[t] = token_embedding_table(:, token_t)                                              llama2.f90:520

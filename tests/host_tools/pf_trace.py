@@ -1,5 +1,5 @@
 """Block timeline of the prefill GEMMs (pf_gemm_kernel): wall-clock stamps per workgroup from the DEBUG library.
-   LLMK_LIB=llm.f90_amd/csrc/libllmk_debug.so LLMK_PF_PLAN=1|2 python tests/host_tools/pf_trace.py [w13|wqkv|wo|w2]
+   LLMK_LIB=llm.f90_amd/csrc/libllmk_debug.so LLMK_PF_PLAN=1|2 python tests/host_tools/pf_trace.py [--type f32|f16|q4_0] [w13|wqkv|wo|w2]
    LLMK_PF_PLAN forces the 16-row groups per wave of pf_plan (csrc/llmk.hip); the tool needs it to know the grid."""
 import os
 import sys
@@ -9,11 +9,14 @@ import llm_f90_amd
 from llm_f90_amd import llmk
 from llm_f90_amd.tools import gguf
 s = gguf.SHAPES["tinyllama"]
+wt = 0
+if "--type" in sys.argv:
+    i = sys.argv.index("--type"); wt = {"f32": 0, "f16": 1, "q4_0": 2}[sys.argv[i + 1]]; del sys.argv[i:i + 2]
 which = sys.argv[1] if len(sys.argv) > 1 else "w13"
 kern = {"w13": 7, "wqkv": 8, "wo": 9, "w2": 10}[which]
 rows = {"w13": 2 * s.hidden_dim, "wqkv": s.emb_dim + 2 * s.kv_dim, "wo": s.emb_dim, "w2": s.emb_dim}[which]
 K = s.hidden_dim if which == "w2" else s.emb_dim
-m = llmk.Llmk(gguf.synth_fused(s, 1, 0))
+m = llmk.Llmk(gguf.synth_fused(s, 1, wt))
 m.prefill([2] + list(range(5, 5 + 127)), 1)
 ms, b = m.time_kernel(kern, 66)
 print("%s GEMM, 128 positions: %.1f us per launch (66 launches), %.1f TFLOP/s" % (which, ms * 1e3, 2 * 128 * rows * K / (ms * 1e-3) / 1e12))
