@@ -114,7 +114,7 @@ struct llmk_ctx {
     int* pf_tok = nullptr;
     hipEvent_t pf_start = nullptr;         // tokens are on the device (and everything before the prefill call is done)
     bool pf_ready = false;                 // pf_setup ran to its end
-    bool pf_hm = false;                    // f16 weights: GEMMs on v_mfma_f32_16x16x32_f16 with the activations as two f16 pieces (prefill.h)
+    bool pf_hm = false;                    // f16 / q4_0 weights: GEMMs on v_mfma_f32_16x16x32_f16 with the activations as two f16 pieces (prefill.h)
     unsigned* pf_flag = nullptr;           // device word: an activation did not fit f16 (the call is redone on the f32 instruction)
 };
 typedef llmk_ctx::PfLane PfLane;
@@ -597,7 +597,7 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
 #define LLMK_PF_H_STEP2 0.80
 #endif
 struct PfPlan { int nr, nk, total, U, grid; };
-PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
+PfPlan pf_plan(const llmk_ctx* c, int rows, int K, int T = PF_TMAX) {
     // ONE workgroup per CU (pinned by the LDS request), one or two 16-row groups per wave.  Step times measured at 128
     // positions (tests/host_tools/pf_trace.py, profiles/README.md round 2): 2.45 us with one row group, 4.25 us with two;
     // ~4 us until the first weights arrive; every partial tile is written once and read once by the epilogue.  Also
@@ -613,6 +613,9 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K) {
     for (int nr = 1; nr <= 2; ++nr) {
         const int sr = 64 * nr;
         if (nr == 2 && rows % sr) continue;
+        // q4_0 on the f16 instruction: the scaled accumulation runs on the VALU, which cannot read accumulation registers --
+        // two row groups at 112+ positions do not fit the 256 architectural VGPRs (pf_gemm_h_kernel<7|8, 2, q4_0> spills)
+        if (nr == 2 && c->pf_hm && c->cfg.weight_type == LLMK_TYPE_Q4_0 && (T + 15) / 16 > 6) continue;
 #ifdef LLMK_PF_TRACE
         if (const char* f = getenv("LLMK_PF_PLAN"))          // debug build: force the row groups per wave (when the shape allows it)
             if (atoi(f) != nr && !(rows % 128)) continue;
@@ -655,7 +658,8 @@ int pf_setup_inner(llmk_ctx* c) {
     const int rows[4] = {c->E + 2 * c->KV, c->E, 2 * c->H, c->E};
     size_t pcap = 0;
     const int Ks[4] = {c->E, c->E, c->E, c->H};
-    for (int i = 0; i < 4; ++i) pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i])) * T * rows[i]);
+    for (int i = 0; i < 4; ++i)
+        for (int t : {(int)PF_TMAX, 96}) pcap = std::max(pcap, (size_t)pf_max_slots(pf_plan(c, rows[i], Ks[i], t)) * T * rows[i]);   // (the plan may depend on the batch length)
     HIPCHK(pf_prepare(c));
     for (int i = 0; i < 2; ++i) {
         PfLane& w = c->pf[i];
@@ -703,15 +707,16 @@ hipError_t pf_gemm_prepare_one() {
     HIPRET(hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_smem<NG, 1>()));
     return hipFuncSetAttribute((const void*)pf_gemm_kernel<NG, WT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_smem<NG, 2>());
 }
-template <int NG>
+template <int NG, int WT>
 hipError_t pf_gemm_h_prepare_one() {
-    HIPRET(hipFuncSetAttribute((const void*)pf_gemm_h_kernel<NG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<NG, 1>()));
-    return hipFuncSetAttribute((const void*)pf_gemm_h_kernel<NG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<NG, 2>());
+    HIPRET(hipFuncSetAttribute((const void*)pf_gemm_h_kernel<NG, 1, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<NG, 1>()));
+    return hipFuncSetAttribute((const void*)pf_gemm_h_kernel<NG, 2, WT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<NG, 2>());
 }
+template <int WT>
 hipError_t pf_gemm_h_prepare() {
-    HIPRET(pf_gemm_h_prepare_one<1>()); HIPRET(pf_gemm_h_prepare_one<2>()); HIPRET(pf_gemm_h_prepare_one<3>()); HIPRET(pf_gemm_h_prepare_one<4>());
-    HIPRET(pf_gemm_h_prepare_one<5>()); HIPRET(pf_gemm_h_prepare_one<6>()); HIPRET(pf_gemm_h_prepare_one<7>());
-    return pf_gemm_h_prepare_one<8>();
+    HIPRET((pf_gemm_h_prepare_one<1, WT>())); HIPRET((pf_gemm_h_prepare_one<2, WT>())); HIPRET((pf_gemm_h_prepare_one<3, WT>())); HIPRET((pf_gemm_h_prepare_one<4, WT>()));
+    HIPRET((pf_gemm_h_prepare_one<5, WT>())); HIPRET((pf_gemm_h_prepare_one<6, WT>())); HIPRET((pf_gemm_h_prepare_one<7, WT>()));
+    return pf_gemm_h_prepare_one<8, WT>();
 }
 template <int WT>
 hipError_t pf_gemm_prepare() {
@@ -722,8 +727,8 @@ hipError_t pf_gemm_prepare() {
 }
 hipError_t pf_prepare(const llmk_ctx* c) {
     switch (c->cfg.weight_type) {
-        case LLMK_TYPE_Q4_0: HIPRET(pf_gemm_prepare<WT_Q4_0>()); break;
-        case LLMK_TYPE_F16: HIPRET(pf_gemm_prepare<WT_F16>()); HIPRET(pf_gemm_h_prepare()); break;
+        case LLMK_TYPE_Q4_0: HIPRET(pf_gemm_prepare<WT_Q4_0>()); HIPRET(pf_gemm_h_prepare<WT_Q4_0>()); break;
+        case LLMK_TYPE_F16: HIPRET(pf_gemm_prepare<WT_F16>()); HIPRET(pf_gemm_h_prepare<WT_F16>()); break;
         default: HIPRET(pf_gemm_prepare<WT_F32>()); break;
     }
     const int smem = (int)pf_attn_smem(c->hs);
@@ -739,9 +744,10 @@ template <int NG, int NR>
 hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, const PfPlan& p) {
     constexpr size_t smem = pf_gemm_smem<NG, NR>();
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
-    if (c->cfg.weight_type == LLMK_TYPE_F16 && c->pf_hm) {
+    if (c->pf_hm) {
         constexpr size_t smem_h = pf_gemm_h_smem<NG, NR>();
-        hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR>), grid, block, smem_h, w.stream, a, c->pf_flag);
+        if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_Q4_0>), grid, block, smem_h, w.stream, a, c->pf_flag);
+        else hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F16>), grid, block, smem_h, w.stream, a, c->pf_flag);
         return hipGetLastError();
     }
     if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
@@ -750,7 +756,7 @@ hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, con
     return hipGetLastError();
 }
 hipError_t pf_gemm(llmk_ctx* c, const PfLane& w, const void* W, int row_stride, const float* X, int rows, int K, int T, PfEpiArgs* e) {
-    const PfPlan p = pf_plan(c, rows, K);
+    const PfPlan p = pf_plan(c, rows, K, T);
     PfGemmArgs a;
     a.W = W; a.X = X; a.P = w.P; a.rows = rows; a.K = K; a.T = T; a.RS = row_stride;
     a.nk = p.nk; a.U = p.U; a.total = p.total;
@@ -1209,7 +1215,7 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
         return LLMK_OK;
     }
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (!c->pf_ready) c->pf_hm = c->cfg.weight_type == LLMK_TYPE_F16 && !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
+    if (!c->pf_ready) c->pf_hm = (c->cfg.weight_type == LLMK_TYPE_F16 || c->cfg.weight_type == LLMK_TYPE_Q4_0) && !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
     rc = pf_setup(c);
     if (rc) return rc;
     std::vector<int> tok0(tokens, tokens + n);

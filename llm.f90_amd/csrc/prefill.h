@@ -334,10 +334,19 @@ __device__ __forceinline__ void pf_ring(F& step, int s, int nsteps) {      // (N
         }
     }
 }
-template <int NG, int NR>
+// q4_0 weights (WT_Q4_0) on the same instruction: a 32-column chunk is one block, the A operand is n - 8 as f16 (exact: byte n
+// under 0x64 is the half 1024 + n, minus 1032), the block's products are summed by the matrix core from zero (hi piece,
+// then lo piece) and the block scale d -- per weight ROW, so it cannot ride in an operand -- multiplies the 16 x 16 result
+// into the accumulators: (sum_k (n_k - 8) x_k) d instead of the reference's sum_k ((n_k - 8) d) x_k, the same real number
+// with one rounding of d's product fewer per term (parity bar 1e-4 on logits, as for every other reordering of this path).
+// Lane (row li, k group kg) takes the low (kg < 2) or high nibbles of bytes 8 (kg & 1) .. + 7 of the block = its elements
+// 16 (kg >> 1) + 8 (kg & 1) .. + 7 = the 8 consecutive columns of slot kg: the activation side is the f16 kernel's.
+template <int NG, int NR, int WT = WT_F16>
 __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag) {
     constexpr int NW = PF_WAVES, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
-    constexpr int ST = PF_HST;
+    constexpr bool Q4 = WT == WT_Q4_0;
+    static_assert(WT == WT_F16 || WT == WT_Q4_0, "f16 or q4_0 weights");
+    constexpr int ST = Q4 ? 4 : PF_HST;      // (q4_0: longer steps, and the scaled accumulation wants the registers)
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     _Float16* xh = reinterpret_cast<_Float16*>(pf_smem);                                  // [2 buffers][hi, lo][TP][PF_HP]
     float* tb = reinterpret_cast<float*>(pf_smem + (size_t)4 * TP * PF_HP * sizeof(_Float16));   // [TP][SR + PF_TPAD]
@@ -345,20 +354,20 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     const int u0 = blockIdx.x * a.U, nsteps = min(a.U, a.total - u0);
     if (nsteps <= 0) return;
     const int li = lane & 15, kg = lane >> 4;
-    const size_t rowb = (size_t)a.K * 2;
-    const char* wbase = static_cast<const char*>(a.W) + (size_t)kg * 16;
-    constexpr int STEPB = PF_KSTEP * 2;
+    const size_t rowb = Q4 ? (size_t)a.RS : (size_t)a.K * 2;
+    const char* wbase = static_cast<const char*>(a.W) + (Q4 ? (size_t)(kg & 1) * 8 : (size_t)kg * 16);
+    constexpr int STEPB = Q4 ? 32 : PF_KSTEP * 2;           // weight bytes per row per step
     int cs = u0 / a.nk, ck = u0 % a.nk;
     int ws = cs, wk = ck, wi = 0, xk = ck, xi = 0;
     const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * STEPB;
     constexpr int XV = TP * (PF_KSTEP / 4) / NT;          // float4 per thread per step (= NG)
     static_assert(XV * NT == TP * (PF_KSTEP / 4), "whole vectors per thread");
-    const float* xg[XV];
+    int xg[XV];               // element offsets into X (T * K < 2^31)
     int xo[XV];
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         const int idx = tid + i * NT, t = idx / (PF_KSTEP / 4), c4 = idx % (PF_KSTEP / 4);
-        xg[i] = a.X + (size_t)min(t, a.T - 1) * a.K + c4 * 4;
+        xg[i] = min(t, a.T - 1) * a.K + c4 * 4;
         xo[i] = t * PF_HP + (((c4 >> 1) ^ ((t >> 1) & 7)) << 3) + (c4 & 1) * 4;
     }
     pf_v4f acc[NR][NG];
@@ -366,8 +375,16 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int g = 0; g < NG; ++g) acc[r][g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
-    float4 w[ST][NR * NJ];
-    pf_v4f xr[2][XV];               // activations of two steps in flight: requested a whole step before they are published
+    // a stage: f16 -- 16 bytes per chunk and row group
+    typedef unsigned pf_v2u __attribute__((ext_vector_type(2)));
+    float4 w[Q4 ? 1 : ST][Q4 ? 1 : NR * NJ];
+    pf_v2u wq[Q4 ? ST : 1][Q4 ? NR * NJ : 1];        // q4_0: the lane's 8 nibble bytes per block and row group
+    unsigned wd[Q4 ? ST : 1][Q4 ? NR : 1];          //       the row's two block scales (f16 pair)
+    // activations of two steps in flight: requested a whole step before they are published, published in the shadow of the
+    // matrix instructions.  (q4_0, two row groups, 112+ positions: the register file has room for one; published at the
+    // step's top, re-requested at once.)
+    constexpr bool XR2 = !(Q4 && NR == 2 && NG > 6);
+    pf_v4f xr[XR2 ? 2 : 1][XV];
 #ifdef LLMK_PF_TRACE
     unsigned long long* tr = a.trace + (size_t)blockIdx.x * 20;
     if (tid == 0) { tr[0] = wall_clock64(); tr[18] = __builtin_readcyclecounter(); }
@@ -379,7 +396,16 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     auto wload = [&](auto stage) {
         constexpr int Q = decltype(stage)::value;
 #pragma unroll
-        for (int q = 0; q < NR * NJ; ++q) w[Q][q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * 64));
+        for (int q = 0; q < NR * NJ; ++q) {
+            if constexpr (Q4) {
+                const char* rp = wp + (size_t)(q / NJ) * 16 * rowb;
+                wq[Q][q] = __builtin_nontemporal_load(reinterpret_cast<const pf_v2u*>(rp + (q % NJ) * 16));
+                if (q % NJ == 0)        // the scales of blocks 2 wk and 2 wk + 1 of this row: K/2 nibble bytes in, 2 bytes per block
+                    wd[Q][q / NJ] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rp - (size_t)(kg & 1) * 8 - (size_t)wk * 32 + (a.K >> 1) + (size_t)wk * 4));
+            } else {
+                w[Q][q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * 64));
+            }
+        }
         const int adv = wi < nsteps - 1 ? 1 : 0;
         wi += adv;
         wk += adv;
@@ -392,7 +418,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     auto xload = [&](auto par) {
         constexpr int B_ = decltype(par)::value;
 #pragma unroll
-        for (int i = 0; i < XV; ++i) xr[B_][i] = *reinterpret_cast<const pf_v4f*>(xg[i] + xk * PF_KSTEP);
+        for (int i = 0; i < XV; ++i) xr[B_][i] = *reinterpret_cast<const pf_v4f*>(a.X + xg[i] + xk * PF_KSTEP);
         const int adv = xi < nsteps - 1 ? 1 : 0;
         xi += adv;
         xk += adv;
@@ -435,43 +461,93 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     auto bread = [&](pf_v8h (&B)[NG], int buf, int p) {
         const _Float16* src = xh + (size_t)(buf * 2 + (p & 1)) * TP * PF_HP + li * PF_HP + ((((p >> 1) * 4 + kg) ^ ((li >> 1) & 7)) << 3);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#if defined(LLMK_PF_EXP) && (LLMK_PF_EXP & 8)
-            B[g] = (pf_v8h){0, 0, 0, 0, 0, 0, 0, 0};
-#else
-            B[g] = *reinterpret_cast<const pf_v8h*>(src + g * 16 * PF_HP);
-#endif
-        }
+        for (int g = 0; g < NG; ++g) B[g] = *reinterpret_cast<const pf_v8h*>(src + g * 16 * PF_HP);
     };
     auto step = [&](int S, auto cur, auto nxt, auto par) {
         constexpr int CUR = decltype(cur)::value, PAR = decltype(par)::value;      // PAR = S & 1
         const int buf = S & 1;
-        xload(std::integral_constant<int, PAR>());          // X(S+2) -> xr[S&1] (published during step S-1: free)
+        if constexpr (XR2) {
+            xload(std::integral_constant<int, PAR>());          // X(S+2) -> xr[S&1] (published during step S-1: free)
+        } else {
+            xstore(std::integral_constant<int, 0>(), buf ^ 1, 0, XV);
+            xload(std::integral_constant<int, 0>());
+        }
         pf_v8h B0[NG], B1[NG];
         bread(B0, buf, 0);
+        if constexpr (Q4) {
+            // per block j: hi fragments in B0, lo in B1; positions in two halves so that the block's unscaled sums D live in
+            // 32 registers, not 64: D = A.hi (from zero), D += A.lo, acc += d D
+            bread(B1, buf, 1);
+            constexpr int GH = (NG + 1) / 2;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            pf_v8h (&Bc)[NG] = (p & 1) ? B1 : B0;
-            pf_v8h (&Bn)[NG] = (p & 1) ? B0 : B1;
-            if (p < 3) bread(Bn, buf, p + 1);
-            xstore(std::integral_constant<int, PAR ^ 1>(), buf ^ 1, p * XV / 4, (p + 1) * XV / 4);     // X(S+1) from xr[(S+1)&1]
-            pf_v8h A[NR];
+            for (int j = 0; j < 2; ++j) {
+                float sc[NR][4];
+                pf_v8h A[NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) A[r] = *reinterpret_cast<const pf_v8h*>(&w[CUR][r * NJ + (p >> 1)]);
+                for (int r = 0; r < NR; ++r) {
+                    // the block scales in the accumulators' layout: register v of a lane holds weight row 4 kg + v, whose
+                    // scale pair lane 4 kg + v loaded (its A row)
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
+                    for (int v = 0; v < 4; ++v) {
+                        const unsigned dp = (unsigned)__shfl((int)wd[CUR][r], 4 * kg + v, WAVE);
+                        const __half2 h2 = *reinterpret_cast<const __half2*>(&dp);
+                        sc[r][v] = j ? __high2float(h2) : __low2float(h2);
+                    }
+                    typedef _Float16 pf_h2 __attribute__((ext_vector_type(2)));
+                    const unsigned sh = (kg >> 1) * 4;
+                    union { unsigned u[4]; pf_h2 h[4]; pf_v8h v; } t;
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-#if defined(LLMK_PF_EXP) && (LLMK_PF_EXP & 4)
-                    asm volatile("" :: "v"(Bc[g]), "v"(A[r]));
-#else
-                    acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], Bc[g], acc[r][g], 0, 0, 0);
-#endif
+                    for (int d = 0; d < 2; ++d) {
+                        const unsigned q = ((d ? wq[CUR][r * NJ + j].y : wq[CUR][r * NJ + j].x) >> sh) & 0x0F0F0F0Fu;
+                        t.u[2 * d] = __builtin_amdgcn_perm(0x64646464u, q, 0x04010400u);        // halves 0x64nn = 1024 + n of bytes 0, 1
+                        t.u[2 * d + 1] = __builtin_amdgcn_perm(0x64646464u, q, 0x04030402u);    // ... of bytes 2, 3
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) t.h[d] = t.h[d] - (pf_h2){(_Float16)1032.0f, (_Float16)1032.0f};
+                    A[r] = t.v;
                 }
+                if constexpr (XR2) xstore(std::integral_constant<int, PAR ^ 1>(), buf ^ 1, j * XV / 2, (j + 1) * XV / 2);     // X(S+1) from xr[(S+1)&1]
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    pf_v4f D[NR][GH];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int gi = 0; gi < GH; ++gi)
+                            if (hf * GH + gi < NG) D[r][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], B0[hf * GH + gi], (pf_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int gi = 0; gi < GH; ++gi)
+                            if (hf * GH + gi < NG) D[r][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], B1[hf * GH + gi], D[r][gi], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+#pragma unroll
+                        for (int gi = 0; gi < GH; ++gi)
+                            if (hf * GH + gi < NG) {
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) acc[r][hf * GH + gi][v] = fmaf(sc[r][v], D[r][gi][v], acc[r][hf * GH + gi][v]);
+                            }
+                    __builtin_amdgcn_sched_barrier(0);      // (or the scheduler starts the other half early and all 64 sums are live)
+                }
+                if (j == 0) { bread(B0, buf, 2); bread(B1, buf, 3); }
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                pf_v8h (&Bc)[NG] = (p & 1) ? B1 : B0;
+                pf_v8h (&Bn)[NG] = (p & 1) ? B0 : B1;
+                if (p < 3) bread(Bn, buf, p + 1);
+                xstore(std::integral_constant<int, PAR ^ 1>(), buf ^ 1, p * XV / 4, (p + 1) * XV / 4);     // X(S+1) from xr[(S+1)&1]
+                pf_v8h A[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) A[r] = *reinterpret_cast<const pf_v8h*>(&w[CUR][r * NJ + (p >> 1)]);
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], Bc[g], acc[r][g], 0, 0, 0);
+            }
         }
-#if defined(LLMK_PF_EXP) && (LLMK_PF_EXP & 16)
-        if (S < 0)
-#endif
         wload(nxt);
         if (++ck == a.nk || S == nsteps - 1) {
             const int slot = (int)blockIdx.x - pf_first_block(cs, a.nk, a.U);
@@ -500,7 +576,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     pf_prologue<0, ST - 1>(wload);
     xload(std::integral_constant<int, 0>());
     xstore(std::integral_constant<int, 0>(), 0, 0, XV);
-    xload(std::integral_constant<int, 1>());
+    xload(std::integral_constant<int, XR2 ? 1 : 0>());
     __syncthreads();
     PF_STAMP(1);
     // two ring cycles per trip: the loop's back edge costs a drain of the weight prefetch (hipcc's waitcnt pass merges the
