@@ -592,9 +592,13 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
 // is priced with the measured step times (tests/host_tools/pf_trace.py, round 2): a step of NR row groups at 128
 // positions keeps a SIMD's matrix core busy for 1.7*NR us per resident wave, plus ~0.5 us of barrier / staging per step;
 // the first weights take ~4 us to arrive and every partial tile costs a write and a read in the epilogue.
+// measured step times of pf_gemm_h_kernel at 128 positions, one / two row groups per wave (us; tests/host_tools/pf_trace.py
+// --type f16 | q4_0, round 3): the activation tile costs the same either way
 #ifndef LLMK_PF_H_STEP1
-#define LLMK_PF_H_STEP1 0.55         // measured step times of pf_gemm_h_kernel at 128 positions, one / two row groups per wave (us)
-#define LLMK_PF_H_STEP2 0.80
+#define LLMK_PF_H_STEP1 1.00
+#define LLMK_PF_H_STEP2 1.32
+#define LLMK_PF_HQ_STEP1 1.20
+#define LLMK_PF_HQ_STEP2 1.92
 #endif
 struct PfPlan { int nr, nk, total, U, grid; };
 PfPlan pf_plan(const llmk_ctx* c, int rows, int K, int T = PF_TMAX) {
@@ -606,16 +610,13 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K, int T = PF_TMAX) {
     // Four row groups per wave (128 accumulator registers, 256-row strips): step 8.2 us for 512 MFMAs -- 87 % of the matrix rate
     // in the loop against 84 % with two, eaten by the coarser units (TinyLlama w1|w3 67.9 vs 62.2 us; Llama-2-7B q4_0 +0.4 %).
     // f16 weights on the f16 instruction (pf_gemm_h_kernel): a step is 8x less matrix work
-    static const double step_f32[2] = {2.45, 4.25}, step_h[2] = {LLMK_PF_H_STEP1, LLMK_PF_H_STEP2};
-    const double* step_us = c->pf_hm ? step_h : step_f32;
+    static const double step_f32[2] = {2.45, 4.25}, step_h[2] = {LLMK_PF_H_STEP1, LLMK_PF_H_STEP2}, step_hq[2] = {LLMK_PF_HQ_STEP1, LLMK_PF_HQ_STEP2};
+    const double* step_us = !c->pf_hm ? step_f32 : c->cfg.weight_type == LLMK_TYPE_Q4_0 ? step_hq : step_h;
     PfPlan best{};
     double best_t = 1e30;
     for (int nr = 1; nr <= 2; ++nr) {
         const int sr = 64 * nr;
         if (nr == 2 && rows % sr) continue;
-        // q4_0 on the f16 instruction: the scaled accumulation runs on the VALU, which cannot read accumulation registers --
-        // two row groups at 112+ positions do not fit the 256 architectural VGPRs (pf_gemm_h_kernel<7|8, 2, q4_0> spills)
-        if (nr == 2 && c->pf_hm && c->cfg.weight_type == LLMK_TYPE_Q4_0 && (T + 15) / 16 > 6) continue;
 #ifdef LLMK_PF_TRACE
         if (const char* f = getenv("LLMK_PF_PLAN"))          // debug build: force the row groups per wave (when the shape allows it)
             if (atoi(f) != nr && !(rows % 128)) continue;
@@ -626,7 +627,10 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K, int T = PF_TMAX) {
         p.total = (rows + sr - 1) / sr * p.nk;
         p.U = (p.total + c->n_cu - 1) / c->n_cu;
         p.grid = (p.total + p.U - 1) / p.U;
-        const double t = 4.0 + p.U * step_us[nr - 1] + 0.15 * ((p.nk - 1) / p.U + 1);
+        // before the first step and after the last: the f16-instruction kernel's ring takes 2.8 / 4.6 us to fill and its last
+        // step (the flush) runs 0.5 / 1.4 us over, one / two row groups (block timelines, round 3); the f32 kernel: ~4 us
+        const double fixed = !c->pf_hm ? 4.0 : nr == 1 ? 3.3 : 6.0;
+        const double t = fixed + p.U * step_us[nr - 1] + 0.15 * ((p.nk - 1) / p.U + 1);
         if (t < best_t) { best_t = t; best = p; }
     }
     return best;

@@ -334,13 +334,11 @@ __device__ __forceinline__ void pf_ring(F& step, int s, int nsteps) {      // (N
         }
     }
 }
-// q4_0 weights (WT_Q4_0) on the same instruction: a 32-column chunk is one block, the A operand is n - 8 as f16 (exact: byte n
-// under 0x64 is the half 1024 + n, minus 1032), the block's products are summed by the matrix core from zero (hi piece,
-// then lo piece) and the block scale d -- per weight ROW, so it cannot ride in an operand -- multiplies the 16 x 16 result
-// into the accumulators: (sum_k (n_k - 8) x_k) d instead of the reference's sum_k ((n_k - 8) d) x_k, the same real number
-// with one rounding of d's product fewer per term (parity bar 1e-4 on logits, as for every other reordering of this path).
-// Lane (row li, k group kg) takes the low (kg < 2) or high nibbles of bytes 8 (kg & 1) .. + 7 of the block = its elements
-// 16 (kg >> 1) + 8 (kg & 1) .. + 7 = the 8 consecutive columns of slot kg: the activation side is the f16 kernel's.
+// q4_0 weights (WT_Q4_0) on the same instruction: a 32-column chunk is one block; lane (row li, k group kg) takes the low
+// (kg < 2) or high nibbles of bytes 8 (kg & 1) .. + 7 of the block = its elements 16 (kg >> 1) + 8 (kg & 1) .. + 7 = the 8
+// consecutive columns of slot kg (the activation side is the f16 kernel's), turns them into the reference's f32 weights
+// (n - 8) d exactly (n - 8 as f16: byte n under 0x64 is the half 1024 + n, minus 1032; times the row's f16 block scale through
+// v_fma_mix_f32) and feeds each as two f16 pieces: see the step.
 template <int NG, int NR, int WT = WT_F16>
 __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag) {
     constexpr int NW = PF_WAVES, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
@@ -381,9 +379,8 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     pf_v2u wq[Q4 ? ST : 1][Q4 ? NR * NJ : 1];        // q4_0: the lane's 8 nibble bytes per block and row group
     unsigned wd[Q4 ? ST : 1][Q4 ? NR : 1];          //       the row's two block scales (f16 pair)
     // activations of two steps in flight: requested a whole step before they are published, published in the shadow of the
-    // matrix instructions.  (q4_0, two row groups, 112+ positions: the register file has room for one; published at the
-    // step's top, re-requested at once.)
-    constexpr bool XR2 = !(Q4 && NR == 2 && NG > 6);
+    // matrix instructions
+    constexpr bool XR2 = true;
     pf_v4f xr[XR2 ? 2 : 1][XV];
 #ifdef LLMK_PF_TRACE
     unsigned long long* tr = a.trace + (size_t)blockIdx.x * 20;
@@ -475,62 +472,67 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
         pf_v8h B0[NG], B1[NG];
         bread(B0, buf, 0);
         if constexpr (Q4) {
-            // per block j: hi fragments in B0, lo in B1; positions in two halves so that the block's unscaled sums D live in
-            // 32 registers, not 64: D = A.hi (from zero), D += A.lo, acc += d D
-            bread(B1, buf, 1);
-            constexpr int GH = (NG + 1) / 2;
+            // q4_0: the weight (n - 8) d is an exact f32 (4 x 11 significand bits) and splits EXACTLY into two f16 pieces,
+            // wh + wl (15 bits: 11 + the rest; the tail of a weight below 2^-9 that falls under the f16 subnormal step,
+            // 2^-24, is dropped) -- so a chunk is three instructions into the SAME accumulators, wh.xhi + wl.xhi + wh.xlo
+            // (wl.xlo is 2^-22 of the term), with the reference's own weight values and no arithmetic on the accumulators
+            // outside the matrix core: they can live in accumulation registers, and two row groups per wave fit.  (First
+            // version, round 3: n - 8 as the A operand and the block scale applied to each block's 16x16 sum by the VALU --
+            // 64 accumulators + the sums in architectural VGPRs, one row group per wave at 128 positions.)
+            // Per pair of weights: two v_fma_mix_f32 (f16 n - 8 times f16 d, exact), v_cvt_pkrtz (wh), two v_fma_mix_f32
+            // (w - wh), v_cvt_pkrtz (wl).
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float sc[NR][4];
-                pf_v8h A[NR];
+                pf_v8h Wh[NR], Wl[NR];
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    // the block scales in the accumulators' layout: register v of a lane holds weight row 4 kg + v, whose
-                    // scale pair lane 4 kg + v loaded (its A row)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const unsigned dp = (unsigned)__shfl((int)wd[CUR][r], 4 * kg + v, WAVE);
-                        const __half2 h2 = *reinterpret_cast<const __half2*>(&dp);
-                        sc[r][v] = j ? __high2float(h2) : __low2float(h2);
-                    }
                     typedef _Float16 pf_h2 __attribute__((ext_vector_type(2)));
-                    const unsigned sh = (kg >> 1) * 4;
-                    union { unsigned u[4]; pf_h2 h[4]; pf_v8h v; } t;
+                    typedef __fp16 pf_g2 __attribute__((ext_vector_type(2)));
+                    const unsigned sh = (kg >> 1) * 4, dp = wd[CUR][r];
+                    union { unsigned u[4]; pf_h2 h[4]; } t;
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
                         const unsigned q = ((d ? wq[CUR][r * NJ + j].y : wq[CUR][r * NJ + j].x) >> sh) & 0x0F0F0F0Fu;
                         t.u[2 * d] = __builtin_amdgcn_perm(0x64646464u, q, 0x04010400u);        // halves 0x64nn = 1024 + n of bytes 0, 1
                         t.u[2 * d + 1] = __builtin_amdgcn_perm(0x64646464u, q, 0x04030402u);    // ... of bytes 2, 3
                     }
+                    union { unsigned u[4]; pf_g2 g[4]; pf_v8h v; } H, L;
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) t.h[d] = t.h[d] - (pf_h2){(_Float16)1032.0f, (_Float16)1032.0f};
-                    A[r] = t.v;
+                    for (int d = 0; d < 4; ++d) {
+                        t.h[d] = t.h[d] - (pf_h2){(_Float16)1032.0f, (_Float16)1032.0f};       // n - 8
+                        float w0, w1, r0, r1;
+                        if (j == 0)
+                            asm("v_fma_mix_f32 %0, %2, %3, 0 op_sel_hi:[1,1,0]\n\t"
+                                "v_fma_mix_f32 %1, %2, %3, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=&v"(w0), "=&v"(w1) : "v"(t.u[d]), "v"(dp));
+                        else
+                            asm("v_fma_mix_f32 %0, %2, %3, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n\t"
+                                "v_fma_mix_f32 %1, %2, %3, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=&v"(w0), "=&v"(w1) : "v"(t.u[d]), "v"(dp));
+                        H.g[d] = __builtin_amdgcn_cvt_pkrtz(w0, w1);
+                        asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+                            "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(r0), "=&v"(r1) : "v"(H.u[d]), "v"(w0), "v"(w1));
+                        L.g[d] = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+                    }
+                    Wh[r] = H.v;
+                    Wl[r] = L.v;
                 }
-                if constexpr (XR2) xstore(std::integral_constant<int, PAR ^ 1>(), buf ^ 1, j * XV / 2, (j + 1) * XV / 2);     // X(S+1) from xr[(S+1)&1]
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    pf_v4f D[NR][GH];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r)
-#pragma unroll
-                        for (int gi = 0; gi < GH; ++gi)
-                            if (hf * GH + gi < NG) D[r][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], B0[hf * GH + gi], (pf_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                for (int pp = 0; pp < 2; ++pp) {
+                    const int p = 2 * j + pp;
+                    pf_v8h (&Bc)[NG] = (p & 1) ? B1 : B0;
+                    pf_v8h (&Bn)[NG] = (p & 1) ? B0 : B1;
+                    if (p < 3) bread(Bn, buf, p + 1);
+                    if constexpr (XR2) xstore(std::integral_constant<int, PAR ^ 1>(), buf ^ 1, p * XV / 4, (p + 1) * XV / 4);     // X(S+1) from xr[(S+1)&1]
 #pragma unroll
                     for (int r = 0; r < NR; ++r)
 #pragma unroll
-                        for (int gi = 0; gi < GH; ++gi)
-                            if (hf * GH + gi < NG) D[r][gi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[r], B1[hf * GH + gi], D[r][gi], 0, 0, 0);
+                        for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wh[r], Bc[g], acc[r][g], 0, 0, 0);
+                    if (pp == 0) {
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
+                        for (int r = 0; r < NR; ++r)
 #pragma unroll
-                        for (int gi = 0; gi < GH; ++gi)
-                            if (hf * GH + gi < NG) {
-#pragma unroll
-                                for (int v = 0; v < 4; ++v) acc[r][hf * GH + gi][v] = fmaf(sc[r][v], D[r][gi][v], acc[r][hf * GH + gi][v]);
-                            }
-                    __builtin_amdgcn_sched_barrier(0);      // (or the scheduler starts the other half early and all 64 sums are live)
+                            for (int g = 0; g < NG; ++g) acc[r][g] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wl[r], Bc[g], acc[r][g], 0, 0, 0);
+                    }
                 }
-                if (j == 0) { bread(B0, buf, 2); bread(B1, buf, 3); }
             }
         } else {
 #pragma unroll

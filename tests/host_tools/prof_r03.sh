@@ -52,4 +52,15 @@ rm -rf /tmp/st_pf
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_pf -- python $ROOT/bench.py --prefill 512 > /dev/null 2> /tmp/st_pf.err || tail -3 /tmp/st_pf.err
 reduce_stats /tmp/st_pf $OUT/prefill512_kernel_stats.csv
 timeout 300 python $ROOT/bench.py --prefill 512 --shape llama2-7b --type q4_0 > $OUT/prefill512_llama2-7b_q4_0_bench.json 2>/dev/null; cut -c1-300 $OUT/prefill512_llama2-7b_q4_0_bench.json
+# f16 / q4_0 weights: the f16 matrix instruction (default) beside the f32 instruction (LLMK_PF_F32_MFMA=1), same box
+for t in f16 q4_0; do
+  timeout 300 python $ROOT/bench.py --prefill 512 --type $t > $OUT/prefill512_tinyllama_${t}_bench.json 2>/dev/null; cut -c1-200 $OUT/prefill512_tinyllama_${t}_bench.json
+  LLMK_PF_F32_MFMA=1 timeout 300 python $ROOT/bench.py --prefill 512 --type $t > $OUT/prefill512_tinyllama_${t}_f32_instruction_bench.json 2>/dev/null; cut -c1-200 $OUT/prefill512_tinyllama_${t}_f32_instruction_bench.json
+done
+LLMK_PF_F32_MFMA=1 timeout 300 python $ROOT/bench.py --prefill 512 --shape llama2-7b --type q4_0 > $OUT/prefill512_llama2-7b_q4_0_f32_instruction_bench.json 2>/dev/null; cut -c1-200 $OUT/prefill512_llama2-7b_q4_0_f32_instruction_bench.json
+rm -rf /tmp/st_pfh
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_pfh -- python $ROOT/bench.py --prefill 512 --type f16 > /dev/null 2> /tmp/st_pfh.err || tail -3 /tmp/st_pfh.err
+reduce_stats /tmp/st_pfh $OUT/prefill512_tinyllama_f16_kernel_stats.csv
+echo "=== KV-length curve"
+for a in "" "--type f16" "--shape llama2-7b"; do timeout 300 python $ROOT/tests/host_tools/tk_curve.py $a 1 256 512 1024 2048 2>&1 | tail -1; done | tee $OUT/kv_length_curve.txt
 ls -la $OUT
