@@ -233,11 +233,11 @@ def prefill_line(a):
     ms, wbytes = m.time_kernel(7, 2 * shape.n_layers)
     flop = 2.0 * 128 * 2 * shape.hidden_dim * shape.emb_dim
     kname = f"pf_gemm_kernel<8, {a.type}>"
-    # f16 and q4_0 weights run on v_mfma_f32_16x16x32_f16 (prefill.h pf_gemm_h_kernel, activations as two f16 pieces) unless
+    # all three weight types run on v_mfma_f32_16x16x32_f16 (prefill.h pf_gemm_h_kernel, activations -- and f32 / q4_0 weights -- as two f16 pieces) unless
     # LLMK_PF_F32_MFMA=1: 256 flop per 2-byte weight at 128 positions is below that instruction's ridge (2,500 TFLOP/s / 8 TB/s
     # = 312 flop/B; q4_0: 455 flop/B, above it, but the kernel's own limit is its VALU work), so the kernel is priced against
     # HBM: weight bytes / launch
-    hm = a.type in ("f16", "q4_0") and os.environ.get("LLMK_PF_F32_MFMA", "0")[:1] != "1"
+    hm = os.environ.get("LLMK_PF_F32_MFMA", "0")[:1] != "1"
     out = {"metric": f"prompt tokens/sec {a.shape} prefill", "value": n / dt, "unit": "tokens/s", "n_gpus": 1,
            "steps": reps, "warmup": max(1, a.warmup // 4), "ms_per_step": 1000.0 * dt, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": a.type, "data": "synthetic",
@@ -251,11 +251,12 @@ def prefill_line(a):
                         "flop_per_launch": flop, "weight_bytes_per_launch": wbytes,
                         "hbm_GBps": wbytes / (ms * 1e-3) / 1e9}}
     if hm:
-        wdesc = "f16 weights as they are" if a.type == "f16" else "q4_0 nibbles as the exact f16 integers n - 8, block scale applied to each block's 16x16 sum in f32"
+        wdesc = {"f16": "f16 weights as they are", "q4_0": "q4_0 weights (n - 8) d formed exactly in registers, as two exact f16 pieces",
+                 "f32": "f32 weights as two f16 pieces (|error| <= 2^-20 |w|)"}[a.type]
         out["config"]["arithmetic"] = (wdesc + " x f32 activations as two f16 pieces (hi + lo, |error| <= 2^-20 |x|) on "
                                        "v_mfma_f32_16x16x32_f16, exact products, f32 accumulate")
         gbps = wbytes / (ms * 1e-3) / 1e9
-        out["roofline"].update({"bound": "hbm", "kernel": f"pf_gemm_h_kernel<8, {2 if a.type == 'f16' else 1}, {a.type}> (w1|w3, 128 positions, v_mfma_f32_16x16x32_f16)",
+        out["roofline"].update({"bound": "hbm", "kernel": f"pf_gemm_h_kernel<8, 2, {a.type}> (w1|w3, 128 positions, v_mfma_f32_16x16x32_f16)",
                                 "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
                                 "traffic": pmc_traffic("pf_gemm_h_kernel", "prefill_w13", a.type), "tflops": flop / (ms * 1e-3) / 1e12})
     print(json.dumps(out))

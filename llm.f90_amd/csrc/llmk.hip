@@ -114,7 +114,7 @@ struct llmk_ctx {
     int* pf_tok = nullptr;
     hipEvent_t pf_start = nullptr;         // tokens are on the device (and everything before the prefill call is done)
     bool pf_ready = false;                 // pf_setup ran to its end
-    bool pf_hm = false;                    // f16 / q4_0 weights: GEMMs on v_mfma_f32_16x16x32_f16 with the activations as two f16 pieces (prefill.h)
+    bool pf_hm = false;                    // GEMMs on v_mfma_f32_16x16x32_f16, activations (and f32 / q4_0 weights) as two f16 pieces (prefill.h)
     unsigned* pf_flag = nullptr;           // device word: an activation did not fit f16 (the call is redone on the f32 instruction)
 };
 typedef llmk_ctx::PfLane PfLane;
@@ -611,7 +611,7 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K, int T = PF_TMAX) {
     // in the loop against 84 % with two, eaten by the coarser units (TinyLlama w1|w3 67.9 vs 62.2 us; Llama-2-7B q4_0 +0.4 %).
     // f16 weights on the f16 instruction (pf_gemm_h_kernel): a step is 8x less matrix work
     static const double step_f32[2] = {2.45, 4.25}, step_h[2] = {LLMK_PF_H_STEP1, LLMK_PF_H_STEP2}, step_hq[2] = {LLMK_PF_HQ_STEP1, LLMK_PF_HQ_STEP2};
-    const double* step_us = !c->pf_hm ? step_f32 : c->cfg.weight_type == LLMK_TYPE_Q4_0 ? step_hq : step_h;
+    const double* step_us = !c->pf_hm ? step_f32 : c->cfg.weight_type == LLMK_TYPE_F16 ? step_h : step_hq;   // (f32 weights: three instructions per chunk, as q4_0)
     PfPlan best{};
     double best_t = 1e30;
     for (int nr = 1; nr <= 2; ++nr) {
@@ -733,7 +733,7 @@ hipError_t pf_prepare(const llmk_ctx* c) {
     switch (c->cfg.weight_type) {
         case LLMK_TYPE_Q4_0: HIPRET(pf_gemm_prepare<WT_Q4_0>()); HIPRET(pf_gemm_h_prepare<WT_Q4_0>()); break;
         case LLMK_TYPE_F16: HIPRET(pf_gemm_prepare<WT_F16>()); HIPRET(pf_gemm_h_prepare<WT_F16>()); break;
-        default: HIPRET(pf_gemm_prepare<WT_F32>()); break;
+        default: HIPRET(pf_gemm_prepare<WT_F32>()); HIPRET(pf_gemm_h_prepare<WT_F32>()); break;
     }
     const int smem = (int)pf_attn_smem(c->hs);
     switch (c->hs) {
@@ -751,7 +751,8 @@ hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, con
     if (c->pf_hm) {
         constexpr size_t smem_h = pf_gemm_h_smem<NG, NR>();
         if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_Q4_0>), grid, block, smem_h, w.stream, a, c->pf_flag);
-        else hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F16>), grid, block, smem_h, w.stream, a, c->pf_flag);
+        else if (c->cfg.weight_type == LLMK_TYPE_F16) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F16>), grid, block, smem_h, w.stream, a, c->pf_flag);
+        else hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F32>), grid, block, smem_h, w.stream, a, c->pf_flag);
         return hipGetLastError();
     }
     if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
@@ -1219,7 +1220,7 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
         return LLMK_OK;
     }
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (!c->pf_ready) c->pf_hm = (c->cfg.weight_type == LLMK_TYPE_F16 || c->cfg.weight_type == LLMK_TYPE_Q4_0) && !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
+    if (!c->pf_ready) c->pf_hm = !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
     rc = pf_setup(c);
     if (rc) return rc;
     std::vector<int> tok0(tokens, tokens + n);

@@ -342,9 +342,9 @@ __device__ __forceinline__ void pf_ring(F& step, int s, int nsteps) {      // (N
 template <int NG, int NR, int WT = WT_F16>
 __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag) {
     constexpr int NW = PF_WAVES, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
-    constexpr bool Q4 = WT == WT_Q4_0;
-    static_assert(WT == WT_F16 || WT == WT_Q4_0, "f16 or q4_0 weights");
-    constexpr int ST = Q4 ? 4 : PF_HST;      // (q4_0: longer steps, and the scaled accumulation wants the registers)
+    constexpr bool Q4 = WT == WT_Q4_0, F32W = WT == WT_F32;
+    // ring depth: f16 six 16-byte stages; q4_0 four (longer steps); f32 four / three (a stage is 32 bytes per chunk and row group)
+    constexpr int ST = Q4 ? 4 : F32W ? (NR == 1 ? 4 : 3) : PF_HST;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     _Float16* xh = reinterpret_cast<_Float16*>(pf_smem);                                  // [2 buffers][hi, lo][TP][PF_HP]
     float* tb = reinterpret_cast<float*>(pf_smem + (size_t)4 * TP * PF_HP * sizeof(_Float16));   // [TP][SR + PF_TPAD]
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     const int u0 = blockIdx.x * a.U, nsteps = min(a.U, a.total - u0);
     if (nsteps <= 0) return;
     const int li = lane & 15, kg = lane >> 4;
-    const size_t rowb = Q4 ? (size_t)a.RS : (size_t)a.K * 2;
-    const char* wbase = static_cast<const char*>(a.W) + (Q4 ? (size_t)(kg & 1) * 8 : (size_t)kg * 16);
-    constexpr int STEPB = Q4 ? 32 : PF_KSTEP * 2;           // weight bytes per row per step
+    const size_t rowb = Q4 ? (size_t)a.RS : (size_t)a.K * (F32W ? 4 : 2);
+    const char* wbase = static_cast<const char*>(a.W) + (Q4 ? (size_t)(kg & 1) * 8 : (size_t)kg * (F32W ? 32 : 16));
+    constexpr int STEPB = Q4 ? 32 : PF_KSTEP * (F32W ? 4 : 2);           // weight bytes per row per step
     int cs = u0 / a.nk, ck = u0 % a.nk;
     int ws = cs, wk = ck, wi = 0, xk = ck, xi = 0;
     const char* wp = wbase + (size_t)min(ws * SR + wid * (16 * NR) + li, a.rows - 1) * rowb + (size_t)wk * STEPB;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
         for (int g = 0; g < NG; ++g) acc[r][g] = (pf_v4f){0.f, 0.f, 0.f, 0.f};
     // a stage: f16 -- 16 bytes per chunk and row group
     typedef unsigned pf_v2u __attribute__((ext_vector_type(2)));
-    float4 w[Q4 ? 1 : ST][Q4 ? 1 : NR * NJ];
+    float4 w[Q4 ? 1 : ST][Q4 ? 1 : NR * NJ * (F32W ? 2 : 1)];     // f32: a lane's 8 columns of a chunk are two 16-byte loads
     pf_v2u wq[Q4 ? ST : 1][Q4 ? NR * NJ : 1];        // q4_0: the lane's 8 nibble bytes per block and row group
     unsigned wd[Q4 ? ST : 1][Q4 ? NR : 1];          //       the row's two block scales (f16 pair)
     // activations of two steps in flight: requested a whole step before they are published, published in the shadow of the
@@ -399,6 +399,9 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
                 wq[Q][q] = __builtin_nontemporal_load(reinterpret_cast<const pf_v2u*>(rp + (q % NJ) * 16));
                 if (q % NJ == 0)        // the scales of blocks 2 wk and 2 wk + 1 of this row: K/2 nibble bytes in, 2 bytes per block
                     wd[Q][q / NJ] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rp - (size_t)(kg & 1) * 8 - (size_t)wk * 32 + (a.K >> 1) + (size_t)wk * 4));
+            } else if constexpr (F32W) {
+                w[Q][2 * q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * 128));
+                w[Q][2 * q + 1] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * 128 + 16));
             } else {
                 w[Q][q] = ldg_nt(reinterpret_cast<const float4*>(wp + (size_t)(q / NJ) * 16 * rowb + (q % NJ) * 64));
             }
@@ -471,7 +474,9 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
         }
         pf_v8h B0[NG], B1[NG];
         bread(B0, buf, 0);
-        if constexpr (Q4) {
+        if constexpr (Q4 || F32W) {
+            // f32 weights: w = wh + wl, two f16 pieces (|w - wh - wl| <= 2^-20 |w|, as for the activations; a weight of
+            // magnitude >= 65504 raises the same flag), three instructions per chunk: wh.xhi + wl.xhi + wh.xlo.
             // q4_0: the weight (n - 8) d is an exact f32 (4 x 11 significand bits) and splits EXACTLY into two f16 pieces,
             // wh + wl (15 bits: 11 + the rest; the tail of a weight below 2^-9 that falls under the f16 subnormal step,
             // 2^-24, is dropped) -- so a chunk is three instructions into the SAME accumulators, wh.xhi + wl.xhi + wh.xlo
@@ -488,25 +493,36 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
                 for (int r = 0; r < NR; ++r) {
                     typedef _Float16 pf_h2 __attribute__((ext_vector_type(2)));
                     typedef __fp16 pf_g2 __attribute__((ext_vector_type(2)));
-                    const unsigned sh = (kg >> 1) * 4, dp = wd[CUR][r];
                     union { unsigned u[4]; pf_h2 h[4]; } t;
+                    unsigned dp = 0;
+                    if constexpr (Q4) {
+                        const unsigned sh = (kg >> 1) * 4;
+                        dp = wd[CUR][r];
 #pragma unroll
-                    for (int d = 0; d < 2; ++d) {
-                        const unsigned q = ((d ? wq[CUR][r * NJ + j].y : wq[CUR][r * NJ + j].x) >> sh) & 0x0F0F0F0Fu;
-                        t.u[2 * d] = __builtin_amdgcn_perm(0x64646464u, q, 0x04010400u);        // halves 0x64nn = 1024 + n of bytes 0, 1
-                        t.u[2 * d + 1] = __builtin_amdgcn_perm(0x64646464u, q, 0x04030402u);    // ... of bytes 2, 3
+                        for (int d = 0; d < 2; ++d) {
+                            const unsigned q = ((d ? wq[CUR][r * NJ + j].y : wq[CUR][r * NJ + j].x) >> sh) & 0x0F0F0F0Fu;
+                            t.u[2 * d] = __builtin_amdgcn_perm(0x64646464u, q, 0x04010400u);        // halves 0x64nn = 1024 + n of bytes 0, 1
+                            t.u[2 * d + 1] = __builtin_amdgcn_perm(0x64646464u, q, 0x04030402u);    // ... of bytes 2, 3
+                        }
                     }
                     union { unsigned u[4]; pf_g2 g[4]; pf_v8h v; } H, L;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        t.h[d] = t.h[d] - (pf_h2){(_Float16)1032.0f, (_Float16)1032.0f};       // n - 8
                         float w0, w1, r0, r1;
+                        if constexpr (F32W) {
+                            const float4& wv = w[CUR][2 * (r * NJ + j) + d / 2];
+                            w0 = (d & 1) ? wv.z : wv.x;
+                            w1 = (d & 1) ? wv.w : wv.y;
+                            amax = fmaxf(fmaxf(amax, fabsf(w0)), fabsf(w1));
+                        } else {
+                        t.h[d] = t.h[d] - (pf_h2){(_Float16)1032.0f, (_Float16)1032.0f};       // n - 8
                         if (j == 0)
                             asm("v_fma_mix_f32 %0, %2, %3, 0 op_sel_hi:[1,1,0]\n\t"
                                 "v_fma_mix_f32 %1, %2, %3, 0 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=&v"(w0), "=&v"(w1) : "v"(t.u[d]), "v"(dp));
                         else
                             asm("v_fma_mix_f32 %0, %2, %3, 0 op_sel:[0,1,0] op_sel_hi:[1,1,0]\n\t"
                                 "v_fma_mix_f32 %1, %2, %3, 0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=&v"(w0), "=&v"(w1) : "v"(t.u[d]), "v"(dp));
+                        }
                         H.g[d] = __builtin_amdgcn_cvt_pkrtz(w0, w1);
                         asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
                             "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(r0), "=&v"(r1) : "v"(H.u[d]), "v"(w0), "v"(w1));
