@@ -190,9 +190,9 @@ def test_prefill_f16_matches_oracle_on_decoded_weights(shape, n, gguf):
     m.close()
 
 
-@pytest.mark.parametrize("wtype", [1, 2], ids=["f16", "q4_0"])
+@pytest.mark.parametrize("wtype", [0, 1, 2], ids=["f32", "f16", "q4_0"])
 def test_prefill_range_guard_redoes_the_call_on_the_f32_instruction(wtype, gguf):
-    """f16 / q4_0 weights multiply on v_mfma_f32_16x16x32_f16 with the f32 activation as two f16 pieces (prefill.h
+    """The GEMMs multiply on v_mfma_f32_16x16x32_f16 with the f32 activation as two f16 pieces (prefill.h
     pf_gemm_h_kernel): an activation of magnitude >= 65504 fits neither piece.  FFN norm gains of 1e5 put the w1|w3 input
     at ~1e5 and the w2 input at ~1e9 (attention inputs stay normalised, so nothing chaotic happens to the softmax): without
     the guard hi would clamp and the logits would be garbage; with it the call is redone on the f32 instruction and matches
@@ -203,7 +203,7 @@ def test_prefill_range_guard_redoes_the_call_on_the_f32_instruction(wtype, gguf)
     rng = np.random.default_rng(11)
     n = 37
     prompt = [2] + (rng.integers(3, s.vocab_size, n - 1) + 1).tolist()
-    o = Oracle(fw.as_f32(), "omp")
+    o = Oracle(fw.as_f32() if wtype else fw, "omp")
     for pos, tok in enumerate(prompt, 1):
         ol = o.forward(tok, pos)
     assert np.all(np.isfinite(ol))
