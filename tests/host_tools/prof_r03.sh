@@ -53,7 +53,7 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_pf -
 reduce_stats /tmp/st_pf $OUT/prefill512_kernel_stats.csv
 timeout 300 python $ROOT/bench.py --prefill 512 --shape llama2-7b --type q4_0 > $OUT/prefill512_llama2-7b_q4_0_bench.json 2>/dev/null; cut -c1-300 $OUT/prefill512_llama2-7b_q4_0_bench.json
 # f16 / q4_0 weights: the f16 matrix instruction (default) beside the f32 instruction (LLMK_PF_F32_MFMA=1), same box
-for t in f16 q4_0; do
+for t in f32 f16 q4_0; do
   timeout 300 python $ROOT/bench.py --prefill 512 --type $t > $OUT/prefill512_tinyllama_${t}_bench.json 2>/dev/null; cut -c1-200 $OUT/prefill512_tinyllama_${t}_bench.json
   LLMK_PF_F32_MFMA=1 timeout 300 python $ROOT/bench.py --prefill 512 --type $t > $OUT/prefill512_tinyllama_${t}_f32_instruction_bench.json 2>/dev/null; cut -c1-200 $OUT/prefill512_tinyllama_${t}_f32_instruction_bench.json
 done
