@@ -15,9 +15,16 @@ def test_persistent_kernels_do_not_spill():
     instruction inside a loop, and at most 32 bytes of scratch at all (the f32 kernel currently keeps one 16-byte value
     across its straight-line classifier tail: one store, one reload per token, measured faster than the spill-free
     neighbours of the same schedule -- DESIGN.md section 3b)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_tools", "tk_resources.py")], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_tools", "tk_resources.py"), "--all"], capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    # the prefill GEMMs on the f16 matrix instruction hold a ring of weight stages, two activation stages and 64 accumulators
+    # per wave in (unified) registers: they must not spill at all (a first q4_0 version did: prefill.h)
+    gemm = [l for l in r.stdout.splitlines() if "pf_gemm_h_kernel" in l]
+    assert len(gemm) >= 48, len(gemm)
+    for l in gemm:
+        m = re.search(r"scratch\s+(\d+)", l)
+        assert m and int(m.group(1)) == 0, l
     rows = [l for l in r.stdout.splitlines() if "token_kernel" in l or "tk2" in l]
     assert len(rows) >= 5, r.stdout
     for l in rows:
