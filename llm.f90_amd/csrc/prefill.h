@@ -6,8 +6,10 @@
 // :615-616); only the order of the dot-product partial sums differs.
 //
 // The weight GEMMs are the one place on this path where the matrix cores are the right tool: Y[T][rows] =
-// X[T][K] . W[rows][K]^T has 2*T flop per weight word.  v_mfma_f32_16x16x4_f32 keeps full f32 operands
-// (parity bar: 1e-4 relative on logits), 256 flop/clk/CU.
+// X[T][K] . W[rows][K]^T has 2*T flop per weight word.  Default since round 3: pf_gemm_h_kernel (further down) --
+// v_mfma_f32_16x16x32_f16 with every f32 operand fed as two f16 pieces, exact products, 16x the products per clock.
+// pf_gemm_kernel (v_mfma_f32_16x16x4_f32, full f32 operands, 256 flop/clk/CU) is the path of LLMK_PF_F32_MFMA=1 and of
+// prompts whose activations exceed the f16 range.  Parity bar either way: 1e-4 relative on logits.
 //
 // pf_gemm: 4 waves per block; wave w owns weight rows strip*64+16w .. +15 of the block's units, all four share the
 // units' activations through LDS (up to 128 tokens x 64 columns per step, double-buffered).
