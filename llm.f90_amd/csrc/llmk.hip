@@ -834,7 +834,7 @@ hipError_t pf_batch(llmk_ctx* c, PfLane& w, const PfLane* prev, const int* tok, 
         // (rmsnorm above) + w1|w3 + SwiGLU                                                :608-616
         HIPRET(gemm(LLMK_W13, 2 * H, w.Xs, E));
         e.rows = 2 * H; e.out = w.HB;
-        hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H + 255) / 256, T), dim3(256), 0, w.stream, e);
+        hipLaunchKernelGGL(pf_epi_swiglu_kernel, dim3((H / 4 + 255) / 256, T), dim3(256), 0, w.stream, e);
         HIPRET(hipGetLastError());
         // x += w2 . hb                                                                    :618-620
         HIPRET(gemm(LLMK_W2, E, w.HB, H));

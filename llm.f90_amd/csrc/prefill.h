@@ -809,6 +809,24 @@ __device__ __forceinline__ float pf_sum(const PfEpiArgs& a, int t, int r) {
     return s;
 }
 
+// the same for four consecutive rows (r % 4 == 0: one strip, one slot count; 16-byte loads): each row's partials still add in
+// slot order
+__device__ __forceinline__ float4 pf_sum4(const PfEpiArgs& a, int t, int r) {
+    const int n = pf_nslots(r >> a.sh, a.nk, a.U);
+    const size_t pitch = (size_t)a.Tp * a.rows;
+    const float* p = a.P + (size_t)t * a.rows + r;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
+    int ks = 0;
+    for (; ks + 4 <= n; ks += 4, p += 4 * pitch) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + pitch),
+                     v2 = *reinterpret_cast<const float4*>(p + 2 * pitch), v3 = *reinterpret_cast<const float4*>(p + 3 * pitch);
+        add(v0); add(v1); add(v2); add(v3);
+    }
+    for (; ks < n; ++ks, p += pitch) add(*reinterpret_cast<const float4*>(p));
+    return s;
+}
+
 // one thread per (token, RoPE pair / V pair)                                          llama2.f90:543-565
 __global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
@@ -835,12 +853,14 @@ __global__ __launch_bounds__(1024) void pf_epi_resid_norm_kernel(PfEpiArgs a, co
     __shared__ float red[16];
     const int t = blockIdx.x, tid = threadIdx.x;
     float ss = 0.f;
-    for (int r = tid; r < a.rows; r += 1024) {
-        const float v = a.out[(size_t)t * a.rows + r] + pf_sum(a, t, r);
-        a.out[(size_t)t * a.rows + r] = v;
+    for (int r = 4 * tid; r < a.rows; r += 4096) {       // rows % 64 == 0 on this path (llmk_prefill)
+        const float4 x = *reinterpret_cast<const float4*>(a.out + (size_t)t * a.rows + r), d = pf_sum4(a, t, r);
+        const float4 v = make_float4(x.x + d.x, x.y + d.y, x.z + d.z, x.w + d.w);
+        *reinterpret_cast<float4*>(a.out + (size_t)t * a.rows + r) = v;
         if (w) {
-            ss = fmaf(v, v, ss);
-            Xs[(size_t)t * a.rows + r] = v * w[r];
+            ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+            const float4 g = *reinterpret_cast<const float4*>(w + r);
+            *reinterpret_cast<float4*>(Xs + (size_t)t * a.rows + r) = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
         }
     }
     if (!w) return;
@@ -855,11 +875,15 @@ __global__ __launch_bounds__(1024) void pf_epi_resid_norm_kernel(PfEpiArgs a, co
 }
 // hb = silu(gate) * up                                                                  :613-616
 __global__ void pf_epi_swiglu_kernel(PfEpiArgs a) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    const int g = 4 * (blockIdx.x * blockDim.x + threadIdx.x), t = blockIdx.y;      // four hidden units per thread (H % 64 == 0)
     if (g >= a.H) return;
-    const float gate = pf_sum(a, t, g) / a.xn[t], up = pf_sum(a, t, g + a.H) / a.xn[t];
-    const float hb = gate * (1.0f / (1.0f + expf(-gate)));
-    a.out[(size_t)t * a.H + g] = hb * up;
+    const float xn = a.xn[t];
+    const float4 gs = pf_sum4(a, t, g), us = pf_sum4(a, t, g + a.H);
+    auto unit = [&](float gsum, float usum) {
+        const float gate = gsum / xn, up = usum / xn;
+        return gate * (1.0f / (1.0f + expf(-gate))) * up;
+    };
+    *reinterpret_cast<float4*>(a.out + (size_t)t * a.H + g) = make_float4(unit(gs.x, us.x), unit(gs.y, us.y), unit(gs.z, us.z), unit(gs.w, us.w));
 }
 
 }  // namespace llmk
