@@ -805,7 +805,7 @@ hipError_t pf_batch(llmk_ctx* c, PfLane& w, const PfLane* prev, const int* tok, 
         }
         HIPRET(gemm(LLMK_WQKV, QKV, w.Xs, E));
         e.rows = QKV; e.out = w.Q; e.kc = kc; e.vc = vc;
-        hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 2 + 255) / 256, T), dim3(256), 0, w.stream, e);
+        hipLaunchKernelGGL(pf_epi_qkv_kernel, dim3((QKV / 4 + 255) / 256, T), dim3(256), 0, w.stream, e);
         HIPRET(hipGetLastError());
         if (!last) HIPRET(hipEventRecord(w.kv[l], w.stream));             // the next batch's attention reads these rows
         if (prev) HIPRET(hipStreamWaitEvent(w.stream, prev->kv[l], 0));   // ... as this one reads the previous batch's

@@ -828,11 +828,8 @@ __device__ __forceinline__ float4 pf_sum4(const PfEpiArgs& a, int t, int r) {
 }
 
 // one thread per (token, RoPE pair / V pair)                                          llama2.f90:543-565
-__global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-    if (p >= a.rows / 2) return;
-    const int r0 = 2 * p, pos = a.pos0 + t;
-    const float a0 = pf_sum(a, t, r0) / a.xn[t], a1 = pf_sum(a, t, r0 + 1) / a.xn[t];
+__device__ __forceinline__ void pf_epi_qkv_pair(const PfEpiArgs& a, int t, int r0, float a0, float a1) {
+    const int pos = a.pos0 + t;
     if (r0 < a.E + a.KV) {
         const int i0 = (r0 < a.E) ? r0 : r0 - a.E;
         const float rval = (float)pos * a.rope[(i0 % a.hs) >> 1];
@@ -845,6 +842,15 @@ __global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
         dst[0] = a0;
         dst[1] = a1;
     }
+}
+__global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
+    // a thread takes four rows = two pairs (16-byte loads of the partial tiles); E, KV and the head size are multiples of 4,
+    // so both pairs lie in the same part (q, k or v)
+    const int p4 = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (p4 >= a.rows / 4) return;
+    const float4 s4 = pf_sum4(a, t, 4 * p4);
+    pf_epi_qkv_pair(a, t, 4 * p4, s4.x / a.xn[t], s4.y / a.xn[t]);
+    pf_epi_qkv_pair(a, t, 4 * p4 + 2, s4.z / a.xn[t], s4.w / a.xn[t]);
 }
 // x[t] += sum (:603-605, :618-620), then the NEXT rmsnorm's products from the finished row (:450-457): xs[t] = x[t]*w and
 // xn[t] = sqrt(dot(x,x)/E + eps).  One workgroup per position; w == nullptr (after the last layer): residual only.
