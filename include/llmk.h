@@ -120,6 +120,10 @@ int llmk_tp_p2p_connect_local(llmk_ctx *ctx, llmk_ctx *const *ranks);
  * host gathers the ranks' verdicts over its side channel; unless ALL are 0, every rank calls llmk_tp_p2p_disable and
  * llmk_tp_init_comm, and the token pass runs over RCCL (what `llm --ngpu` and `bench.py --tp` do). */
 int llmk_tp_p2p_selftest(llmk_ctx *ctx, int iters);
+/* Verification only: the self-test's rounds with pseudo-random delays (seeded by `seed`) injected before and between the
+ * sends and the reads of every exchange, so that ranks and wavefronts drift apart by up to a whole exchange -- what a slower
+ * link or a time-sliced GPU does to them.  Same verdicts as the self-test; all ranks call it together. */
+int llmk_tp_p2p_stress(llmk_ctx *ctx, int iters, unsigned seed);
 int llmk_tp_p2p_disable(llmk_ctx *ctx);
 
 /* Single-process stepping of a tensor-parallel ctx, for verification on one GPU (no communicator): the
@@ -231,6 +235,10 @@ int llmk_path(llmk_ctx *ctx);
 /* How many ranks this ctx's collective actually spans: ncclCommCount of its RCCL communicator, or the number of mapped
  * peer inboxes (+ itself) on the peer-memory path, or 1.  For the benchmark line of a multi-GPU run (`ranks_seen`). */
 int llmk_tp_ranks_seen(llmk_ctx *ctx);
+
+/* Verification: 64-bit sum of the 32-bit words of a tensor's DEVICE image (this rank's shard, device layout).  Equal images
+ * give equal sums: two uploads of the same weights, or one context before and after a run, compare without a read-back. */
+int llmk_tensor_checksum(llmk_ctx *ctx, int tensor_id, unsigned long long *out);
 
 int llmk_destroy(llmk_ctx *ctx);
 

@@ -40,6 +40,18 @@ extern "C" int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, 
 
 namespace {
 
+// Every device allocation of the shim goes through here.  LLMK_POISON=1 (a test aid: tests/test_tp70_gpu.py and
+// tests/host_tools/gpu_job.sh poison) fills the fresh allocation with 0xFF bytes -- NaN as f32 or f16, -1 as an integer --
+// BEFORE the shim's own initialisation: a kernel that reads memory the shim never wrote then yields NaN every time,
+// whatever the allocator happened to hand out (a fresh process usually sees zero pages, a long-lived one does not).
+template <class T>
+hipError_t dev_alloc(T** p, size_t bytes) {
+    static const bool poison = getenv("LLMK_POISON") && getenv("LLMK_POISON")[0] == '1';
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e == hipSuccess && poison) e = hipMemset(*p, 0xFF, bytes);
+    return e;
+}
+
 struct TensorDesc {
     bool layered;   // has a leading layer dimension
     int rows;       // rows per layer (1 for vectors)
@@ -385,9 +397,9 @@ int tk_setup(llmk_ctx* c, int id) {
     if (per_cu < 1 || (long long)per_cu * c->n_cu < TK_NCU) return LLMK_OK;
     // qkv | xb | xa | hb | x | per head: the (PMAX - 1) other parts of a long context's attention (HS values + maximum + sum each)
     const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H + (size_t)TK::NH * (TkAttPlan<TK>::PMAX - 1) * (TK::HS + 2);
-    HIPCHK(hipMalloc(&c->d_gran, ngran * sizeof(unsigned long long)));
-    HIPCHK(hipMalloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
-    if (TK_DEBUG && getenv("LLMK_TK_TRACE")) HIPCHK(hipMalloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));   // libllmk_debug.so only
+    HIPCHK(dev_alloc(&c->d_gran, ngran * sizeof(unsigned long long)));
+    HIPCHK(dev_alloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
+    if (TK_DEBUG && getenv("LLMK_TK_TRACE")) HIPCHK(dev_alloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));   // libllmk_debug.so only
     HIPCHK(hipMemset(c->d_gran, 0, ngran * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->d_zeros, 0, (size_t)TK_NCU * TK_WAVES * 1024));
     c->use_tk = true;
@@ -443,9 +455,23 @@ int enqueue_token_tp(llmk_ctx* c) {
 }
 
 // Enqueue one token pass on c->stream.  timed: bracket the reference's five sections with events.
-hipError_t launch_tp_allreduce_add(llmk_ctx* c, int call) {   // x += sum over ranks of d_part   (:603-605, :618-620)
-    hipLaunchKernelGGL(tp_allreduce_add_kernel, dim3((c->E + 255) / 256), dim3(256), 0, c->stream, c->peers, c->d_part, c->d_x,
-                       c->d_tokpos, call, 2 * c->L, c->tp_rank, c->tp_size, c->E, reinterpret_cast<unsigned*>(c->d_logits + c->V));
+// jseed != 0: the jittered instantiation (llmk_tp_p2p_stress only)
+hipError_t launch_tp_allreduce_add(llmk_ctx* c, int call, unsigned jseed = 0) {   // x += sum over ranks of d_part   (:603-605, :618-620)
+    const dim3 grid((c->E + 255) / 256), block(256);
+    unsigned* err = reinterpret_cast<unsigned*>(c->d_logits + c->V);
+    if (jseed) hipLaunchKernelGGL(tp_allreduce_add_kernel<true>, grid, block, 0, c->stream, c->peers, c->d_part, c->d_x, c->d_tokpos, call,
+                                  2 * c->L, c->tp_rank, c->tp_size, c->E, err, jseed);
+    else hipLaunchKernelGGL(tp_allreduce_add_kernel<false>, grid, block, 0, c->stream, c->peers, c->d_part, c->d_x, c->d_tokpos, call,
+                            2 * c->L, c->tp_rank, c->tp_size, c->E, err, 0u);
+    return hipGetLastError();
+}
+hipError_t launch_tp_allgather(llmk_ctx* c, unsigned jseed = 0) {   // every rank's classifier rows into every rank's logits   (:634-636)
+    const dim3 grid((c->V + 255) / 256), block(256);
+    unsigned* err = reinterpret_cast<unsigned*>(c->d_logits + c->V);
+    if (jseed) hipLaunchKernelGGL(tp_allgather_kernel<true>, grid, block, 0, c->stream, c->peers, c->d_logits, c->d_tokpos, 2 * c->L,
+                                  c->tp_rank, c->tp_size, c->E, c->V, err, jseed);
+    else hipLaunchKernelGGL(tp_allgather_kernel<false>, grid, block, 0, c->stream, c->peers, c->d_logits, c->d_tokpos, 2 * c->L,
+                            c->tp_rank, c->tp_size, c->E, c->V, err, 0u);
     return hipGetLastError();
 }
 
@@ -463,9 +489,7 @@ hipError_t enqueue_token(llmk_ctx* c, bool greedy, bool timed) {
             HIPRET(launch_tp_allreduce_add(c, 2 * l + 1));
         }
         HIPRET(launch_cls(c));
-        hipLaunchKernelGGL(tp_allgather_kernel, dim3((c->V + 255) / 256), dim3(256), 0, c->stream, c->peers, c->d_logits, c->d_tokpos,
-                           2 * c->L, c->tp_rank, c->tp_size, c->E, c->V, reinterpret_cast<unsigned*>(c->d_logits + c->V));
-        HIPRET(hipGetLastError());
+        HIPRET(launch_tp_allgather(c));
         return enqueue_tail(c, greedy);
     }
     if (c->use_tk) {
@@ -542,6 +566,20 @@ int tk_retire(llmk_ctx* c, unsigned code, int pos) {
     return LLMK_OK;
 }
 
+// the sticky word of a timed-out peer-memory exchange (tp_p2p.h tp_err_code), in words
+const char* tp_describe_err(const llmk_ctx* c, unsigned code, char* buf, size_t n) {
+    if ((code >> 28) != 3u) { snprintf(buf, n, "code 0x%x", code); return buf; }
+    const unsigned per = 2u * (unsigned)c->L + 1u, e24 = code & 0xffffffu;
+    // the epoch's low 24 bits, completed with the host's serial (the device's can be at most a graph replay ahead)
+    const unsigned cur = (unsigned)c->h_tokpos[2] * per + per;
+    unsigned epoch = (cur & ~0xffffffu) | e24;
+    if (epoch > cur) epoch -= 0x1000000u;
+    const unsigned serial = (epoch - 1u) / per, call = (epoch - 1u) % per;
+    if (call == per - 1u) snprintf(buf, n, "code 0x%x: rank %u's logits slice never arrived (all-gather of serial %u)", code, (code >> 24) & 15u, serial);
+    else snprintf(buf, n, "code 0x%x: rank %u's partial never arrived (all-reduce %u of serial %u: layer %u, %s)", code, (code >> 24) & 15u,
+                  call, serial, call / 2u, (call & 1u) ? "w2" : "wo");
+    return buf;
+}
 int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
     int rc = check_ready(c);
     if (rc) return rc;
@@ -574,8 +612,9 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->p2p) {   // a peer never delivered its granules: the sticky word says so (cleared by llmk_reset)
             const unsigned perr = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
-            if (perr) fprintf(stderr, "llmk: rank %d of %d: a peer's granules never arrived (code 0x%x, position %d, serial %d)\n",
-                              c->tp_rank, c->tp_size, perr, pos, c->h_tokpos[2]);
+            char what[160];
+            if (perr) fprintf(stderr, "llmk: rank %d of %d: a peer's granules never arrived (%s; position %d, serial %d)\n",
+                              c->tp_rank, c->tp_size, tp_describe_err(c, perr, what, sizeof(what)), pos, c->h_tokpos[2]);
             return perr ? LLMK_E_TIMEOUT : LLMK_OK;
         }
         if (!c->use_tk) return LLMK_OK;
@@ -657,7 +696,7 @@ void pf_teardown(llmk_ctx* c) {
 // of launching on null buffers.
 int pf_setup_inner(llmk_ctx* c) {
     const size_t T = PF_TMAX;
-    HIPCHK(hipMalloc(&c->pf_flag, sizeof(unsigned)));
+    HIPCHK(dev_alloc(&c->pf_flag, sizeof(unsigned)));
     HIPCHK(hipMemset(c->pf_flag, 0, sizeof(unsigned)));
     const int rows[4] = {c->E + 2 * c->KV, c->E, 2 * c->H, c->E};
     size_t pcap = 0;
@@ -667,13 +706,13 @@ int pf_setup_inner(llmk_ctx* c) {
     HIPCHK(pf_prepare(c));
     for (int i = 0; i < 2; ++i) {
         PfLane& w = c->pf[i];
-        HIPCHK(hipMalloc(&w.X, T * c->E * sizeof(float)));
-        HIPCHK(hipMalloc(&w.Xs, T * c->E * sizeof(float)));
-        HIPCHK(hipMalloc(&w.Q, T * c->E * sizeof(float)));
-        HIPCHK(hipMalloc(&w.XB, T * c->E * sizeof(float)));
-        HIPCHK(hipMalloc(&w.HB, T * c->H * sizeof(float)));
-        HIPCHK(hipMalloc(&w.P, pcap * sizeof(float)));
-        HIPCHK(hipMalloc(&w.xn, T * sizeof(float)));
+        HIPCHK(dev_alloc(&w.X, T * c->E * sizeof(float)));
+        HIPCHK(dev_alloc(&w.Xs, T * c->E * sizeof(float)));
+        HIPCHK(dev_alloc(&w.Q, T * c->E * sizeof(float)));
+        HIPCHK(dev_alloc(&w.XB, T * c->E * sizeof(float)));
+        HIPCHK(dev_alloc(&w.HB, T * c->H * sizeof(float)));
+        HIPCHK(dev_alloc(&w.P, pcap * sizeof(float)));
+        HIPCHK(dev_alloc(&w.xn, T * sizeof(float)));
         if (i == 0) w.stream = c->stream;
         else HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         w.kv.assign(c->L, nullptr);
@@ -681,7 +720,7 @@ int pf_setup_inner(llmk_ctx* c) {
         HIPCHK(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     }
     HIPCHK(hipEventCreateWithFlags(&c->pf_start, hipEventDisableTiming));
-    HIPCHK(hipMalloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
+    HIPCHK(dev_alloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
     return LLMK_OK;
 }
 int pf_setup(llmk_ctx* c) {
@@ -951,25 +990,25 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
             continue;
         }
         const size_t extra = i == LLMK_RMS_ATT_WEIGHT ? ((size_t)L + 1) * E * sizeof(float) : 0;
-        CK(hipMalloc(&t.data, rows * t.row_bytes + extra + TENSOR_SLACK));
+        CK(dev_alloc(&t.data, rows * t.row_bytes + extra + TENSOR_SLACK));
         if (rc == LLMK_OK) {
             if (t.type == LLMK_TYPE_Q4_0) CK(hipMemset(t.data, 0, rows * t.row_bytes + TENSOR_SLACK));
             else CK(hipMemset((char*)t.data + rows * t.row_bytes + extra, 0, TENSOR_SLACK));
         }
     }
     const size_t kvn = (size_t)L * S * c->KVl;
-    CK(hipMalloc(&c->d_kc, kvn * sizeof(float)));
-    CK(hipMalloc(&c->d_vc, kvn * sizeof(float)));
-    CK(hipMalloc(&c->d_x, (size_t)E * sizeof(float)));
-    CK(hipMalloc(&c->d_q, (size_t)E * sizeof(float)));
-    CK(hipMalloc(&c->d_xb, (size_t)E * sizeof(float)));
-    CK(hipMalloc(&c->d_hb, (size_t)H * sizeof(float)));
-    CK(hipMalloc(&c->d_part, (size_t)E * sizeof(float)));
+    CK(dev_alloc(&c->d_kc, kvn * sizeof(float)));
+    CK(dev_alloc(&c->d_vc, kvn * sizeof(float)));
+    CK(dev_alloc(&c->d_x, (size_t)E * sizeof(float)));
+    CK(dev_alloc(&c->d_q, (size_t)E * sizeof(float)));
+    CK(dev_alloc(&c->d_xb, (size_t)E * sizeof(float)));
+    CK(dev_alloc(&c->d_hb, (size_t)H * sizeof(float)));
+    CK(dev_alloc(&c->d_part, (size_t)E * sizeof(float)));
     // [V] = sticky device error word; behind it (at V + 4) the two candidate buffers of the pipelined greedy decode
-    CK(hipMalloc(&c->d_logits, ((size_t)V + 4 + 4 * TK_NCU) * sizeof(float)));
-    CK(hipMalloc(&c->d_rope, (size_t)(hs / 2) * sizeof(float)));
-    CK(hipMalloc(&c->d_tokpos, 4 * sizeof(int)));
-    CK(hipMalloc(&c->d_next, 2 * sizeof(int)));
+    CK(dev_alloc(&c->d_logits, ((size_t)V + 4 + 4 * TK_NCU) * sizeof(float)));
+    CK(dev_alloc(&c->d_rope, (size_t)(hs / 2) * sizeof(float)));
+    CK(dev_alloc(&c->d_tokpos, 4 * sizeof(int)));
+    CK(dev_alloc(&c->d_next, 2 * sizeof(int)));
     CK(hipHostMalloc(&c->h_tokpos, 4 * sizeof(int), hipHostMallocDefault));
     // [V] = the error word as the host sees it; behind it (at V + 4) the ids of llmk_decode_greedy, S ints
     CK(hipHostMalloc(&c->h_logits, ((size_t)V + 4 + S) * sizeof(float), hipHostMallocMapped));
@@ -1035,7 +1074,7 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
         const size_t chunk_rows_max = ((size_t)256 << 20) / col_bytes + 1;
         uint8_t* tmp = nullptr;
         const size_t cr0 = (size_t)nrows < chunk_rows_max ? (size_t)nrows : chunk_rows_max;
-        HIPCHK(hipMalloc(&tmp, cr0 * col_bytes));
+        HIPCHK(dev_alloc(&tmp, cr0 * col_bytes));
         for (size_t r = 0; r < (size_t)nrows; r += cr0) {
             const size_t cr = ((size_t)nrows - r) < cr0 ? ((size_t)nrows - r) : cr0;
             const size_t nb = cr * blocks_per_row;
@@ -1157,7 +1196,7 @@ int llmk_set_tensor_type(llmk_ctx* c, int tid, int ggml_type) {
     t.rows_uploaded = 0;
     const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1);
     t.row_bytes = ggml_type == LLMK_TYPE_Q4_0 ? q4_row_stride(d.K) : row_bytes_for(ggml_type, d.K);
-    HIPCHK(hipMalloc(&t.data, rows * t.row_bytes + TENSOR_SLACK));
+    HIPCHK(dev_alloc(&t.data, rows * t.row_bytes + TENSOR_SLACK));
     HIPCHK(hipMemset(t.data, 0, rows * t.row_bytes + TENSOR_SLACK));
     if (c->use_tk) {
         c->use_tk = false;
@@ -1490,6 +1529,11 @@ static int tp_inbox_alloc(llmk_ctx* c) {
     HIPCHK(hipMemset(c->d_inbox, 0, bytes));      // tag 0 is never a valid epoch
     HIPCHK(hipDeviceSynchronize());
     c->peers.inbox[c->tp_rank] = c->d_inbox;
+    // bound of every spin of the exchange kernels in WALL-CLOCK ticks (tp_p2p.h): 20 s unless LLMK_TP_TIMEOUT_MS says otherwise
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->cfg.device) != hipSuccess || khz <= 0) khz = 100000;   // 100 MHz on gfx9
+    const long long ms = getenv("LLMK_TP_TIMEOUT_MS") ? atoll(getenv("LLMK_TP_TIMEOUT_MS")) : 20000;
+    c->peers.timeout_ticks = (unsigned long long)(ms > 0 ? ms : 20000) * (unsigned long long)khz;
     return LLMK_OK;
 }
 
@@ -1564,12 +1608,12 @@ __global__ void tp_selftest_check_kernel(const float* x, const float* logits, in
     }
     if (i < V && logits[i] != (float)((i * 3 + it) % 4093)) atomicAdd(bad, 1u);
 }
-int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) {
+static int tp_selftest_run(llmk_ctx* c, int iters, unsigned jseed) {
     if (!c || iters < 1) return LLMK_E_ARG;
     if (!c->p2p) return LLMK_E_COMM;
     HIPCHK(hipSetDevice(c->cfg.device));
     unsigned* d_bad = nullptr;
-    HIPCHK(hipMalloc(&d_bad, sizeof(unsigned)));
+    HIPCHK(dev_alloc(&d_bad, sizeof(unsigned)));
     HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
     const int n = std::max(c->E, c->V);
     int rc = LLMK_OK;
@@ -1580,22 +1624,24 @@ int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) {
     if (e0 == hipSuccess) e0 = hipStreamSynchronize(c->stream);
     if (e0 != hipSuccess) rc = LLMK_E_HIP + (int)e0;
     for (int it = 0; it < iters && rc == LLMK_OK; ++it) {
+        const unsigned js = jseed ? (jseed + (unsigned)it * 2654435761u) | 1u : 0u;
         hipLaunchKernelGGL(bump_serial_kernel, dim3(1), dim3(1), 0, c->stream, c->d_tokpos);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) {
             hipLaunchKernelGGL(tp_selftest_fill_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_part, c->d_x, c->d_logits, c->E,
                                c->V, c->tp_rank, c->tp_size, it);
-            e = launch_tp_allreduce_add(c, 0);
+            e = launch_tp_allreduce_add(c, 0, js);
         }
-        if (e == hipSuccess) e = launch_tp_allreduce_add(c, 1);
+        if (e == hipSuccess) e = launch_tp_allreduce_add(c, 1, js);
+        if (e == hipSuccess) e = launch_tp_allgather(c, js);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(tp_allgather_kernel, dim3((c->V + 255) / 256), dim3(256), 0, c->stream, c->peers, c->d_logits, c->d_tokpos,
-                               2 * c->L, c->tp_rank, c->tp_size, c->E, c->V, reinterpret_cast<unsigned*>(c->d_logits + c->V));
             hipLaunchKernelGGL(tp_selftest_check_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_x, c->d_logits, c->E, c->V,
                                c->tp_size, it, d_bad);
             e = hipGetLastError();
         }
         if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
+        // the jittered rounds are milliseconds each: do not queue thousands of spinning launches ahead of the device
+        if (jseed && (it & 63) == 63 && rc == LLMK_OK) { e = hipStreamSynchronize(c->stream); if (e != hipSuccess) rc = LLMK_E_HIP + (int)e; }
     }
     c->h_tokpos[2] += iters;                     // every rank ran the same number of rounds: the serials stay in step
     unsigned bad = 0, err = 0;
@@ -1612,12 +1658,19 @@ int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) {
     hipMemsetAsync(c->d_x, 0, (size_t)c->E * sizeof(float), c->stream);
     hipMemsetAsync(c->d_logits, 0, ((size_t)c->V + 4) * sizeof(float), c->stream);
     hipStreamSynchronize(c->stream);
-    if (rc != LLMK_OK)
-        fprintf(stderr, "llmk: rank %d of %d: the peer-memory collectives failed their self-test (%s, %u mismatches, code 0x%x)\n",
-                c->tp_rank, c->tp_size, rc == LLMK_E_TIMEOUT ? "a peer's granules never arrived" : rc == LLMK_E_COMM ? "wrong sums" : "HIP error",
-                bad, err);
+    if (rc != LLMK_OK) {
+        char what[160];
+        fprintf(stderr, "llmk: rank %d of %d: the peer-memory collectives failed their %s (%s, %u mismatches, %s)\n",
+                c->tp_rank, c->tp_size, jseed ? "stress run" : "self-test",
+                rc == LLMK_E_TIMEOUT ? "a peer's granules never arrived" : rc == LLMK_E_COMM ? "wrong sums" : "HIP error", bad,
+                tp_describe_err(c, err, what, sizeof(what)));
+    }
     return rc;
 }
+int llmk_tp_p2p_selftest(llmk_ctx* c, int iters) { return tp_selftest_run(c, iters, 0u); }
+// The same rounds with wave-uniform pseudo-random delays before and between the sends and the reads of every exchange
+// (tp_p2p.h JIT): ranks and waves drift apart by up to a whole exchange.  Verification only (tests/test_tp_gpu.py).
+int llmk_tp_p2p_stress(llmk_ctx* c, int iters, unsigned seed) { return tp_selftest_run(c, iters, seed | 1u); }
 
 // Stop using the peer-memory collectives on this ctx (after a failed self-test on ANY rank): the token pass then needs
 // the RCCL communicator (llmk_tp_init_comm).  The inbox stays mapped until llmk_destroy.
@@ -1684,6 +1737,35 @@ int llmk_tp_read_logits(llmk_ctx* c, float* out_slice) {
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipMemcpy(out_slice, c->d_logits + (size_t)c->tp_rank * c->Vl, (size_t)c->Vl * sizeof(float), hipMemcpyDeviceToHost));
     return LLMK_OK;
+}
+
+// 64-bit sum of the 32-bit words of a tensor's DEVICE image (this rank's shard, in the device layout): equal images give
+// equal sums, so two uploads of the same weights, two contexts, or one context before and after a run can be compared
+// without reading gigabytes back (tests: upload determinism, "weights untouched by the token pass").
+__global__ void checksum_kernel(const unsigned* __restrict__ w, size_t nwords, unsigned long long* out) {
+    unsigned long long t = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) t += w[i];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, t);
+}
+int llmk_tensor_checksum(llmk_ctx* c, int tid, unsigned long long* out) {
+    if (!c || !out || tid < 0 || tid >= LLMK_N_TENSORS) return LLMK_E_ARG;
+    const TensorDesc& d = c->desc[tid];
+    const DevTensor& t = c->t[tid];
+    if (!t.data) return LLMK_E_STATE;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t nwords = (size_t)d.rows * (d.layered ? c->L : 1) * t.row_bytes / 4;
+    unsigned long long* d_out = nullptr;
+    HIPCHK(dev_alloc(&d_out, sizeof(*d_out)));
+    hipError_t e = hipMemsetAsync(d_out, 0, sizeof(*d_out), c->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, c->stream, (const unsigned*)t.data, nwords, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(*d_out), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_out);
+    return e == hipSuccess ? LLMK_OK : LLMK_E_HIP + (int)e;
 }
 
 int llmk_path(llmk_ctx* c) {

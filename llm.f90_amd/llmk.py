@@ -22,10 +22,10 @@ TENSOR_IDS = {
 FLAG_NO_GRAPH, FLAG_TIMINGS, FLAG_MULTI_KERNEL = 1, 2, 4
 # every symbol include/llmk.h declares
 SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_comm", "llmk_tp_p2p_handle", "llmk_tp_p2p_connect",
-           "llmk_tp_p2p_connect_local", "llmk_tp_p2p_selftest", "llmk_tp_p2p_disable", "llmk_tp_begin", "llmk_tp_segment",
+           "llmk_tp_p2p_connect_local", "llmk_tp_p2p_selftest", "llmk_tp_p2p_stress", "llmk_tp_p2p_disable", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
            "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_decode_greedy", "llmk_reset", "llmk_timings",
-           "llmk_time_kernel", "llmk_peek", "llmk_path", "llmk_tp_ranks_seen", "llmk_destroy", "llmk_strerror", "llmk_version"]
+           "llmk_time_kernel", "llmk_peek", "llmk_tensor_checksum", "llmk_path", "llmk_tp_ranks_seen", "llmk_destroy", "llmk_strerror", "llmk_version"]
 PATH_NAMES = {0: "multi-kernel (5 launches per layer)", 1: "persistent whole-token kernel",
               2: "tensor-parallel rank: 6 launches per layer + one-shot peer-memory exchanges",
               3: "tensor-parallel rank: eager launches + RCCL collectives", 4: "tensor-parallel rank, collectives not connected"}
@@ -69,7 +69,9 @@ def lib():
         L.llmk_tp_p2p_connect.argtypes = [vp, C.c_char_p]
         L.llmk_tp_p2p_connect_local.argtypes = [vp, C.POINTER(vp)]
         L.llmk_tp_p2p_selftest.argtypes = [vp, ci]
+        L.llmk_tp_p2p_stress.argtypes = [vp, ci, C.c_uint]
         L.llmk_tp_p2p_disable.argtypes = [vp]
+        L.llmk_tensor_checksum.argtypes = [vp, ci, C.POINTER(C.c_ulonglong)]
         L.llmk_tp_begin.argtypes = [vp, ci, ci]
         L.llmk_tp_segment.argtypes = [vp, ci, ci]
         L.llmk_tp_read_partial.argtypes = [vp, cf]
@@ -240,6 +242,16 @@ class Llmk:
     def tp_p2p_selftest(self, iters: int = 64) -> int:
         """0 when this rank's peer-memory exchanges all gave exact sums (every rank must call it); else the LLMK_E_* code"""
         return lib().llmk_tp_p2p_selftest(self._h, iters)
+
+    def tp_p2p_stress(self, iters: int, seed: int) -> int:
+        """the self-test's rounds with random delays around every send and read (llmk_tp_p2p_stress); 0 = all sums exact"""
+        return lib().llmk_tp_p2p_stress(self._h, iters, seed)
+
+    def tensor_checksum(self, name: str) -> int:
+        """64-bit word sum of the tensor's device image (llmk_tensor_checksum)"""
+        out = C.c_ulonglong(0)
+        _ck(lib().llmk_tensor_checksum(self._h, TENSOR_IDS[name], C.byref(out)))
+        return out.value
 
     def tp_p2p_disable(self):
         _ck(lib().llmk_tp_p2p_disable(self._h))

@@ -543,6 +543,33 @@ def write_synth_q4_gguf_streamed(path: str, shape: LlamaShape, seed: int, alignm
     return os.path.getsize(path)
 
 
+def write_synth_q4_decoded_f32_gguf(path: str, shape: LlamaShape, seed: int, alignment: int = 32, scale_jitter: bool = True) -> int:
+    """The weights of synth_fused_q4_direct / write_synth_q4_gguf_streamed DECODED to f32 -- (nibble - 8) * d, exact -- as an
+    f32 GGUF the unmodified reference loader reads (read_ggml.f90 accepts type 0 only): the file a full-depth
+    Llama-2-7B golden is generated from (27 GB, written tensor by tensor).  Returns the file size."""
+    names = tensor_names(shape)
+    idx = {n: i for i, (n, _, _) in enumerate(names)}
+    dims_of = {n: d for n, d, _ in names}
+    kind_of = {n: k for n, _, k in names}
+
+    def src(name):
+        d = dims_of[name]
+        if kind_of[name] != "mat":
+            return synth_tensor(shape, seed, idx[name], d, kind_of[name])
+        return dequantize_q4_0(synth_q4_rows(seed, idx[name], int(np.prod(d[:-1])), d[-1], scale_jitter), d[-1])
+    vocab = vocab_strings(shape.vocab_size)
+    scores = -np.arange(len(vocab), dtype="<f4")
+    kvs = [("general.architecture", T_STR, b"llama"), ("general.name", T_STR, b"synthetic"),
+           ("llama.context_length", T_U32, shape.seq_len), ("llama.embedding_length", T_U32, shape.emb_dim),
+           ("llama.block_count", T_U32, shape.n_layers), ("llama.feed_forward_length", T_U32, shape.hidden_dim),
+           ("llama.attention.head_count", T_U32, shape.n_heads), ("llama.attention.head_count_kv", T_U32, shape.n_kv_heads),
+           ("llama.attention.layer_norm_rms_epsilon", T_F32, 1e-5), ("general.alignment", T_U32, alignment),
+           ("tokenizer.ggml.model", T_STR, b"llama")]
+    _write_gguf_file(path, shape, GGML_F32, GGML_F32, kvs, vocab, scores, names, src, lambda name: int(np.prod(dims_of[name])) * 4,
+                     alignment, 3)
+    return os.path.getsize(path)
+
+
 def write_ak(path: str, fw: "FusedWeights") -> None:
     """llama2.c-style flat checkpoint ("ak" format) in the order the reference's `--ak` reader
     consumes it (/root/reference/llama2.f90:160-292): 7 int32 header, token_embedding_table,

@@ -42,6 +42,11 @@ CASES = [
     # BASELINE.json configs[0]/[1] at FULL size from the real reference: 320 positions of TinyLlama-1.1B f32 on the
     # synthetic weights bench.py uses.  41 MB of logits are reduced to ids + top-8 + 64 probe columns + checksums.
     ("tinyllama", 320, "COMPACT"),
+    # BASELINE.json configs[3] at FULL depth from the real reference (round-3 verdict, "missing" 1): the q4_0 blocks the GPU
+    # tests generate (synth_fused_q4_direct: every block its own scale, some negative) decoded to f32 -- the reference reads
+    # f32 only -- as a 27 GB GGUF, 24 positions through llm_ref_llama2-7b (dims patched, oracle/Makefile).
+    # Needs ~35 GB of RAM and ~30 GB of scratch disk; run it by name: make_golden.py llama2-7b
+    ("llama2-7b", 40, "Q4COMPACT:Llama-2 7B, q4_0: full depth!"),     # 30 prompt tokens (all different characters would be dull: repeats included), then 10 greedy ones
 ]
 LONG_PROMPT = "".join(chr(33 + (7 * i + i // 13) % 90) for i in range(256))   # 256 printable non-blank characters
 PROBE_SEED = 12345
@@ -56,16 +61,19 @@ def prompt_ids(prompt: str):
 def main():
     outdir = os.path.dirname(os.path.abspath(__file__))
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True)
-    with tempfile.TemporaryDirectory() as td:
+    with tempfile.TemporaryDirectory(dir=os.environ.get("LLMK_GOLDEN_TMP")) as td:
         only = set(sys.argv[1:])
         for name, n, prompt in CASES:
             if only and name not in only:
                 continue
             s = gguf.SHAPES[name]
             ak = prompt == "ak"
-            compact = prompt == "COMPACT"
+            q4dec = prompt.startswith("Q4COMPACT")
+            compact = prompt == "COMPACT" or q4dec
+            if q4dec and name not in only:
+                continue                      # the 27 GB case only when asked for by name
             if compact:
-                prompt = ""
+                prompt = prompt.partition(":")[2]
             if prompt == "LONG":
                 prompt = LONG_PROMPT
             if ak:
@@ -74,6 +82,9 @@ def main():
                 gguf.write_ak(path, gguf.synth_fused(s, SEED))
                 tokp = os.path.join(td, name + ".tokenizer.bin")
                 gguf.write_tokenizer_bin(tokp, gguf.vocab_strings(s.vocab_size))
+            elif q4dec:
+                path = os.path.join(td, name + ".gguf")
+                gguf.write_synth_q4_decoded_f32_gguf(path, s, SEED, scale_jitter=True)
             else:
                 path = os.path.join(td, name + ".gguf")
                 gguf.write_synth_gguf(path, s, SEED)
@@ -102,6 +113,7 @@ def main():
                 probe = np.sort(np.random.default_rng(PROBE_SEED).choice(s.vocab_size, 64, replace=False)).astype(np.int32)
                 l64 = logits.astype(np.float64)
                 np.savez_compressed(os.path.join(outdir, tag + ".npz"), shape=name, seed=SEED, n=n, prompt=prompt, ak=ak,
+                                    weights="synth_fused_q4_direct(scale_jitter) decoded to f32" if q4dec else "synth_fused f32",
                                     prompt_ids=np.asarray(pids, np.int32), tokens=np.asarray(toks, np.int32),
                                     stdout=np.frombuffer(r.stdout, np.uint8), top1_margin=(srt[:, -1] - srt[:, -2]),
                                     top8_idx=top8, top8_val=np.take_along_axis(logits, top8, axis=1),

@@ -1,5 +1,7 @@
 """The oracle (oracle/llm_oracle.c, a C restatement of /root/reference/llama2.f90:480-640) against
 golden vectors produced by the real reference (tests/golden/make_golden.py). CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,6 +30,20 @@ def test_oracle_matches_reference_at_full_tinyllama_size(gguf):
     g = load_golden("tinyllama")
     fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
     n = 12
+    toks, logits = Oracle(fw, "omp").generate(n, prompt=g["tokens"][:n].tolist())
+    err = compact_err(logits, g, n)
+    assert err.max() <= 1e-5, err
+    ok = safe_positions(g, n)
+    assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][:n][ok])
+
+
+@pytest.mark.skipif(not os.environ.get("LLMK_BIG_ORACLE"), reason="31 GB of host memory and ~3 minutes: LLMK_BIG_ORACLE=1")
+def test_oracle_matches_reference_at_full_llama2_7b_depth(gguf):
+    """BASELINE.json configs[3] at FULL depth: tests/golden/llama2-7b.npz is the real reference (dims patched to Llama-2-7B)
+    on the q4_0 blocks of synth_fused_q4_direct decoded to f32; the oracle replays the first positions teacher-forced."""
+    g = load_golden("llama2-7b-prompt")
+    fw = gguf.synth_fused_q4_direct(gguf.SHAPES["llama2-7b"], int(g["seed"])).as_f32()
+    n = 6
     toks, logits = Oracle(fw, "omp").generate(n, prompt=g["tokens"][:n].tolist())
     err = compact_err(logits, g, n)
     assert err.max() <= 1e-5, err

@@ -33,6 +33,37 @@ class _Side:
         out[:] = self.conn.recv()
 
 
+def expected_checksum(fw, name, r):
+    """What llmk_tensor_checksum must return for rank r's shard of tensor `name`: the 64-bit sum of the 32-bit words of the
+    DEVICE image (csrc/llmk.hip upload_rows_sharded + q4_repack_kernel: per row the K/2 nibble bytes, then the K/32 f16
+    scales, zero padding), computed here from the host arrays -- so a shard that arrived damaged, or was cut at the wrong
+    rows / columns, is told apart from one that was damaged later."""
+    s = fw.shape
+    E, H, KV, V, hs = s.emb_dim, s.hidden_dim, s.kv_dim, s.vocab_size, s.head_size
+    Eq, KVl, Hl, Vl = s.n_heads // P * hs, s.n_kv_heads // P * hs, H // P, V // P
+    a = getattr(fw, name)
+    if name in ("token_embedding_table", "rms_att_weight", "rms_ffn_weight", "rms_final_weight"):
+        return int(np.ascontiguousarray(a).view("<u4").astype(np.uint64).sum() & np.uint64(0xFFFFFFFFFFFFFFFF))
+    K = {"wqkv": E, "wo": E, "w13": E, "w2": H, "wcls": E}[name]
+    b = np.asarray(a).reshape(-1, a.shape[-2], K // 32, 18)          # [L or 1][rows][blocks][18 bytes]
+    if name == "wqkv":
+        b = np.concatenate([b[:, r * Eq:(r + 1) * Eq], b[:, E + r * KVl:E + (r + 1) * KVl], b[:, E + KV + r * KVl:E + KV + (r + 1) * KVl]], axis=1)
+    elif name == "wo":
+        b = b[:, :, r * Eq // 32:(r + 1) * Eq // 32]
+    elif name == "w13":
+        b = np.concatenate([b[:, r * Hl:(r + 1) * Hl], b[:, H + r * Hl:H + (r + 1) * Hl]], axis=1)
+    elif name == "w2":
+        b = b[:, :, r * Hl // 32:(r + 1) * Hl // 32]
+    else:
+        b = b[:, r * Vl:(r + 1) * Vl]
+    b = np.ascontiguousarray(b)
+    assert b.shape[2] % 2 == 0                                          # scales pair up into whole words
+    nib = np.ascontiguousarray(b[..., 2:18]).view("<u4").astype(np.uint64).sum()
+    sc = np.ascontiguousarray(b[..., 0:2]).view("<u2")[..., 0].astype(np.uint64)
+    tot = nib + sc[..., 0::2].sum() + np.uint64(65536) * sc[..., 1::2].sum()
+    return int(tot & np.uint64(0xFFFFFFFFFFFFFFFF))
+
+
 def _rank_oracle_case(rank, dirpath, n, prompt, conn):
     """one rank process: its shard of the weights the parent left in dirpath, handles over the pipe, n positions"""
     import llm_f90_amd     # noqa: F401
@@ -43,14 +74,40 @@ def _rank_oracle_case(rank, dirpath, n, prompt, conn):
     for f in FIELDS:
         setattr(fw, f, np.load(os.path.join(dirpath, f + ".npy"), mmap_mode="r"))
     m = lk.Llmk(fw, device=0, tp_rank=rank, tp_size=P)
+    diag = {"sum_after_upload": {f: m.tensor_checksum(f) for f in FIELDS}}
     side = _Side(conn)
     handles, verdicts = [None] * P, [None] * P
     side.all_gather_object(handles, m.tp_p2p_handle())
     m.tp_p2p_connect(handles)
     side.all_gather_object(verdicts, m.tp_p2p_selftest(16))      # every collective on known integers, all ranks together
-    _, logits = m.generate(n, prompt=prompt)
-    greedy, _ = m.generate(8, want_logits=False, greedy_on_device=True)
-    conn.send(("result", (logits, greedy, m.path(), verdicts)))
+    try:
+        _, logits = m.generate(n, prompt=prompt)
+        greedy, _ = m.generate(8, want_logits=False, greedy_on_device=True)
+        diag["error"] = None
+    except lk.LlmkError as e:                                    # a timed-out exchange: deliver what there is, the parent reports it
+        logits, greedy = np.full((n, s.vocab_size), np.nan, np.float32), np.zeros(8, np.int32)
+        diag["error"] = str(e)
+    diag["sum_after_run"] = {f: m.tensor_checksum(f) for f in FIELDS}
+    diag["x"] = m.peek(0, s.emb_dim)
+    diag["kv_row1"] = [m.peek(w, s.kv_dim // P, layer=l, pos=1) for w in (4, 5) for l in range(s.n_layers)]
+    conn.send(("result", (logits, greedy, m.path(), verdicts, diag)))
+    m.close()
+
+
+def _rank_stress(rank, rounds, seed, conn):
+    """one rank process of the jitter run: a weightless 70B-width ctx (the exchanges need E, V and the inboxes only)"""
+    import llm_f90_amd     # noqa: F401
+    from llm_f90_amd import llmk as lk
+    from llm_f90_amd.tools import gguf as gg
+    m = lk.Llmk.create_empty(gg.LlamaShape(8192, 28672, 1, 64, 8, 32000, 32), 2, tp_rank=rank, tp_size=P)
+    side = _Side(conn)
+    handles, first = [None] * P, [None] * P
+    side.all_gather_object(handles, m.tp_p2p_handle())
+    m.tp_p2p_connect(handles)
+    side.all_gather_object(first, m.tp_p2p_selftest(8))
+    rc = m.tp_p2p_stress(rounds, seed)
+    after = m.tp_p2p_selftest(8) if rc == 0 else -1               # and the plain exchanges still work behind it
+    conn.send(("result", (first, rc, after)))
     m.close()
 
 
@@ -106,13 +163,19 @@ def test_llama2_70b_geometry_8_rank_processes_match_oracle(gguf, tmp_path_factor
             np.save(os.path.join(td, f + ".npy"), np.ascontiguousarray(getattr(fw, f)))
         n = 64
         ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
-        del fw
         assert np.all(np.isfinite(ol))
         margin = np.sort(ol, axis=1)
         safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
 
-        def check(res):
-            for r, (logits, greedy, path, verdicts) in enumerate(res):
+        res = _run_ranks(_rank_oracle_case, lambda r: (r, td, n, ot.tolist()), 600)
+        want = {f: [expected_checksum(fw, f, r) for r in range(P)] for f in FIELDS}
+        del fw
+        try:
+            for r, (logits, greedy, path, verdicts, diag) in enumerate(res):
+                assert diag["error"] is None, (r, diag["error"])
+                for f in FIELDS:                                           # the shard arrived whole, and the token pass left it alone
+                    assert diag["sum_after_upload"][f] == want[f][r], (r, f, "upload")
+                    assert diag["sum_after_run"][f] == want[f][r], (r, f, "after the run")
                 assert np.all(np.isfinite(logits)), (r, np.argwhere(~np.isfinite(logits))[:4].tolist())
                 assert path == 2                                           # tensor-parallel rank over the peer-memory collectives
                 assert verdicts == [0] * P                                 # llmk_tp_p2p_selftest: exact sums on every rank
@@ -121,16 +184,50 @@ def test_llama2_70b_geometry_8_rank_processes_match_oracle(gguf, tmp_path_factor
                 assert np.array_equal((np.argmax(logits, axis=1) + 1)[safe], ot[safe])
                 assert np.array_equal(logits, res[0][0]), r                # rank-order sums: bit-identical on all eight ranks
                 assert np.array_equal(greedy[safe[:8]], ot[:8][safe[:8]])
+        except AssertionError:
+            _dump_failure("geometry", res, ol, want)                       # what failed, on which rank, from which position on
+            raise
 
-        # Eight rank processes time-slicing ONE GPU (this box) is not the production topology, and in ~1 of 15 whole-suite runs of
-        # round 3 this case failed once and passed on every repetition (5 + 6 + 3 dedicated reruns): a first failure is
-        # reported as a warning with its details and the ranks are run a second time, which has to pass.
-        try:
-            check(_run_ranks(_rank_oracle_case, lambda r: (r, td, n, ot.tolist()), 600))
-        except (AssertionError, pytest.fail.Exception) as first:
-            import warnings
-            warnings.warn(f"tp70 geometry case failed once, rerunning the ranks: {str(first)[:500]}")
-            check(_run_ranks(_rank_oracle_case, lambda r: (r, td, n, ot.tolist()), 600))
+
+def _dump_failure(tag, res, ol, want):
+    """Everything a post-mortem needs, where the lease pulls it from (gpurun_out/tp70_fail/): per rank the first non-finite
+    and the first out-of-tolerance position with the index of the worst logit, the error text, the self-test verdicts,
+    checksum mismatches, x and the first K/V rows; the logits of the first failing rank in full."""
+    from conftest import ROOT
+    out = os.path.join(ROOT, "gpurun_out", "tp70_fail")
+    os.makedirs(out, exist_ok=True)
+    lines, saved = [], False
+    for r, (logits, greedy, path, verdicts, diag) in enumerate(res):
+        fin = np.isfinite(logits).all(axis=1)
+        err = rel_err(np.nan_to_num(logits), ol)
+        badpos = np.flatnonzero(~fin | (err > REL_TOL))
+        sums = [f"{f}:{k}" for f in FIELDS for k in ("sum_after_upload", "sum_after_run") if diag[k][f] != want[f][r]]
+        lines.append(f"rank {r}: path {path} verdicts {verdicts} error {diag['error']!r} first non-finite position "
+                     f"{int(np.argmin(fin)) if not fin.all() else None} bad positions {badpos[:8].tolist()} (of {len(badpos)}) "
+                     f"non-finite logits {int((~np.isfinite(logits)).sum())} checksum mismatches {sums} "
+                     f"x finite {bool(np.isfinite(diag['x']).all())} "
+                     f"kv rows finite {[bool(np.isfinite(v).all()) for v in diag['kv_row1']]} same as rank 0 {bool(np.array_equal(logits, res[0][0]))}")
+        if len(badpos) and not saved:
+            p0 = int(badpos[0])
+            lines.append(f"  rank {r} position {p0}: worst logit index {int(np.argmax(np.abs(np.nan_to_num(logits[p0]) - ol[p0])))}, "
+                         f"non-finite columns {np.flatnonzero(~np.isfinite(logits[p0]))[:8].tolist()}")
+            np.savez_compressed(os.path.join(out, f"{tag}_rank{r}.npz"), logits=logits, oracle=ol, x=diag["x"], kv=np.asarray(diag["kv_row1"]))
+            saved = True
+    with open(os.path.join(out, f"{tag}.txt"), "a") as f:
+        f.write("\n".join(lines) + "\n\n")
+    print("\n".join(lines))
+
+
+def test_peer_memory_collectives_under_jitter_8_rank_processes():
+    """Round-3 verdict item 1: the REAL exchange kernels (csrc/tp_p2p.h) at the 70B widths (E 8192, V 32000), eight rank
+    processes on this GPU, 2,500 rounds of two all-reduces + the all-gather with pseudo-random delays of up to ~15 us
+    before and between the sends and the reads of every wavefront -- ranks and waves drift apart by up to a whole exchange.
+    Every round's sums are checked exactly on every rank; the plain self-test must still pass behind it."""
+    res = _run_ranks(_rank_stress, lambda r: (r, 2500, 0xC0FFEE + 17 * r), 600)
+    for r, (first, rc, after) in enumerate(res):
+        assert first == [0] * P, (r, first)
+        assert rc == 0, (r, rc)
+        assert after == 0, (r, after)
 
 
 def test_llama2_70b_full_size_8_rank_processes_properties():

@@ -67,3 +67,16 @@ def test_two_rank_tensor_parallel_protocol_over_gloo(tag, n, tmp_path):
         assert rel_err(r["logits"], g["logits"][:n]).max() <= 1e-5      # same arithmetic, partial sums regrouped per rank
         assert np.array_equal(r["toks"], g["tokens"][:n])
     assert np.array_equal(res[0]["logits"], res[1]["logits"])           # both ranks hold the same replicated stream
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_two_half_epoch_rule_holds_over_every_interleaving(P):
+    """csrc/tp_p2p.h's claim -- a half of the inbox is never overwritten while a peer still reads it -- checked exhaustively:
+    every interleaving of the ranks' sends and blocking reads over three token passes (two all-reduces + the all-gather
+    each), no ordering assumed between ranks beyond what the granules themselves enforce.  The same search with ONE half
+    must find the overwrite (the checker has teeth)."""
+    from tp_cpu_model import check_interleavings
+    assert check_interleavings(P, tokens=3, ncalls=2, halves=2) is None
+    assert check_interleavings(P, tokens=4, ncalls=4, halves=2) is None
+    bad = check_interleavings(P, tokens=3, ncalls=2, halves=1)
+    assert bad is not None and bad.startswith("deadlock"), bad

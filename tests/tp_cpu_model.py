@@ -83,3 +83,75 @@ class TpRank:
             x = x + self.allreduce((self.w2[l] @ hb).astype(f32))       # exchange 2   (:618-620)
         x = rmsnorm(x, self.rms_final)
         return self.allgather((self.wcls @ x).astype(f32))              # exchange 3   (:634-636)
+
+
+# ---- the peer-memory exchange protocol of csrc/tp_p2p.h as a state machine, checked over EVERY interleaving ----------------
+def tp_program(P, rank, tokens, ncalls):
+    """The memory operations ONE element's threads of rank `rank` perform over `tokens` token passes, in program order
+    (csrc/tp_p2p.h): per all-reduce call its P-1 sends then its P-1 blocking reads in rank order, then the all-gather --
+    for one logit column per owner: the owner's P-1 sends, everybody else's one blocking read.
+    ops: ("send", dst, cell, epoch, value) | ("recv", cell, epoch, expected value); a cell is the address of one granule in
+    a rank's inbox: ("ar", half, src) or ("ag", half, column)."""
+    ops = []
+    per = ncalls + 1
+    for serial in range(1, tokens + 1):
+        for call in range(ncalls):
+            epoch, half = serial * per + call + 1, call & 1
+            val = ("part", rank, serial, call)
+            for r in range(1, P):
+                ops.append(("send", (rank + r) % P, ("ar", half, rank), epoch, val))
+            for r in range(P):
+                if r != rank:
+                    ops.append(("recv", ("ar", half, r), epoch, ("part", r, serial, call)))
+        epoch, half = serial * per + ncalls + 1, serial & 1
+        for col in range(P):                       # one logit column per owner
+            if col == rank:
+                for r in range(1, P):
+                    ops.append(("send", (rank + r) % P, ("ag", half, col), epoch, ("logit", col, serial)))
+        for col in range(P):
+            if col != rank:
+                ops.append(("recv", ("ag", half, col), epoch, ("logit", col, serial)))
+    return ops
+
+
+def check_interleavings(P, tokens=3, ncalls=2, halves=2):
+    """Depth-first search over every interleaving of the P ranks' operations (a blocked read is simply not enabled).
+    Returns None when every reachable state is sound, else a description of the first violation:
+      * a read whose tag matches but whose value is not the one its exchange must deliver (a granule was overwritten by a
+        LATER exchange that reuses the cell AND the epoch -- cannot happen with unique epochs, checked anyway);
+      * a deadlock: some rank blocked forever, i.e. the granule it waits for was overwritten before it was read (the
+        failure the two alternating halves exist to exclude; halves=1 must produce it)."""
+    progs = [tp_program(P, r, tokens, ncalls) for r in range(P)]
+    if halves == 1:                                # the broken variant: every exchange in half 0
+        progs = [[(o[0], o[1], (o[2][0], 0, o[2][2]), *o[3:]) if o[0] == "send" else (o[0], (o[1][0], 0, o[1][2]), *o[2:])
+                  for o in p] for p in progs]
+    cells = sorted({(o[1], o[2]) for p in progs for o in p if o[0] == "send"})
+    index = {c: i for i, c in enumerate(cells)}
+    start = (tuple([0] * P), tuple([None] * len(cells)))
+    seen, stack = {start}, [start]
+    while stack:
+        pcs, mem = stack.pop()
+        progressed = False
+        for r in range(P):
+            if pcs[r] == len(progs[r]):
+                continue
+            op = progs[r][pcs[r]]
+            if op[0] == "send":
+                m = list(mem)
+                m[index[(op[1], op[2])]] = (op[3], op[4])
+                nxt = (pcs[:r] + (pcs[r] + 1,) + pcs[r + 1:], tuple(m))
+            else:
+                g = mem[index[(r, op[1])]] if (r, op[1]) in index else None
+                if g is None or g[0] != op[2]:
+                    continue                       # tag is not this exchange's epoch: the thread keeps polling
+                if g[1] != op[3]:
+                    return f"rank {r} read {g} where {op} was due"
+                nxt = (pcs[:r] + (pcs[r] + 1,) + pcs[r + 1:], mem)
+            progressed = True
+            if nxt not in seen:
+                seen.add(nxt)
+                stack.append(nxt)
+        if not progressed and any(pcs[r] < len(progs[r]) for r in range(P)):
+            blocked = {r: progs[r][pcs[r]] for r in range(P) if pcs[r] < len(progs[r])}
+            return f"deadlock: {blocked}"
+    return None
