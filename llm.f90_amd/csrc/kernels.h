@@ -729,7 +729,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w)
             if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-        out[0] = idx + 1;
+        out[0] = (unsigned)idx < (unsigned)n ? idx + 1 : 0;   // no finite maximum (all NaN / -inf): 0 is no token -- the next call rejects it (LLMK_E_ARG)
     }
 }
 

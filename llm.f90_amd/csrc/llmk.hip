@@ -361,7 +361,8 @@ hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false, const TkGreedy&
     }
 }
 // the last position of a pipelined greedy run has no next launch to fold its candidates: this does (1 wave)
-__global__ __launch_bounds__(64) void cand_resolve_kernel(const float2* __restrict__ cand, int* id_out, int* next) {
+// (no id while the sticky error word is set, and none from candidates without a finite maximum: see tk_token)
+__global__ __launch_bounds__(64) void cand_resolve_kernel(const float2* __restrict__ cand, int* id_out, int* next, unsigned* err, int V) {
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int k = threadIdx.x; k < TK_NCU; k += 64) {
@@ -371,8 +372,12 @@ __global__ __launch_bounds__(64) void cand_resolve_kernel(const float2* __restri
     }
     tk_wave_argmax(bv, bi);
     if (threadIdx.x == 0) {
-        next[0] = bi + 1;
-        __hip_atomic_store(id_out, bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool none = (unsigned)bi >= (unsigned)V;
+        if (none) atomicOr(err, 0x2000u);
+        if (!none && *err == 0) {
+            next[0] = bi + 1;
+            __hip_atomic_store(id_out, bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1331,11 +1336,12 @@ int llmk_decode_greedy(llmk_ctx* c, int token, int pos0, int n, int* ids_out, ll
             TkGreedy g;
             g.gflags = TKG_GREEDY | (i ? TKG_CAND_IN | TKG_ID : 0);
             g.id_index = i - 1;
-            c->tk_short_grid = false;
+            // debug library only: this launch one workgroup short, so its peers really time out INSIDE the pipeline
+            c->tk_short_grid = TK_DEBUG && getenv("LLMK_TK_INJECT_TIMEOUT") && atoi(getenv("LLMK_TK_INJECT_TIMEOUT")) == pos0 + i;
             HIPCHK(launch_token_kernel(c, false, g));
         }
         hipLaunchKernelGGL(cand_resolve_kernel, dim3(1), dim3(64), 0, c->stream, d_cand + (size_t)((pos0 + n - 1) & 1) * TK_NCU,
-                           h_ids_dev + (n - 1), c->d_next);
+                           h_ids_dev + (n - 1), c->d_next, reinterpret_cast<unsigned*>(c->d_logits + c->V), c->V);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(c->h_next + 1, c->d_logits + c->V, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         // drain: ids are 1-based, 0 = not resolved yet
@@ -1363,6 +1369,7 @@ int llmk_decode_greedy(llmk_ctx* c, int token, int pos0, int n, int* ids_out, ll
         rc = tk_retire(c, err, pos0 + done);
         if (rc) return rc;
         if (done > 0) token = ids_out[done - 1];
+        c->tk_short_grid = false;
     }
     for (int i = done; i < n; ++i) {
         rc = run_token(c, token, pos0 + i, true);

@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void tk_attention(const TokenArgs& a, char* lds, int 
 // (granule sweep), rmsnorm, barrier A, barrier B, epilogue + publish.
 // ------------------------------------------------------------------------------------------------
 // the 0-based token of this launch: an argument / device word, or (GR) the fold of the previous launch's candidates
-template <bool GR>
+template <bool GR, int SHV>
 __device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
     if constexpr (GR) {
         if (a.gflags & TKG_CAND_IN) {   // the previous launch's per-CU maxima -> its greedy token (plain loads: a kernel boundary lies between)
@@ -1139,8 +1139,19 @@ __device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
                 if (cd.x > bv || (cd.x == bv && ci < bi)) { bv = cd.x; bi = ci; }
             }
             tk_wave_argmax(bv, bi);
-            if ((a.gflags & TKG_ID) && c == 0 && lane == 0)
-                __hip_atomic_store(reinterpret_cast<int*>(a.herr + 4) + a.tok_imm, bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // No finite maximum among the candidates (all NaN / -inf: a bad upload, an overflow) leaves the seed index: raise
+            // the sticky word instead of using it as an embedding row (advisor, round 3)
+            const bool none = (unsigned)bi >= (unsigned)SHV;
+            if (none) bi = 0;
+            // The id of the PREVIOUS position is published only while the error word is clear: once a launch has timed out its
+            // candidates are garbage, and so is everything folded from them.  The host then sees no id from that position on,
+            // retires the token kernel and redoes exactly those positions on the multi-kernel path (llmk_decode_greedy).
+            if (c == 0 && lane == 0) {
+                if (none) atomicOr(a.err, 0x2000u);
+                const unsigned e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((a.gflags & TKG_ID) && e == 0 && !none)
+                    __hip_atomic_store(reinterpret_cast<int*>(a.herr + 4) + a.tok_imm, bi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return bi;
         }
     }
@@ -1167,7 +1178,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     constexpr int GPC_A = (SH::R_A / 2 + 2) / 3;
     constexpr bool HB3 = LLMK_TK_HB3 && !SH::GCOOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
     const int L = a.L;
-    const int tok = tk_token<GR>(a, c, lane);
+    const int tok = tk_token<GR, SH::V>(a, c, lane);
     const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
     constexpr int HPC = TK_NCU / SH::NH;

@@ -75,7 +75,22 @@ contains
     read(u, iostat=ios) w%wcls
     if (ios /= 0) w%wcls = w%token_embedding_table      ! llama2.c files with a shared classifier end here
     close(u)
-    if (verbose) print *, "loaded ak weights:", size(w%wqkv) + size(w%wo) + size(w%w13) + size(w%w2) + size(w%wcls)
+    if (verbose) then
+       ! the reference's lines, its counts included: "wv" is ONE layer's slice and "w3" a single hidden row across the layers
+       ! (llama2.f90:230 size(wqkv(:,emb+kv+1:,l)), :271 size(w13(:,hidden_dim,:))) -- what -v printed is what -v prints
+       print *, "loaded embedding weights:", size(w%token_embedding_table)
+       print *, "loaded rms att weights:", size(w%rms_att_weight)
+       print *, "loaded wq weights:", E * E * L_
+       print *, "loaded wk weights:", E * KV * L_
+       print *, "loaded wv weights:", E * KV
+       print *, "loaded wo weights:", size(w%wo)
+       print *, "loaded rms ffn  weights:", size(w%rms_ffn_weight)
+       print *, "loaded w1 weights:", E * H * L_
+       print *, "loaded w2 weights:", size(w%w2)
+       print *, "loaded w3 weights:", E * L_
+       print *, "loaded rms_final weights:", size(w%rms_final_weight)
+       if (ios == 0) print *, "loaded wcls weights:", size(w%wcls)      ! (a shared classifier prints nothing, :281-288)
+    end if
   end subroutine load_ak
 
 end module ak_loader

@@ -17,7 +17,7 @@ module read_ggml
   use weight_module
   implicit none
   private
-  public :: load_ggml, stream_ggml_weights, half_bits_to_real, tensor_sink
+  public :: load_ggml, stream_ggml_weights, half_bits_to_real, tensor_sink, verbose_ext
   public :: TID_TOKEN_EMBEDDING_TABLE, TID_RMS_ATT_WEIGHT, TID_RMS_FFN_WEIGHT, TID_WQKV, TID_WO, TID_W13, TID_W2, &
             TID_RMS_FINAL_WEIGHT, TID_WCLS
 
@@ -53,6 +53,10 @@ module read_ggml
   integer(8) :: data_pos          ! 1-based stream position of the tensor data section
   integer :: u                    ! unit
   logical :: deferred = .false.   ! load_ggml(..., defer=.true.) left the matrices in the (still open) file
+  ! `-v` prints the reference's lines, in the reference's order and format (read_ggml.f90:114-120, 136, 155-156, 181-182,
+  ! 208-214, 234-235, 245-413, 438, 457, 467, 479); what this loader can say beyond them (matrix type, streaming) is printed
+  ! only when the host also sets this (llm --vx)
+  logical :: verbose_ext = .false.
 
 contains
 
@@ -109,7 +113,10 @@ contains
        select case (vtype)
        case (8)
           call read_string(str)
-          if (v) print *, key, " = ", str
+          if (v) then
+             print *, pad64(key)                ! print *, keys(i): character(len=64)          read_ggml.f90:155
+             print *, pad64(str)                ! print_multi: m%string is character(64)       :692-693
+          end if
        case (9)
           read(u) etype, n
           if (key == "tokenizer.ggml.tokens" .and. etype == 8) then
@@ -127,10 +134,22 @@ contains
           else
              call skip_array(etype, n)
           end if
-          if (v) print *, key, " : array of", n
+          if (v) then
+             print *, pad64(key)
+             print *, int(n, 4)                 ! print *, size(m%a)                           :700-701
+          end if
        case default
           ival = read_scalar(vtype)
-          if (v) print *, key, " = ", ival
+          if (v) then
+             if (key == "general.alignment") print *, "alignment set to", int(ival, 4)          ! :136 (before the key line)
+             print *, pad64(key)
+             select case (vtype)
+             case (4, 5); print *, int(ival, 4)                                                  ! m%i32   :694-697
+             case (6);    print *, real(last_real, 4)                                            ! m%f32   :698-699
+             case (12);   print *, last_real      ! (the types below stop the reference: "Not implemented", :682-684)
+             case default; print *, ival
+             end select
+          end if
           select case (key)
           case ("general.alignment");               alignment = int(ival)
           case ("llama.block_count");                n_layers = int(ival, 4)
@@ -207,7 +226,6 @@ contains
     if (.not. deferred) then
        allocate(w%token_embedding_table(E, vocab_size))
        call read_matrix_as_f32("token_embd.weight", w%token_embedding_table, E, vocab_size)
-       if (v) print *, "loaded embedding weights:", size(w%token_embedding_table)
     end if
 
     allocate(w%rms_att_weight(E, n_layers), w%rms_ffn_weight(E, n_layers), w%rms_final_weight(E))
@@ -216,10 +234,9 @@ contains
        call read_vector(layer_name(l, "ffn_norm.weight"), w%rms_ffn_weight(:, l), E)
     end do
     call read_vector("output_norm.weight", w%rms_final_weight, E)
-    if (v) print *, "loaded rms weights:", size(w%rms_att_weight), size(w%rms_ffn_weight), size(w%rms_final_weight)
 
     if (deferred) then
-       if (v) print *, "matrices stay in the file (streamed to the device), ggml type", mt
+       if (v .and. verbose_ext) print *, "matrices stay in the file (streamed to the device), ggml type", mt
     else if (mt == GT_F32) then
        allocate(w%wqkv(E, E + 2*KV, n_layers), w%wo(E, E, n_layers), w%w13(E, 2*H, n_layers), &
                 w%w2(H, E, n_layers), w%wcls(E, vocab_size))
@@ -257,7 +274,24 @@ contains
           w%wcls_type = GT_F32
        end if
     end if
-    if (v .and. .not. deferred) print *, "loaded matmul weights, ggml type", mt
+    if (v) then
+       ! the reference's twelve lines in its order (read_ggml.f90:245-413: it loads family by family, this loader layer by
+       ! layer -- the counts are the arrays' element counts whatever the matrices' encoding, and whether or not they are
+       ! still in the file)
+       call loaded("loaded embedding weights:", int(E, 8) * vocab_size)
+       call loaded("loaded rms att weights:", int(E, 8) * n_layers)
+       call loaded("loaded wq weights:", int(E, 8) * E * n_layers)
+       call loaded("loaded wk weights:", int(E, 8) * KV * n_layers)
+       call loaded("loaded wv weights:", int(E, 8) * KV * n_layers)
+       call loaded("loaded wo weights:", int(E, 8) * E * n_layers)
+       call loaded("loaded ffn norm weights:", int(E, 8) * n_layers)
+       call loaded("loaded w1 (gate) weights:", int(E, 8) * H * n_layers)
+       call loaded("loaded w2 (down) weights:", int(E, 8) * H * n_layers)
+       call loaded("loaded w3 (up) weights:", int(E, 8) * H * n_layers)
+       call loaded("loaded output norm weights:", int(E, 8))
+       call loaded("loaded classifier weights:", int(E, 8) * vocab_size)
+       if (verbose_ext .and. .not. deferred) print *, "loaded matmul weights, ggml type", mt
+    end if
 
     ! ---- vocabulary (second visit of the tokens array) ---------------------------------------
     if (tokens_pos == 0 .or. .not. allocated(scores)) then
@@ -286,6 +320,7 @@ contains
        deallocate(str)
     end do
     if (v) then
+       print *, "loading tokens"                                                                  ! read_ggml.f90:438
        write (*, "(A,I0,A)") "found ", size(vocab), " tokens"
        write (*, "(A,I0,A)") "found ", size(scores), " scores"
        print *, "maximum token length ", maxval(token_lengths)
@@ -296,7 +331,25 @@ contains
        deallocate(dir)
     end if
 
+  contains
+    ! `print *, "loaded ...", size(array)`: a default integer in the reference (element counts beyond it wrap there)
+    subroutine loaded(what, n)
+      character(len=*), intent(in) :: what
+      integer(8), intent(in) :: n
+      if (n <= huge(1_4)) then
+         print *, what, int(n, 4)
+      else
+         print *, what, n
+      end if
+    end subroutine
   end subroutine load_ggml
+
+  ! a string as the reference holds it: character(len=64), blank-padded or cut (read_ggml.f90:15, 66, 127)
+  function pad64(sv) result(r)
+    character(len=*), intent(in) :: sv
+    character(len=NAME_LEN) :: r
+    r = sv
+  end function
 
   function layer_name(l1, suffix) result(nm)
     integer, intent(in) :: l1
@@ -371,7 +424,7 @@ contains
        call stream_rows(layer_name(l1, "ffn_up.weight"), TID_W13, l1 - 1, E, H, tp_rank * Hl, Hl, H + tp_rank * Hl)
        call stream_rows(layer_name(l1, "ffn_down.weight"), TID_W2, l1 - 1, H, E, 0, E, 0)
     end do
-    if (v) print *, "streamed matmul weights, ggml type", mt, " largest host buffer (bytes)", peak
+    if (v .and. verbose_ext) print *, "streamed matmul weights, ggml type", mt, " largest host buffer (bytes)", peak
     close(u)
     deallocate(dir)
     deferred = .false.

@@ -22,6 +22,7 @@ module arg_parse
      character(:), allocatable :: prompt
      character(:), allocatable :: tokenizer
      logical :: verbose, ak
+     logical :: verbose_ext       ! extension: --vx adds this loader's own lines to -v (the matrices' ggml type, streaming)
      integer :: n
      integer :: device            ! extension: HIP device ordinal
      logical :: device_argmax     ! extension: greedy pick on the GPU (SURVEY.md 8f rank 1)
@@ -49,6 +50,7 @@ contains
     a%prompt = ""
     a%tokenizer = ""
     a%verbose = .false.
+    a%verbose_ext = .false.
     a%ak = .false.
     a%n = 256
     a%device = 0
@@ -78,6 +80,7 @@ contains
        case ("-n", "--num_tokens");  read (val, *) a%n;           i = i + 2
        case ("-d", "--device");      read (val, *) a%device;      i = i + 2
        case ("-v", "--verbose");     a%verbose = .true.;       i = i + 1
+       case ("--vx");                a%verbose = .true.; a%verbose_ext = .true.; i = i + 1
        case ("--ak");                a%ak = .true.;            i = i + 1
        case ("--device-argmax");     a%device_argmax = .true.; i = i + 1
        case ("--prefill");           a%prefill = .true.;       i = i + 1
@@ -147,7 +150,7 @@ program llm
   use precision_module
   use weight_module
   use arg_parse
-  use read_ggml, only: load_ggml, stream_ggml_weights
+  use read_ggml, only: load_ggml, stream_ggml_weights, verbose_ext
   use ak_loader, only: load_ak
   use llmk_binding
   implicit none
@@ -189,6 +192,7 @@ program llm
      ! --ngpu N (and --stream-load): the matrices stay in the file until the device context exists, then each rank streams
      ! the rows of its own shard to its GPU -- no rank ever holds the model, or even a layer, in host memory
      if (opts%ngpu > 1) opts%stream_load = .true.
+     verbose_ext = opts%verbose_ext
      call load_ggml(opts%model_file, weights, conf, vocab, scores, vocab_len, opts%verbose .and. lead, defer=opts%stream_load)
   end if
   if (opts%verbose .and. lead) print *, "Loaded weights"
@@ -274,9 +278,12 @@ program llm
   end if
   ! --device-argmax at temperature 0: every position after the prompt is one call (llmk_decode_greedy: the argmax stays on
   ! the device, the launches are enqueued back to back, the ids stream back through mapped memory and are printed as they
-  ! arrive).  The positions whose next token is a PROMPT token still go through the loop below.
+  ! arrive).  The positions whose next token is a PROMPT token still go through the loop below -- and so does the FIRST
+  ! position in any case: the reference starts its clock after the first token (llama2.f90:398-399) and divides seq_len - 1
+  ! tokens by what follows, so that token is produced, and the clock started, before the pipelined launches are enqueued
+  ! (started at the first streamed id instead, several tokens had already completed: the printed rate was slightly high).
   loop_end = seq_len
-  if (opts%device_argmax .and. opts%temperature == 0 .and. opts%ngpu == 1) loop_end = min(seq_len, max(size(prompt_tokens), pos0 - 1))
+  if (opts%device_argmax .and. opts%temperature == 0 .and. opts%ngpu == 1) loop_end = min(seq_len, max(size(prompt_tokens), pos0))
   do pos = pos0, loop_end
      call llmk_check(llmk_forward(ctx, int(token, c_int), int(pos, c_int), logits), "llmk_forward")
      if (pos <= size(prompt_tokens)) then

@@ -35,6 +35,9 @@ CASES = [
     ("tk-small", 32, ""),
     ("tk-small", 24, "GPU token"),
     ("tiny-gqa", 16, "ak"),          # same weights through the `--ak` flat format + `-s tokenizer.bin`
+    # the reference's `-v` transcript (round-3 verdict, "missing" 4): stdout only, GGUF and --ak
+    ("tiny-gqa", 12, "VERBOSE"),
+    ("tiny-gqa", 12, "VERBOSE-ak"),
     # long contexts: the KV length crosses the attention kernels' timestep tiles (256 for head size 64, 128 for 128)
     ("tk-small-long", 704, ""),      # the whole context of the persistent-kernel parity shape: tiles at 256 and 512
     ("tk-small-long", 300, "LONG"),  # 256-character prompt (the reference's argument buffer is character(256), llama2.f90:21)
@@ -67,7 +70,10 @@ def main():
             if only and name not in only:
                 continue
             s = gguf.SHAPES[name]
-            ak = prompt == "ak"
+            verbose = prompt.startswith("VERBOSE")
+            ak = prompt in ("ak", "VERBOSE-ak")
+            if verbose:
+                prompt = "ak" if ak else ""
             q4dec = prompt.startswith("Q4COMPACT")
             compact = prompt == "COMPACT" or q4dec
             if q4dec and name not in only:
@@ -92,6 +98,13 @@ def main():
             cmd = [exe, "-m", path, "-n", str(n), "-t", "0"] + (["-p", prompt] if prompt else [])
             if ak:
                 cmd += ["--ak", "-s", tokp]
+            if verbose:
+                r = subprocess.run(cmd + ["-v"], cwd=td, capture_output=True, check=True)
+                tag = name + ("-ak" if ak else "") + "-verbose"
+                np.savez_compressed(os.path.join(outdir, tag + ".npz"), shape=name, seed=SEED, n=n, ak=ak,
+                                    stdout=np.frombuffer(r.stdout, np.uint8))
+                print(f"{tag}: {r.stdout.count(10)} lines of -v output")
+                continue
             r = subprocess.run(cmd, cwd=td, capture_output=True, check=True)
             logits = np.fromfile(os.path.join(td, "logits.bin"), dtype="<f4").reshape(n, s.vocab_size)
             pids = prompt_ids(prompt)

@@ -111,3 +111,39 @@ def test_cli_device_argmax_streams_the_reference_transcript(gguf, tmp_path):
         out, ref = r.stdout.split(b"\n"), bytes(g["stdout"]).split(b"\n")
         k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
         assert out[:k] == ref[:k], tag
+
+
+@pytest.mark.parametrize("at", [1, 7, 32], ids=["first-launch", "mid-pipeline", "last-launch"])
+def test_decode_greedy_timeout_inside_the_pipeline_still_returns_the_reference_ids(at):
+    """Advisor (round 3, medium): a launch of the pipelined greedy decode that times out leaves garbage candidates, and the
+    launches behind it used to fold them and publish ids from them -- llmk_decode_greedy returned LLMK_OK with a wrong
+    transcript.  Now no id is published while the device error word is set; the host retires the token kernel and redoes the
+    positions from the first missing id on the multi-kernel path.  The debug library launches position `at` one workgroup
+    short (LLMK_TK_INJECT_TIMEOUT), so the timeout is real: first, middle and last launch of the pipeline."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    dbg = os.path.join(ROOT, "llm.f90_amd", "csrc", "libllmk_debug.so")
+    assert os.path.exists(dbg), "libllmk_debug.so not built (make -C llm.f90_amd debug)"
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import llm_f90_amd\n"
+        "from llm_f90_amd import llmk\n"
+        "from llm_f90_amd.tools import gguf\n"
+        "from conftest import load_golden\n"
+        "g = load_golden('tk-small')\n"
+        "fw = gguf.synth_fused(gguf.SHAPES['tk-small'], int(g['seed']))\n"
+        "m = llmk.Llmk(fw)\n"
+        "assert m.path() == 1\n"
+        "seen = []\n"
+        "ids = m.decode_greedy(2, 1, int(g['n']), on_token=lambda i, t, u: seen.append((i, t)))\n"
+        "assert np.array_equal(ids, g['tokens']), (ids.tolist(), g['tokens'].tolist())\n"
+        "assert seen == [(i, int(t)) for i, t in enumerate(g['tokens'])], seen\n"     # streamed once each, in order, the right ids
+        "assert m.path() == 0\n"                                                      # retired to the multi-kernel path
+        "print('PIPELINE-FALLBACK-OK')\n")
+    env = dict(os.environ, LLMK_LIB=dbg, LLMK_TK_INJECT_TIMEOUT=str(at))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
+    assert r.returncode == 0 and b"PIPELINE-FALLBACK-OK" in r.stdout, r.stdout + r.stderr
+    assert b"timed out" in r.stderr and b"multi-kernel path" in r.stderr

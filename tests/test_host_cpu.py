@@ -208,3 +208,27 @@ def test_converter_cli_replaces_load_f90(tools, gguf, tmp_path):
     assert d["wtype"] == 2 and np.array_equal(d["wo"].reshape(-1), got.wo.view(np.uint8).reshape(-1))
     r = subprocess.run([sys.executable, conv, src], capture_output=True)
     assert r.returncode != 0 and b"nothing to do" in r.stderr
+
+
+@pytest.mark.parametrize("ak", [False, True], ids=["gguf", "ak"])
+def test_verbose_loader_lines_are_the_reference_s(tools, gguf, ak):
+    """`-v` (round-3 verdict, "missing" 4): everything the reference prints while it loads -- header, every key / value
+    pair at the reference's 64-character width, position / deficit / data offset, the dims, the twelve "loaded ..." lines in
+    the reference's order with the reference's counts, the tokenizer lines, "Loaded weights" -- byte for byte
+    (tests/golden/tiny-gqa[-ak]-verbose.npz = the real reference's stdout).  No GPU needed up to that line."""
+    g = load_golden("tiny-gqa-ak-verbose" if ak else "tiny-gqa-verbose")
+    s = gguf.SHAPES["tiny-gqa"]
+    d = tools["dir"]
+    if ak:
+        path, tok = str(d / "v.ak"), str(d / "v.tok")
+        gguf.write_ak(path, gguf.synth_fused(s, int(g["seed"])))
+        gguf.write_tokenizer_bin(tok, gguf.vocab_strings(s.vocab_size))
+        args = ["-m", path, "--ak", "-s", tok]
+    else:
+        path = str(d / "v.gguf")
+        gguf.write_synth_gguf(path, s, int(g["seed"]))
+        args = ["-m", path]
+    r = subprocess.run([tools["llm"]] + args + ["-n", str(int(g["n"])), "-t", "0", "-v"], capture_output=True)
+    ref = bytes(g["stdout"]).split(b"\n")
+    k = ref.index(b" Loaded weights") + 1
+    assert r.stdout.split(b"\n")[:k] == ref[:k]

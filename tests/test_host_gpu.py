@@ -39,6 +39,28 @@ def test_cli_output_matches_reference_transcript(tag, gguf, tmp_path):
     assert [l.split()[0] for l in out[k + 3:k + 8]] == [b"1", b"2", b"3", b"4", b"5"]   # same 5 timer lines
 
 
+@pytest.mark.parametrize("tag", ["tiny-gqa-verbose", "tiny-gqa-ak-verbose"])
+def test_cli_verbose_output_matches_reference_transcript(tag, gguf, tmp_path):
+    """`-v`: the whole transcript -- the loader's lines, "Loaded weights", the generated text -- is the reference's, byte for
+    byte, up to the timing report (round-3 verdict, "missing" 4; read_ggml.f90:114-479, llama2.f90:169-296)."""
+    g = load_golden(tag)
+    s = gguf.SHAPES[str(g["shape"])]
+    if bool(g["ak"]):
+        path, tok = str(tmp_path / "m.ak"), str(tmp_path / "tokenizer.bin")
+        gguf.write_ak(path, gguf.synth_fused(s, int(g["seed"])))
+        gguf.write_tokenizer_bin(tok, gguf.vocab_strings(s.vocab_size))
+        args = ["-m", path, "--ak", "-s", tok]
+    else:
+        path = str(tmp_path / "m.gguf")
+        gguf.write_synth_gguf(path, s, int(g["seed"]))
+        args = ["-m", path]
+    out = _run(args + ["-n", str(int(g["n"])), "-t", "0", "-v"], str(tmp_path)).split(b"\n")
+    ref = bytes(g["stdout"]).split(b"\n")
+    k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
+    assert out[:k] == ref[:k]
+    assert out[k].startswith(b" Inference time:") and out[k + 2].strip() == b"Timings"
+
+
 def test_cli_device_argmax_and_verbose_timings(gguf, tmp_path):
     g = load_golden("tiny-hs64")
     path = str(tmp_path / "m.gguf")

@@ -105,7 +105,15 @@ def _rank_stress(rank, rounds, seed, conn):
     side.all_gather_object(handles, m.tp_p2p_handle())
     m.tp_p2p_connect(handles)
     side.all_gather_object(first, m.tp_p2p_selftest(8))
-    rc = m.tp_p2p_stress(rounds, seed)
+    import time
+    rc, t0 = 0, time.time()
+    with open(os.path.join(_fail_dir(), f"stress_rank{rank}.log"), "w") as hb:      # heartbeat: where each rank was, and when
+        for part in range(0, rounds, 100):
+            rc = m.tp_p2p_stress(min(100, rounds - part), seed + part)
+            hb.write(f"{part + 100} rounds rc {rc} at {time.time() - t0:.2f} s\n")
+            hb.flush()
+            if rc:
+                break
     after = m.tp_p2p_selftest(8) if rc == 0 else -1               # and the plain exchanges still work behind it
     conn.send(("result", (first, rc, after)))
     m.close()
@@ -123,20 +131,62 @@ def _rank_full_size(rank, n, conn):
     m.close()
 
 
+def _fail_dir():
+    from conftest import ROOT
+    out = os.path.join(ROOT, "gpurun_out", "tp70_fail")
+    os.makedirs(out, exist_ok=True)
+    return out
+
+
+def _rank_main(target, rank, args, conn, faildir):
+    """entry point of a rank process: SIGUSR1 dumps every thread's stack to <faildir>/stack_rank<r>.txt (the parent asks
+    for it when a rank goes silent), an exception leaves its traceback in <faildir>/error_rank<r>.txt"""
+    import faulthandler
+    import signal
+    import traceback
+    faulthandler.register(signal.SIGUSR1, file=open(os.path.join(faildir, f"stack_rank{rank}.txt"), "w"), all_threads=True)
+    try:
+        target(*args, conn)
+    except BaseException:
+        with open(os.path.join(faildir, f"error_rank{rank}.txt"), "w") as f:
+            traceback.print_exc(file=f)
+        raise
+
+
 def _run_ranks(target, args_of, timeout):
-    """P rank processes; the parent relays their all-gathers until every rank has delivered its result"""
+    """P rank processes; the parent relays their all-gathers until every rank has delivered its result.  A rank that dies is
+    named with its exit code and traceback; if a rank goes silent every rank's Python stack is dumped before they are killed."""
     import multiprocessing as mp
+    import signal
+    import time
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(P)]
-    procs = [ctx.Process(target=target, args=args_of(r) + (pipes[r][1],)) for r in range(P)]
+    faildir = _fail_dir()
+    procs = [ctx.Process(target=_rank_main, args=(target, r, args_of(r), pipes[r][1], faildir)) for r in range(P)]
     for p in procs:
         p.start()
 
+    def read_file(name):
+        try:
+            return open(os.path.join(faildir, name)).read()[-1500:]
+        except OSError:
+            return ""
+
     def get(r):
-        if not pipes[r][0].poll(timeout):
-            for p in procs:
-                p.terminate()
-            pytest.fail(f"rank {r} went silent")
+        t_end = time.time() + timeout
+        while not pipes[r][0].poll(1.0):
+            dead = [(k, p.exitcode) for k, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or time.time() > t_end:
+                if not dead:
+                    for p in procs:
+                        if p.is_alive():
+                            os.kill(p.pid, signal.SIGUSR1)
+                    time.sleep(2)
+                for p in procs:
+                    p.terminate()
+                if dead:
+                    pytest.fail(f"rank(s) died (rank, exit code): {dead}\n" + "\n".join(read_file(f"error_rank{k}.txt") for k, _ in dead))
+                pytest.fail(f"rank {r} went silent for {timeout} s; stacks:\n" + "\n".join(f"--- rank {k}\n" + read_file(f"stack_rank{k}.txt") for k in range(P)))
         return pipes[r][0].recv()
     while True:
         msgs = [get(r) for r in range(P)]
