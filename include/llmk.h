@@ -68,6 +68,7 @@ extern "C" {
 #define LLMK_E_NOMEM 7
 #define LLMK_E_TIMEOUT 8   /* an in-kernel exchange timed out (GPU shared with other work?)        */
 #define LLMK_E_COMM 9      /* tensor-parallel ctx used before llmk_tp_init_comm, or an RCCL error       */
+#define LLMK_E_VERIFY 10   /* an uploaded block's word sum on the device differed from the host's, three times over      */
 #define LLMK_E_HIP 1000    /* 1000 + hipError_t                                                     */
 
 /* Run-time replacement of the reference's compile-time dims (llama2.f90:102-108) and of
@@ -181,7 +182,7 @@ int llmk_forward(llmk_ctx *ctx, int token, int pos, float *logits_out);
  * through MFMA GEMMs (a layer's weights cross HBM once per batch); tensor-parallel contexts, and shapes whose emb_dim /
  * hidden_dim is not a multiple of the GEMM's 64-column step, run the token-by-token pass inside.
  * The GEMMs multiply on the f16 matrix instruction with each f32 activation (and each f32 / q4_0 weight) as two f16 pieces
- * (exact products, |error| <= 2^-20 of the operand; csrc/prefill.h); a prompt with an activation of magnitude >= 65504 is redone on the
+ * (exact products; |error| <= 2^-20 of an operand of magnitude >= 2^-3, 2^-24 absolute below: csrc/prefill.h); a prompt with an activation of magnitude >= 65504 is redone on the
  * f32 instruction inside the same call, and the context stays there.  LLMK_PF_F32_MFMA=1 in the environment selects the
  * f32 instruction from the start. */
 int llmk_prefill(llmk_ctx* ctx, const int* tokens, int n, int pos0, float* logits_out);
@@ -215,7 +216,8 @@ int llmk_timings(llmk_ctx *ctx, float ms[5]);
  * the algorithmic bytes one launch moves.  kernel: 0 qkv, 1 attention, 2 wo, 3 w13, 4 w2,
  * 5 classifier (successive launches walk the layers), 6 the persistent whole-token kernel
  * (LLMK_E_ARG when the ctx runs the multi-kernel path), 7..10 the w1|w3, wqkv, wo, w2 GEMMs of llmk_prefill at 128 positions
- * (bytes = that matrix of one layer; flop = 2 * 128 * rows * K). */
+ * (bytes = that matrix of one layer; flop = 2 * 128 * rows * K), 11 the five per-layer kernels of the multi-kernel path (a
+ * tensor-parallel rank's too, without its exchanges) for all layers as one hipGraph: milliseconds and bytes per LAYER. */
 int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double *bytes_per_launch);
 
 /* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),

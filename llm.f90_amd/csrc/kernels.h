@@ -17,6 +17,7 @@ namespace llmk {
 constexpr int WAVE = 64;
 constexpr int GEMV_THREADS = 256;  // 4 waves
 constexpr int GEMV_WAVES = GEMV_THREADS / WAVE;
+constexpr int GEMV_SU = 8;         // vectors of x per thread requested at once while a block stages it (K <= 8192: all of them)
 
 enum WeightType { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2 };
 enum Epilogue {
@@ -288,21 +289,33 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
     }
     const bool pf = active && (ncol >= NCH);
     Tile<WT, ROWS, NCH> pre;
-    if (pf) pre.load(w, sc, lane);
 
     // ---- stage x (optionally rmsnorm'ed) into LDS -------------------------------------------
     {
         const float4* xg = reinterpret_cast<const float4*>(a.x);
         float ss = 0.f;
-        for (int i = tid; i < nx4; i += GEMV_THREADS) {
-            float4 v = xg[i];
-            if (NORM) ss = dot4(v, v, ss);
-            if (WT == WT_Q4_0) {  // transposed staging: element group m of block b
-                xs[(i & 7) * nvec + (i >> 3)] = v;
-            } else {
-                xs[i] = v;
-            }
+        // x's loads go out first, GEMV_SU per thread at once, then the weight tile; x is staged while the weights stream
+        // (round 4: one load per trip was a dependent L2 round trip per trip, the first behind the weight tile -- see gemv_q4_kernel)
+        float4 v[GEMV_SU];
+#define G_X_REQUEST(I0_) _Pragma("unroll") for (int u = 0; u < GEMV_SU; ++u) v[u] = xg[min((I0_) + u * GEMV_THREADS, nx4 - 1)];
+#define G_X_STAGE(I0_)                                                          \
+        _Pragma("unroll") for (int u = 0; u < GEMV_SU; ++u) {                    \
+            const int i_ = (I0_) + u * GEMV_THREADS;                             \
+            if (i_ < nx4) {                                                      \
+                if (NORM) ss = dot4(v[u], v[u], ss);                             \
+                if (WT == WT_Q4_0) xs[(i_ & 7) * nvec + (i_ >> 3)] = v[u];       \
+                else xs[i_] = v[u];                                              \
+            }                                                                    \
         }
+        G_X_REQUEST(tid)
+        if (pf) pre.load(w, sc, lane);
+        G_X_STAGE(tid)
+        for (int i0 = tid + GEMV_THREADS * GEMV_SU; i0 < nx4; i0 += GEMV_THREADS * GEMV_SU) {
+            G_X_REQUEST(i0)
+            G_X_STAGE(i0)
+        }
+#undef G_X_REQUEST
+#undef G_X_STAGE
         if (NORM) {
             ss = wave_sum(ss);
             if (lane == 0) red[wid] = ss;
@@ -310,15 +323,23 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a) {
             ss = red[0] + red[1] + red[2] + red[3];
             const float xn = sqrtf(ss / (float)K + a.eps);
             const float4* wg = reinterpret_cast<const float4*>(a.norm_w);
-            for (int i = tid; i < nx4; i += GEMV_THREADS) {
-                const int li = (WT == WT_Q4_0) ? ((i & 7) * nvec + (i >> 3)) : i;
-                float4 v = xs[li];
-                const float4 nw = wg[i];
-                v.x = v.x * nw.x / xn;
-                v.y = v.y * nw.y / xn;
-                v.z = v.z * nw.z / xn;
-                v.w = v.w * nw.w / xn;
-                xs[li] = v;
+            for (int i0 = tid; i0 < nx4; i0 += GEMV_THREADS * GEMV_SU) {
+                float4 nw[GEMV_SU];
+#pragma unroll
+                for (int u = 0; u < GEMV_SU; ++u) nw[u] = wg[min(i0 + u * GEMV_THREADS, nx4 - 1)];
+#pragma unroll
+                for (int u = 0; u < GEMV_SU; ++u) {
+                    const int i = i0 + u * GEMV_THREADS;
+                    if (i < nx4) {
+                        const int li = (WT == WT_Q4_0) ? ((i & 7) * nvec + (i >> 3)) : i;
+                        float4 xv = xs[li];
+                        xv.x = xv.x * nw[u].x / xn;
+                        xv.y = xv.y * nw[u].y / xn;
+                        xv.z = xv.z * nw[u].z / xn;
+                        xv.w = xv.w * nw[u].w / xn;
+                        xs[li] = xv;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -451,18 +472,8 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
         rows[2 * j] = (EPI == EPI_SWIGLU) ? g : 2 * g;
         rows[2 * j + 1] = (EPI == EPI_SWIGLU) ? g + a.H : 2 * g + 1;
     }
-    // first block column of all 8 rows is requested before x is staged
     uint4 wq[NR];
     __half wd[NR];
-    {
-        const int b = min(cb0 + lane, nblk - 1);
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const char* rp = Wb + (size_t)rows[i] * RS;
-            wq[i] = ldg_nt(reinterpret_cast<const uint4*>(rp) + b);
-            wd[i] = reinterpret_cast<const __half*>(rp + soff)[b];
-        }
-    }
     // ---- stage x: transposed float4 groups + per-block sums ------------------------------------
     float xn = 1.f;
     {
@@ -472,18 +483,50 @@ __global__ __launch_bounds__(GEMV_THREADS) void gemv_q4_kernel(GemvArgs a) {
         // ONE pass: rmsnorm (llama2.f90:450-457) stages x*w -- the gains do not wait for the sum of squares, because the
         // division by sqrt(mean(x^2)+eps) is linear in the dot product and is applied once to each finished row sum
         // (round 3: the separate multiply pass over LDS and its barrier are gone; same products, same sums)
-        for (int i = tid; i < nx4; i += GEMV_THREADS) {
-            float4 v = xg[i];
-            if (NORM) {
-                ss = dot4(v, v, ss);
-                const float4 nw = wg[i];
-                v.x = v.x * nw.x;
-                v.y = v.y * nw.y;
-                v.z = v.z * nw.z;
-                v.w = v.w * nw.w;
-            }
-            xs[(i & 7) * xp + (i >> 3)] = v;
+        // Round 4 (found in the ISA): written as one load per trip, hipcc waits for each -- `s_waitcnt vmcnt(0)` inside the loop:
+        // K = 8192 was eight dependent L2 round trips, and vmcnt retires in order, so the first of them also waited for the
+        // weight column requested ahead of it (an HBM round trip): ~5 us of the 6-12 us a 70B-rank GEMV took.  Now GEMV_SU
+        // vectors of x (and of the gains) per thread are requested at once, AHEAD of the weights (x comes from L2 and is
+        // needed first), and staged while the weights stream.  Same elements, same order per thread: the same sums.
+        float4 v[GEMV_SU], nw[GEMV_SU];
+        // (macros, not lambdas: captured by reference the two arrays went to scratch in the instantiations without NORM)
+#define Q4_X_REQUEST(I0_)                                                       \
+        _Pragma("unroll") for (int u = 0; u < GEMV_SU; ++u) {                    \
+            const int i_ = min((I0_) + u * GEMV_THREADS, nx4 - 1);               \
+            v[u] = xg[i_];                                                       \
+            if (NORM) nw[u] = wg[i_];                                            \
         }
+#define Q4_X_STAGE(I0_)                                                         \
+        _Pragma("unroll") for (int u = 0; u < GEMV_SU; ++u) {                    \
+            const int i_ = (I0_) + u * GEMV_THREADS;                             \
+            if (i_ < nx4) {                                                      \
+                if (NORM) {                                                      \
+                    ss = dot4(v[u], v[u], ss);                                   \
+                    v[u].x = v[u].x * nw[u].x;                                   \
+                    v[u].y = v[u].y * nw[u].y;                                   \
+                    v[u].z = v[u].z * nw[u].z;                                   \
+                    v[u].w = v[u].w * nw[u].w;                                   \
+                }                                                                \
+                xs[(i_ & 7) * xp + (i_ >> 3)] = v[u];                            \
+            }                                                                    \
+        }
+        Q4_X_REQUEST(tid)
+        {   // first block column of all NR rows: requested before x is staged, behind x's own loads
+            const int b = min(cb0 + lane, nblk - 1);
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const char* rp = Wb + (size_t)rows[i] * RS;
+                wq[i] = ldg_nt(reinterpret_cast<const uint4*>(rp) + b);
+                wd[i] = reinterpret_cast<const __half*>(rp + soff)[b];
+            }
+        }
+        Q4_X_STAGE(tid)
+        for (int i0 = tid + GEMV_THREADS * GEMV_SU; i0 < nx4; i0 += GEMV_THREADS * GEMV_SU) {   // K > 8192 (Llama-2-7B's w2: 11008)
+            Q4_X_REQUEST(i0)
+            Q4_X_STAGE(i0)
+        }
+#undef Q4_X_REQUEST
+#undef Q4_X_STAGE
         if (NORM) {
             ss = wave_sum(ss);
             if (lane == 0) red[wid] = ss;

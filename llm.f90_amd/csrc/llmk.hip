@@ -388,7 +388,8 @@ int tk_setup(llmk_ctx* c, int id) {
     if (c->use_tk || g.emb_dim != TK::E || g.hidden_dim != TK::H || g.n_heads != TK::NH || g.n_kv_heads != TK::NKV ||
         g.vocab_size != TK::V || g.weight_type != TK::WT)
         return LLMK_OK;
-    const size_t lds = (size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float);   // scores + exp(scores)
+    // scores + exp(scores), then the LDS annex (f16: the layer's w2 tiles, token_kernel.h LLMK_TK_ANNEX)
+    const size_t lds = (((size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float) + 15) & ~(size_t)15) + TK::ANNEX_BYTES;
     c->tk_lds = lds < 96 * 1024 ? 96 * 1024 : lds;   // > 80 KB: never two workgroups on one CU
     if (c->tk_lds > 160 * 1024) return LLMK_OK;      // context too long for the in-LDS score row: multi-kernel path
     // The kernel spins on its peers, so all TK_NCU workgroups must be co-resident: one per CU by construction (the LDS
@@ -910,6 +911,7 @@ const char* llmk_strerror(int code) {
         case LLMK_E_NOMEM: return "llmk: out of memory";
         case LLMK_E_TIMEOUT: return "llmk: device-side exchange timed out (persistent kernel not fully resident?)";
         case LLMK_E_COMM: return "llmk: tensor-parallel communicator missing or RCCL error";
+        case LLMK_E_VERIFY: return "llmk: uploaded weights did not arrive intact on the device (three attempts)";
     }
     if (code >= LLMK_E_HIP) return hipGetErrorString((hipError_t)(code - LLMK_E_HIP));
     return "llmk: unknown error";
@@ -1066,6 +1068,48 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     return LLMK_OK;
 }
 
+// ---- every upload is verified --------------------------------------------------------------------------------------------------
+// Round 4: in ONE of ~20 runs of the 8-rank 70B-geometry test the w1|w3 shard of ONE rank reached the device damaged (its
+// llmk_tensor_checksum differed from the host-side image right after llmk_upload; logits off by 3.6e-3 on every rank; the
+// source was a read-only mmap of a /dev/shm file that eight processes copied from at once).  Whatever the layer at fault,
+// weights are copied once and read for the life of the ctx: the 64-bit sum of the 16-bit words the host handed over is
+// compared with the same sum of what arrived (the raw copy, before any re-packing), a mismatch is reported on stderr and the
+// block is copied again (three attempts, then LLMK_E_VERIFY).  ~0.2 s per GB of host time; LLMK_VERIFY_UPLOAD=0 skips it.
+__global__ void sum16_kernel(const unsigned* __restrict__ w, size_t nbytes, unsigned long long* out) {
+    const size_t nwords = nbytes / 4;
+    unsigned long long t = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned v = w[i];
+        t += (v & 0xffffu) + (v >> 16);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (nbytes & 2)) t += reinterpret_cast<const unsigned short*>(w)[nbytes / 2 - 1];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, t);
+}
+static unsigned long long host_sum16(const uint8_t* src, size_t spitch, size_t col_bytes, size_t nrows) {
+    unsigned long long t = 0;
+    for (size_t r = 0; r < nrows; ++r) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(src + r * spitch);    // rows of every encoding start 2-byte aligned
+        unsigned long long a = 0;
+        for (size_t i = 0; i < col_bytes / 2; ++i) a += p[i];
+        t += a;
+    }
+    return t;
+}
+static bool verify_uploads() {
+    static const bool on = !(getenv("LLMK_VERIFY_UPLOAD") && getenv("LLMK_VERIFY_UPLOAD")[0] == '0');
+    return on;
+}
+// device sum of `nbytes` contiguous bytes (null stream, like the copies before it); 0 + error code on failure
+static hipError_t device_sum16(const void* dev, size_t nbytes, unsigned long long* d_acc, unsigned long long* out) {
+    hipError_t e = hipMemsetAsync(d_acc, 0, sizeof(*d_acc), 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sum16_kernel, dim3(512), dim3(256), 0, 0, (const unsigned*)dev, nbytes, d_acc);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(out, d_acc, sizeof(*out), hipMemcpyDeviceToHost);
+    return e;
+}
+
 // Copy `nrows` rows of a HOST tensor (row pitch `spitch` bytes in `type` encoding; for each row only the
 // bytes [col_off, col_off + col_bytes) -- a contraction slice for the row-parallel wo / w2) into local rows
 // dst_row0.. of layer `layer` of tensor `tid`.  q4_0 is re-packed (nibble plane + scale plane) on the way.
@@ -1074,29 +1118,52 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
     const TensorDesc& d = c->desc[tid];
     DevTensor& t = c->t[tid];
     const size_t first_row = (size_t)layer * d.rows + dst_row0;
+    const bool verify = verify_uploads();
+    unsigned long long* d_acc = nullptr;
+    if (verify) HIPCHK(dev_alloc(&d_acc, sizeof(*d_acc)));
+    int rc = LLMK_OK;
+    // one chunk: `cr` rows from src_rows into dev_dst (pitch dpitch), checked and copied again on a mismatch
+    auto copy_checked = [&](void* dev_dst, size_t dpitch, const uint8_t* src_rows, size_t cr) -> int {
+        const unsigned long long want = verify ? host_sum16(src_rows + col_off, spitch, col_bytes, cr) : 0;
+        for (int attempt = 1;; ++attempt) {
+            hipError_t e = hipMemcpy2D(dev_dst, dpitch, src_rows + col_off, spitch, col_bytes, cr, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return LLMK_E_HIP + (int)e;
+            if (!verify || dpitch != col_bytes) return LLMK_OK;          // (every destination here is contiguous: dpitch == col_bytes)
+            unsigned long long got = 0;
+            e = device_sum16(dev_dst, cr * col_bytes, d_acc, &got);
+            if (e != hipSuccess) return LLMK_E_HIP + (int)e;
+            if (got == want) return LLMK_OK;
+            fprintf(stderr, "llmk: upload of tensor %d, layer %d, local rows %zu..%zu (%zu bytes) did not arrive intact: 16-bit word sum 0x%llx on the "
+                            "device, 0x%llx on the host (attempt %d of 3)%s\n", tid, layer, first_row, first_row + cr - 1, cr * col_bytes, got, want,
+                    attempt, attempt < 3 ? " -- copying it again" : "");
+            if (attempt == 3) return LLMK_E_VERIFY;
+        }
+    };
     if (t.type == LLMK_TYPE_Q4_0) {
         const size_t blocks_per_row = col_bytes / 18;
         const size_t chunk_rows_max = ((size_t)256 << 20) / col_bytes + 1;
         uint8_t* tmp = nullptr;
         const size_t cr0 = (size_t)nrows < chunk_rows_max ? (size_t)nrows : chunk_rows_max;
-        HIPCHK(dev_alloc(&tmp, cr0 * col_bytes));
-        for (size_t r = 0; r < (size_t)nrows; r += cr0) {
+        hipError_t e = dev_alloc(&tmp, cr0 * col_bytes);
+        if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
+        for (size_t r = 0; r < (size_t)nrows && rc == LLMK_OK; r += cr0) {
             const size_t cr = ((size_t)nrows - r) < cr0 ? ((size_t)nrows - r) : cr0;
             const size_t nb = cr * blocks_per_row;
-            hipError_t e = hipMemcpy2D(tmp, col_bytes, src + r * spitch + col_off, spitch, col_bytes, cr, hipMemcpyHostToDevice);
-            if (e == hipSuccess) {
+            rc = copy_checked(tmp, col_bytes, src + r * spitch, cr);
+            if (rc == LLMK_OK) {
                 hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, tmp, (char*)t.data + (first_row + r) * t.row_bytes,
                                    nb, (int)blocks_per_row, t.row_bytes);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
+                if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
             }
-            if (e != hipSuccess) { hipFree(tmp); return LLMK_E_HIP + (int)e; }
         }
-        HIPCHK(hipFree(tmp));
+        if (tmp) hipFree(tmp);
     } else {
-        HIPCHK(hipMemcpy2D((char*)t.data + first_row * t.row_bytes, t.row_bytes, src + col_off, spitch, col_bytes, nrows,
-                           hipMemcpyHostToDevice));
+        rc = copy_checked((char*)t.data + first_row * t.row_bytes, t.row_bytes, src, (size_t)nrows);
     }
+    if (d_acc) hipFree(d_acc);
+    if (rc) return rc;
     t.rows_uploaded += (size_t)nrows;
     if (t.rows_uploaded >= (size_t)d.rows * (d.layered ? c->L : 1)) t.uploaded = true;
     return LLMK_OK;
@@ -1403,9 +1470,48 @@ int llmk_timings(llmk_ctx* c, float ms[5]) {
 int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* bytes_per_launch) {
     int rc = check_ready(c);
     if (rc) return rc;
-    if (kernel < 0 || kernel > 10 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
+    if (kernel < 0 || kernel > 11 || iters <= 0 || !avg_ms) return LLMK_E_ARG;
     if (kernel == 6 && !c->use_tk) return LLMK_E_ARG;
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (kernel == 11) {
+        // the five per-layer kernels of the multi-kernel path (a tensor-parallel rank's too: without its exchanges) for all L
+        // layers as ONE hipGraph, replayed `iters` times: microseconds per LAYER as the token pass pays them -- a dependent
+        // kernel boundary inside a graph is ~1 us cheaper than between eager launches, which is what kernels 0..4 time
+        if (c->h_tokpos[1] < 1) { c->h_tokpos[0] = 0; c->h_tokpos[1] = 1; }
+        HIPCHK(hipMemcpyAsync(c->d_tokpos, c->h_tokpos, 4 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipSuccess;
+        for (int l = 0; l < c->L && e == hipSuccess; ++l) {
+            e = launch_qkv(c, l);
+            if (e == hipSuccess) e = launch_attn(c, l);
+            if (e == hipSuccess) e = launch_wo(c, l);
+            if (e == hipSuccess) e = launch_w13(c, l);
+            if (e == hipSuccess) e = launch_w2(c, l);
+        }
+        const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        if (e != hipSuccess || e2 != hipSuccess) { if (g) hipGraphDestroy(g); return LLMK_E_HIP + (int)(e != hipSuccess ? e : e2); }
+        e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        HIPCHK(e);
+        for (int i = 0; i < 3 && e == hipSuccess; ++i) e = hipGraphLaunch(ge, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev[6], c->stream);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) e = hipGraphLaunch(ge, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev[7], c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(c->ev[7]);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev[6], c->ev[7]);
+        hipGraphExecDestroy(ge);
+        HIPCHK(e);
+        *avg_ms = ms / (float)iters / (float)c->L;
+        if (bytes_per_launch) {
+            double b = 0;
+            for (int m : {LLMK_WQKV, LLMK_WO, LLMK_W13, LLMK_W2}) b += (double)c->desc[m].rows * (double)row_bytes_for(c->t[m].type, c->desc[m].K);
+            *bytes_per_launch = b;
+        }
+        return LLMK_OK;
+    }
     if (kernel >= 7) {   // the prefill GEMMs at PF_TMAX positions: 7 w1|w3, 8 wqkv, 9 wo, 10 w2 (whatever the workspaces hold: timing only)
         const int pf_step = PF_KSTEP;
         if (c->tp_size != 1 || c->E % pf_step || c->H % pf_step) return LLMK_E_ARG;

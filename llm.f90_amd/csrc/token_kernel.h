@@ -123,6 +123,62 @@
 #ifndef LLMK_TK_XB_DELAY
 #define LLMK_TK_XB_DELAY 0
 #endif
+// f32 / f16 kernels, round 4: slots at the START of the w1|w3 (A) / w2 (D) phase that are refilled inside the phase, right after
+// they are consumed, instead of in the burst behind barrier B.  The tiles they request are the NEXT phase's first (w2's,
+// the next layer's QKV / wo), so they get a head start of a phase, and the burst that the following sweep has to share the
+// CU's memory pipeline with is that much shorter.  (All refills were late since round 1, when a refill issued inside a
+// phase blocked on a pipeline full of earlier prefetch; with the sweeps ordered ahead of the bursts -- LLMK_TK_GF -- the
+// pipeline is all but empty when a phase starts.)
+// Round-4 sweep on TinyLlama f16 (profiles/r04_f16_early_refill.jsonl; tok/s, same box, base 1,942-1,955 = none early, 3 at once):
+//   1 early / 2 at once: 2,017;   1 / 1: 1,943;   2 / 2: 1,988;   2 / 1: 1,971;   2 / 0: 1,878;   2 early in A + 1 in D / 1: 1,904.
+// => f16: one slot of the w1|w3 phase early, two tiles of the burst at once (-1 = these per-type defaults; f32 keeps none early).
+#ifndef LLMK_TK_EARLY_A
+#define LLMK_TK_EARLY_A -1
+#endif
+#ifndef LLMK_TK_EARLY_D
+#define LLMK_TK_EARLY_D 0
+#endif
+// The xb gather is the one whose first passes are CERTAIN to fail: every non-attention CU starts polling the moment its QKV
+// phase ends and attention takes another ~5 us, so 224 CUs sweep the whole 16-32 KB vector six times on average (f16 trace:
+// "gather xb: passes mean 6.2") through the L2 channels the attention CUs' q polls, K/V rows and publishes need.  1: poll ONE
+// granule per head -- the last one its CU publishes -- until all carry the epoch, THEN sweep (the sweep still checks every
+// tag and retries: the granules of a head are two store instructions, and nothing orders their arrival).
+// MEASURED AND LEFT OFF (round 4, same box, profiles/r04_ab.jsonl): Llama-2-7B q4_0 893-894 tok/s with it against 896-897
+// without, TinyLlama f16 2,068-2,090 against 2,107, f32 1,475 either way.  The failed sweeps are not what the hop waits for.
+#ifndef LLMK_TK_XB_SENTINEL
+#define LLMK_TK_XB_SENTINEL 0
+#endif
+// f16 kernel, round 4: the LDS ANNEX (round-3 verdict: "the 80 KB of idle LDS per CU as a second-level tile ring").  The kernel
+// uses 57 KB of the CU's 160 KB of LDS; with LLMK_TK_ANNEX=1 the layer's w2 tiles (12 per CU, 96 KB) are requested at the start
+// of the attention hop -- the one window in which the CU's memory pipeline idles -- with LDS-direct loads
+// (global_load_lds_dwordx4: no registers), dotted from LDS in the w2 phase, and the ring's two w2 slots become padding.
+// BUILT, PARITY GREEN (27 tests), MEASURED SLOWER AND LEFT OFF (profiles/r04_ab.jsonl, r04_trace_tinyllama_f16_annex.txt):
+// 2,010-2,022 tok/s against 2,063-2,064 without it on the same box; kernel 472 / 500 / 593 us at KV length 1 / 256 / 2,048
+// against 449 / 479 / 547.  The trace says where it goes: the hb window does not shrink (gathHB 4.85 -> 4.80 us: its sweep still
+// queues behind the burst of the NEXT layer's tiles) and the wo phase on the attention CUs grows from 1.1 to 4.1 us --
+// their annex requests, issued behind their attention, are still streaming when the wo phase's barrier needs the ring tile
+// that was requested behind them (in-order return) -- and hipcc drains vmcnt before every LDS access that follows an LDS-direct
+// load it cannot prove complete, so the streaming waves sit out the hop instead of polling the gather flag.  The window is real;
+// filling it needs the requests on the non-attention CUs only and a completion the compiler can see.
+#ifndef LLMK_TK_ANNEX
+#define LLMK_TK_ANNEX 0
+#endif
+// q4_0 kernel, round 4.  Its phases are bound by how fast the CU's memory pipeline ACCEPTS the tile requests issued from
+// inside the dots (one request per consumed tile: 57 KB per slot and CU at the CU's 25 KB/us share of HBM = the 2.3 us a slot
+// takes, whatever the ALU needs -- an attention CU, whose QKV slots are empty, spends the same 4.5 us in them), while in the
+// windows between phases nothing is requested at all.  During the attention hop (7.4 us at 7B: 224 CUs wait for 32) the
+// ring entry the QKV phase's last slot has just consumed is FREE: the request the wo slot would issue (tile KO + NB - 1, the
+// second w1|w3 tile) is issued there instead, right behind the QKV phase (attention CUs and attention parts: right behind
+// their attention), and the wo phase's first slot issues none.  1 = on.
+#ifndef LLMK_TK_ADV_HOP
+#define LLMK_TK_ADV_HOP 1
+#endif
+// The same for the first slot of the QKV / w1|w3 / w2 phases, with the sweep in the lead: the request follows the loads of
+// the FIRST pass of the wave's slice of the x / xa / hb gather into the pipeline (a failed first pass retries behind it).
+// bit 0: QKV (x gather), bit 1: w1|w3 (xa gather), bit 2: w2 (hb gather).
+#ifndef LLMK_TK_ADV_GATHER
+#define LLMK_TK_ADV_GATHER 0
+#endif
 
 namespace llmk {
 
@@ -248,7 +304,8 @@ struct TkShape {
     static constexpr bool GCOOP = Q4 || (WT == WT_F16 && LLMK_TK_F16_COOP);
     // "gather first" (LLMK_TK_GF): tiles per wave a phase's refill burst issues before the next sweep is in the pipeline, and
     // s_sleep units the service wave lets the producers have before the first pass of the x / xa / hb sweeps
-    static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : (WT == WT_F16 ? 3 : 2);
+    static constexpr int EARLY_A = LLMK_TK_EARLY_A >= 0 ? LLMK_TK_EARLY_A : (WT == WT_F16 ? 1 : 0);
+    static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : 2;     // (f16: 3 until round 4 put a slot of w1|w3 early)
     static constexpr int GF_DELAY = LLMK_TK_GF_DELAY >= 0 ? LLMK_TK_GF_DELAY : (WT == WT_F16 ? 36 : 56);
     static constexpr bool GF_LAST = LLMK_TK_GF_LAST >= 0 ? LLMK_TK_GF_LAST != 0 : WT == WT_F16;
     static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
@@ -269,8 +326,19 @@ struct TkShape {
     // their partial sums land in slots nobody reads).  The weight allocations carry RPT rows of slack at their end.
     static constexpr int NG_A = (R_A / 2 + RPT - 1) / RPT;               // gate (= up) tiles per CU
     static constexpr int NT_Q = (R_Q + RPT - 1) / RPT, NT_O = R_O / RPT, NT_A = 2 * NG_A, NT_D = (R_D / RPT) * TPR_H, NT_C = R_C / RPT;
+    // q4_0, round 4: a slot costs ~2 us of VALU work whether one wave holds a tile in it or all seven (520 VALU instructions
+    // per tile, two waves per SIMD: the q4_0 phases are ALU-bound at the same ~18 us per layer HBM needs -- an attention CU, whose
+    // QKV tiles are the zero block, spends the same 4.5 us in its two QKV slots).  Llama-2-7B's w1|w3 range is 22 tiles per CU:
+    // three full slots and ONE tile in a fourth.  The service wave idles between the phase's two barriers: it takes that tile
+    // (LLMK_TK_SVC_A), and the phase is three slots.
+#ifndef LLMK_TK_SVC_A
+#define LLMK_TK_SVC_A 1
+#endif
+    static constexpr bool SVC_A = Q4 && LLMK_TK_SVC_A && (NT_A % TK_NS == 1);
+    static constexpr bool XB_SENT = LLMK_TK_XB_SENTINEL != 0;           // xb: poll one granule per head first (left off)
+    static constexpr int NT_A_S = NT_A - (SVC_A ? 1 : 0);                // w1|w3 tiles of the streaming waves
     static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
-                         SL_A = (NT_A + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
+                         SL_A = (NT_A_S + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
     // w2 rows are TPR_H parts wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
     // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
     static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D / RPT + NW_D - 1) / NW_D;
@@ -278,6 +346,9 @@ struct TkShape {
     static constexpr int RA_P = 2 * RPT * NG_A, RQ_P = RPT * NT_Q;       // partial slots incl. the recomputed neighbour rows
     static constexpr int MAXP00 = RA_P > R_C ? RA_P : R_C, MAXP0 = MAXP00 > RQ_P ? MAXP00 : RQ_P, MAXP1 = R_D * TPR_H,
                          MAXP = MAXP0 > MAXP1 ? MAXP0 : MAXP1;           // partial sums per phase
+    static constexpr bool ANNEX = LLMK_TK_ANNEX && WT == WT_F16;        // the CU's w2 tiles wait in LDS (see LLMK_TK_ANNEX)
+    static constexpr int ANNEX_TILES = ANNEX ? NT_D : 0;                 // live (wave, slot) pairs of the w2 phase: compacted
+    static constexpr int ANNEX_BYTES = ANNEX ? ANNEX_TILES * TK_TCOLS * 1024 + 1024 : 0;   // + one junk line: what pairs without a tile write
     static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % RPT == 0, "rows must split over CUs");
     static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
     static_assert(LPR_E <= LPT && (Q4 || (R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
@@ -452,6 +523,24 @@ __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned 
     return tk_gather_pieces<NL, NBP, MAXNL, 0, GFLAST>(rs, epoch, dst, err, lane, nowait, dbg, flag, seq);
 }
 
+// LLMK_TK_XB_SENTINEL: lanes 0 .. n-1 poll granule first + lane * stride each until all n tags match (bounded like every spin)
+__device__ __forceinline__ bool tk_wait_sentinels(const unsigned long long* g, int first, int stride, int n, unsigned epoch, unsigned* err,
+                                                  int lane, bool nowait) {
+    const unsigned long long* p = g + first + (lane < n ? lane : 0) * stride;
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(x >> 32) == epoch) || nowait) return true;
+        if ((spin & 63) == 63) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spin > TK_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(err, 0x700u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
+    }
+}
+
 // ---- 16-byte granules {v0, v1, v2, tag} for the hb vector (round 3; probes/granule16_probe: a 16-byte sc1 store is never
 // seen torn by a 16-byte sc1 load) ------------------------------------------------------------------------------------------
 // The hb exchange is the longest edge of a layer (H = 2.75 E values: 44 loads per lane as {v, tag} pairs): three values per
@@ -517,10 +606,14 @@ __device__ __forceinline__ bool tk_gather3_pieces(__amdgpu_buffer_rsrc_t rs, uns
 // holds this CU's OWN rows cannot complete before the service wave has published them, i.e. after its epilogue has read
 // xraw -- so a wave may start on the next vector while the epilogue of the previous phase still runs.
 //   xraw (optional) <- x;  xs <- x * gains (NORM) or x;  *ss += sum x^2 (NORM)
-template <int NLW, int NBP, bool NORM>
+struct TkNoop { __device__ __forceinline__ void operator()() const {} };
+// after_first(): issued right behind the loads of the FIRST pass (LLMK_TK_ADV_GATHER: a tile request that follows the sweep
+// into the CU's memory pipeline); straight-line code, so the tag check waits with vmcnt(<those loads>), not vmcnt(0)
+template <int NLW, int NBP, bool NORM, class F = TkNoop>
 __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
-                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait) {
-    if constexpr (NLW == 0) return true;
+                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait,
+                                             F after_first = F()) {
+    if constexpr (NLW == 0) { after_first(); return true; }
     else {
         float2 gn[NORM ? NLW : 1];
         if constexpr (NORM) {
@@ -533,6 +626,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
             tk_v4u r[NLW];
 #pragma unroll
             for (int k = 0; k < NLW; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);
+            if constexpr (!std::is_same<F, TkNoop>::value) { if (spin == 0) after_first(); }
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < NLW; ++k) ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
@@ -565,16 +659,16 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
     }
 }
 // wave w (0..7) of the workgroup; red8[w] receives the slice's sum of squares when NORM
-template <int N, int NBP, bool NORM>
+template <int N, int NBP, bool NORM, class F = TkNoop>
 __device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsigned epoch, float* xraw, float* xs, const float* gains,
-                                               float* red8, unsigned* err, int w, int lane, bool nowait) {
+                                               float* red8, unsigned* err, int w, int lane, bool nowait, F after_first = F()) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128, B = NL / TK_WAVES, X = NL % TK_WAVES;      // waves < X take B + 1 loads per lane, the others B
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     float ss = 0.f;
     bool ok;
-    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
-    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
+    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM, F>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, after_first);
+    else ok = tk_coop_part<B, NBP, NORM, F>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, after_first);
     if constexpr (NORM) {
         ss = wave_sum(ss);
         if (lane == 0) red8[w] = ss;
@@ -849,6 +943,46 @@ __device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t,
     }
 }
 
+// The service wave's copy of tk_consume for ONE q4_0 tile of a K = E phase (TkShape::SVC_A): the x fragment one segment at a
+// time (32 registers instead of 64 -- this wave carries the layer loop's exchange state), each row's blocks in the same order
+// with the same operations as tk_dot: bit-identical partial sums.
+template <class SH>
+__device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const TkTile& t, const float4* xs4, float* part, int lane) {
+    static_assert(SH::Q4, "q4_0 tiles");
+    float acc[SH::RPT];
+#pragma unroll
+    for (int s = 0; s < SH::RPT; ++s) acc[s] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < SH::LPT; ++jj) {
+        const int b = jj * WAVE + lane;                      // block of every row of the tile (K = E: all of them exist)
+        float4 xv[8];
+        float t8 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            xv[m] = xs4[m * SH::NBP_E + b];
+            t8 += (xv[m].x + xv[m].y) + (xv[m].z + xv[m].w);
+        }
+        const float xs8 = 8.0f * t8;
+#pragma unroll
+        for (int s = 0; s < SH::RPT; ++s) {
+            const float4& w = e.b[s * SH::LPT + jj];
+            const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+            float tl = 0.f, th = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], xv[i], xv[4 + i], tl, th);
+            const unsigned short hs = e.sc[s * SH::LPT + jj];
+            acc[s] = tk_q4_block(tl, th, __half2float(*reinterpret_cast<const __half*>(&hs)), xs8, acc[s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (the second segment's x is read after the first's dots: 32 registers)
+    }
+#pragma unroll
+    for (int s = 0; s < SH::RPT; ++s) acc[s] = wave_sum(acc[s]);
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = acc[s];
+    }
+}
+
 // Static per-wave schedule: SLP slots per layer (padded to an even count so the 2-deep ring has the
 // same parity at every layer start), then the classifier slots.  Slot K (compile-time) belongs to
 // one phase; the s-th slot of a phase is tile s*15 + sw of the CU's tile range of that phase
@@ -893,6 +1027,76 @@ __device__ __forceinline__ TkTile tk_cls_at(const TokenArgs& a, int c, int sw) {
     else return tk_row_tile<SH>(a.wcls, a.c0, K * TK_NS + sw, a.cn, a.zeros);
 }
 
+// w1|w3 tile ti of CU c: tile 2m is RPT gate rows, tile 2m+1 the RPT up rows of the same hidden units
+template <class SH>
+__device__ __forceinline__ TkTile tk_w13_tile(const TokenArgs& a, int l, int c, int ti, bool live) {
+    const int m = ti >> 1, gu = ti & 1;
+    const long long row = (long long)l * 2 * SH::H + gu * SH::H + c * (SH::R_A / 2) + m * SH::RPT;
+    TkTile t;
+    t.ncol = live ? SH::LPR_E : 0;
+    t.p = live ? tk_rowp<SH, SH::E>(a.w13, row) : a.zeros;
+    t.rstride = SH::RB_E / 16;
+    t.pidx = live ? 2 * m * SH::RPT + gu : SH::MAXP;
+    t.pstep = live ? 2 : 0;
+    t.soff = SH::E / 2;
+    return t;
+}
+// w2 tile of streaming wave sw in slot k of the phase: RPT rows x column part `part` (LPT segments; the last part is ragged)
+template <class SH>
+__device__ __forceinline__ TkTile tk_w2_tile(const TokenArgs& a, int l, int c, int sw, int k) {
+    constexpr int P = SH::TPR_H;
+    const int part = sw % P, nw = (TK_NS - part + P - 1) / P;      // waves that share this column part
+    const int rg = k * nw + sw / P;                                // group of RPT rows
+    const bool live = rg < SH::R_D / SH::RPT;
+    const long long row = (long long)l * SH::E + c * SH::R_D + rg * SH::RPT;
+    TkTile t;
+    t.ncol = live ? min(SH::LPT, SH::LPR_H - part * SH::LPT) : 0;
+    t.p = live ? tk_rowp<SH, SH::H>(a.w2, row) + part * SH::LPT * WAVE : a.zeros;
+    t.rstride = SH::RB_H / 16;
+    t.pidx = live ? rg * SH::RPT * P + part : SH::MAXP;
+    t.pstep = live ? P : 0;
+    t.soff = SH::H / 2 - part * SH::LPT * WAVE * 14;   // p is part * LPT segments (1 KB each) into the row; its scales 128 B each
+    return t;
+}
+// ---- the LDS annex (LLMK_TK_ANNEX) -------------------------------------------------------------------------------------------
+// slot of (wave sw, w2 slot k) in the annex: the rank of the pair among the LIVE pairs in (k, sw) order (7 x SL_D pairs, NT_D of
+// them live: 12 of 14 on TinyLlama), -1 when the pair has no tile.  A handful of scalar operations, once per wave and token.
+template <class SH>
+__device__ __forceinline__ int tk_annex_slot(int sw, int k) {
+    constexpr int P = SH::TPR_H, NRG = SH::R_D / SH::RPT;
+    int n = 0, mine = -1;
+#pragma unroll
+    for (int kk = 0; kk < SH::SL_D; ++kk)
+#pragma unroll
+        for (int w = 0; w < TK_NS; ++w) {
+            const int part = w % P, nw = (TK_NS - part + P - 1) / P;
+            const bool live = kk * nw + w / P < NRG;
+            if (w == sw && kk == k) mine = live ? n : -1;
+            n += live ? 1 : 0;
+        }
+    return mine;
+}
+typedef __attribute__((address_space(3))) void* tk_lds_ptr;
+typedef const __attribute__((address_space(1))) void* tk_glb_ptr;
+// one tile HBM -> LDS, no registers: 8 x global_load_lds_dwordx4 (lane i's 16 bytes land at dst + 16 i: a segment is 1 KB,
+// contiguous).  Segments past a ragged row end read the zero block, as in tk_issue (their x fragment is zero, but what they are
+// multiplied with must be finite).  The loads count in vmcnt like any other; they are older than every ring tile requested after
+// them, so a phase that has consumed such a ring tile has them in LDS (in-order return).
+template <class SH>
+__device__ __forceinline__ void tk_annex_issue(char* dst, int seg_pitch, const TkTile& t, const float4* zp, int lane) {
+#pragma unroll
+    for (int j = 0; j < TK_TCOLS; ++j) {
+        const int s = j / SH::LPT, jj = j % SH::LPT;
+        const bool real = jj < t.ncol;
+        const float4* pj = real ? t.p + s * t.rstride + jj * WAVE + lane : zp;            // (one 16-byte access for the wave, as in tk_issue)
+        __builtin_amdgcn_global_load_lds((tk_glb_ptr)pj, (tk_lds_ptr)(dst + j * seg_pitch), 16, 0, 0);   // (pitch 0: the junk line)
+    }
+}
+template <class SH>
+__device__ __forceinline__ void tk_annex_read(TkSlot<SH>& e, const char* src, int lane) {
+#pragma unroll
+    for (int j = 0; j < TK_TCOLS; ++j) e.b[j] = reinterpret_cast<const float4*>(src + j * 1024)[lane];
+}
 // descriptor of slot K (compile-time) of layer l; K >= SLP looks into layer l+1; past the last
 // layer the stream continues with the classifier slots
 template <class SH, int K>
@@ -910,32 +1114,11 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
         } else if constexpr (K < SC::KD) {
             // w1|w3: tile 2m is RPT gate rows, tile 2m+1 the RPT up rows of the same hidden units (SwiGLU pairs stay in the CU);
             // partials are laid out (gate, up) per hidden unit
-            const int ti = (K - SC::KA) * TK_NS + sw, m = ti >> 1, gu = ti & 1;
-            const bool live = ti < SH::NT_A;
-            const long long row = (long long)l * 2 * SH::H + gu * SH::H + c * (SH::R_A / 2) + m * SH::RPT;
-            TkTile t;
-            t.ncol = live ? SH::LPR_E : 0;
-            t.p = live ? tk_rowp<SH, SH::E>(a.w13, row) : a.zeros;
-            t.rstride = SH::RB_E / 16;
-            t.pidx = live ? 2 * m * SH::RPT + gu : SH::MAXP;
-            t.pstep = live ? 2 : 0;
-            t.soff = SH::E / 2;
-            return t;
+            const int ti = (K - SC::KA) * TK_NS + sw;
+            return tk_w13_tile<SH>(a, l, c, ti, ti < SH::NT_A_S);
         } else if constexpr (K < SC::KP) {
-            // w2: RPT rows x column part `part` (LPT segments; the last part is ragged)
-            constexpr int P = SH::TPR_H;
-            const int part = sw % P, nw = (TK_NS - part + P - 1) / P;      // waves that share this column part
-            const int rg = (K - SC::KD) * nw + sw / P;                     // group of RPT rows
-            const bool live = rg < SH::R_D / SH::RPT;
-            const long long row = (long long)l * SH::E + c * SH::R_D + rg * SH::RPT;
-            TkTile t;
-            t.ncol = live ? min(SH::LPT, SH::LPR_H - part * SH::LPT) : 0;
-            t.p = live ? tk_rowp<SH, SH::H>(a.w2, row) + part * SH::LPT * WAVE : a.zeros;
-            t.rstride = SH::RB_H / 16;
-            t.pidx = live ? rg * SH::RPT * P + part : SH::MAXP;
-            t.pstep = live ? P : 0;
-            t.soff = SH::H / 2 - part * SH::LPT * WAVE * 14;   // p is part * LPT segments (1 KB each) into the row; its scales 128 B each
-            return t;
+            if constexpr (SH::ANNEX) return tk_null<SH>(a.zeros);          // the w2 tiles wait in LDS: the ring's w2 slots are padding
+            else return tk_w2_tile<SH>(a, l, c, sw, K - SC::KD);
         } else {
             return tk_null<SH>(a.zeros);
         }
@@ -1376,9 +1559,15 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
         if constexpr (SH::GCOOP) {
-            if (!att_cu) { tk_xb_delay(); ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok; }
+            if (!att_cu) {
+                tk_xb_delay();
+                // (this wave's slice is the last eighth of the vector: heads (E - E/8) / HS onwards)
+                if constexpr (SH::XB_SENT) ok = tk_wait_sentinels(tk_g_xb<SH>(a), TK_NS * (SH::E / TK_WAVES) + SH::HS - 1, SH::HS, SH::E / TK_WAVES / SH::HS, e_att, a.err, lane, nosync) && ok;
+                ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+            }
         } else {
             if (!att_cu) tk_xb_delay();
+            if constexpr (SH::XB_SENT) { if (!att_cu) ok = tk_wait_sentinels(tk_g_xb<SH>(a), SH::HS - 1, SH::HS, SH::NH, e_att, a.err, lane, nosync) && ok; }
             if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr, gflag, 4 * l + 1) && ok;
         }
         TK_STAMP(7);
@@ -1397,8 +1586,20 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
             ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             TK_STAMP(9);
-            tk_barrier();
-            xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
+            if constexpr (SH::SVC_A) {
+                // the CU's last w1|w3 tile is this wave's (TkShape::SVC_A): requested and dotted between the phase's barriers, while
+                // the streaming waves run their three slots (its ~2.5 us of latency + 2 us of dots end inside their 6)
+                // (requested BEHIND barrier A: in front of it the barrier waited for the tile -- barA 0.18 -> 1.94 us in the first trace)
+                tk_barrier();
+                TkSlot<SH> st;
+                const TkTile tt = tk_w13_tile<SH>(a, l, c, SH::NT_A - 1, true);
+                tk_issue<SH>(st, tt, a.zeros, lane);
+                xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
+                tk_consume_q4_lean<SH>(st, tt, reinterpret_cast<const float4*>(xs), const_cast<float*>(part), lane);
+            } else {
+                tk_barrier();
+                xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
+            }
         } else {
             nrm.prefetch(tk_rms_ffn(a, l, SH::E), lane);
             if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
@@ -1546,8 +1747,10 @@ __device__ __forceinline__ void tk_refill(TkRing<SH>& r, const TokenArgs& a, int
 // (consume), [barrier B], late refills
 template <class SH, int K0, int S, bool CLS, bool WIDE = false>
 __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
-                                         float* part, int lane, volatile int* gflag = nullptr, int seq = 0) {
-    constexpr int LATE = S < SH::NB ? S : SH::NB, EARLY = S - LATE;
+                                         float* part, int lane, volatile int* gflag = nullptr, int seq = 0, const char* annex = nullptr) {
+    constexpr int LATE0 = S < SH::NB ? S : SH::NB;
+    constexpr int WANT = CLS ? 0 : (K0 == TkSched<SH>::KA ? SH::EARLY_A : (K0 == TkSched<SH>::KD ? LLMK_TK_EARLY_D : 0));   // leading slots refilled in-phase
+    constexpr int EARLY = (S - LATE0) > (WANT < S ? WANT : S - 1) ? (S - LATE0) : (WANT < S ? WANT : S - 1), LATE = S - EARLY;
     tk_barrier();
     TkX<SH> x;
     if constexpr (SH::Q4) {
@@ -1557,8 +1760,23 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
         if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
         else x.load(xs4, 0, SH::LPR_E, lane);
     }
-    tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
-    tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
+    if constexpr (SH::ANNEX && WIDE && !CLS) {
+        // the w2 phase with its tiles in LDS (LLMK_TK_ANNEX): the ring's slots of this phase are padding, consumed by doing nothing
+        static_assert(EARLY == 0, "the padding slots are refilled behind barrier B");
+#pragma unroll
+        for (int k = 0; k < SH::SL_D; ++k) {
+            const int slot = tk_annex_slot<SH>(sw, k);
+            if (slot >= 0) {                               // wave-uniform; no global loads inside
+                const TkTile t = tk_w2_tile<SH>(a, l, c, sw, k);
+                TkSlot<SH> e;
+                tk_annex_read<SH>(e, annex + (size_t)slot * (TK_TCOLS * 1024), lane);
+                tk_consume<SH>(e, t, x, part, lane);
+            }
+        }
+    } else {
+        tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
+        tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
+    }
     tk_barrier();
     if constexpr (LLMK_TK_GF && !SH::GCOOP && !CLS) {
         // LLMK_TK_GF: a first part of the burst now, the rest once the service wave's next sweep is in the pipeline ahead of it
@@ -1577,16 +1795,29 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
 // two.  Issuing a load blocks while the CU's memory pipeline is full; spread through 1.9 us of dequantise-and-dot it never
 // does, there is no refill burst anywhere (the f32 / f16 kernels place theirs behind the exchange instead, section 3b), and
 // a wave that polls after its phase has at most one tile of its own in flight.  Prefetch distance NB - 1 = 2 tiles.
+// the request slot K of a phase would issue from inside its dots (tile K + NB - 1 into the entry slot K - 1 has freed), as a
+// statement of its own: LLMK_TK_ADV_HOP / LLMK_TK_ADV_GATHER issue it in the window BEFORE the phase, and the slot issues none
 template <class SH, int K, bool CLS>
+__device__ __forceinline__ void tk_request(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, int lane) {
+    constexpr int RN = (K + SH::NB - 1) % SH::NB;
+    if constexpr (CLS) r.t[RN] = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
+    else r.t[RN] = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
+    tk_issue<SH>(r.b[RN], r.t[RN], a.zeros, lane);
+}
+template <class SH, int K, bool CLS, bool REQ = true>
 __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
     static_assert(SH::Q4 && SH::RPT == 4 && SH::LPT == 2, "written for the q4_0 tile (4 rows x 2 segments)");
     constexpr int R = K % SH::NB, RN = (K + SH::NB - 1) % SH::NB;
     const TkSlot<SH>& e = r.b[R];
     TkTile tn;
-    if constexpr (CLS) tn = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
+    if constexpr (!REQ) tn = r.t[RN];              // already requested (tk_request): the entry and its descriptor stay as they are
+    else if constexpr (CLS) tn = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
     else tn = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
     TkSlot<SH>& n = r.b[RN];
-    float v[4];
+    // a padding slot (the layer's slots rounded up to the ring depth) holds no tile on any wave of any CU: it only keeps the
+    // ring turning -- the request, no dots
+    constexpr bool PAD = !CLS && (K % TkSched<SH>::SLP) >= TkSched<SH>::KP;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
     auto row = [&](int s_) {
         float acc = 0.f;
 #pragma unroll
@@ -1602,53 +1833,64 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
         }
         return acc;
     };
-    v[0] = row(0);
-    v[1] = row(1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < TK_TCOLS; ++j) {          // the tile's 8 nibble vectors
-        const int s_ = j / SH::LPT, jj = j % SH::LPT;
-        const bool real = jj < tn.ncol;
-        const float4* pj = real ? tn.p + s_ * tn.rstride + jj * WAVE : a.zeros;
-        n.b[j] = ldg_nt(pj + (real ? lane : 0));
+    if constexpr (!PAD) {
+        v[0] = row(0);
+        v[1] = row(1);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    v[2] = row(2);
-    v[3] = row(3);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (REQ) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < TK_TCOLS; ++j) {          // ... and its 8 block scales
-        const int s_ = j / SH::LPT, jj = j % SH::LPT;
-        const bool real = jj < tn.ncol;
-        const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(tn.p + s_ * tn.rstride) + tn.soff) + jj * WAVE
-                                        : reinterpret_cast<const unsigned short*>(a.zeros);
-        n.sc[j] = __builtin_nontemporal_load(pj + (real ? lane : 0));
+        for (int j = 0; j < TK_TCOLS; ++j) {          // the tile's 8 nibble vectors
+            const int s_ = j / SH::LPT, jj = j % SH::LPT;
+            const bool real = jj < tn.ncol;
+            const float4* pj = real ? tn.p + s_ * tn.rstride + jj * WAVE : a.zeros;
+            n.b[j] = ldg_nt(pj + (real ? lane : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!PAD) {
+        v[2] = row(2);
+        v[3] = row(3);
+    }
+    if constexpr (REQ) {
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) v[s_] = wave_sum(v[s_]);
-    const TkTile& t = r.t[R];
-    if (lane == 0) {
+        for (int j = 0; j < TK_TCOLS; ++j) {          // ... and its 8 block scales
+            const int s_ = j / SH::LPT, jj = j % SH::LPT;
+            const bool real = jj < tn.ncol;
+            const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(tn.p + s_ * tn.rstride) + tn.soff) + jj * WAVE
+                                            : reinterpret_cast<const unsigned short*>(a.zeros);
+            n.sc[j] = __builtin_nontemporal_load(pj + (real ? lane : 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (!PAD) {
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) part[t.pidx + s_ * t.pstep] = v[s_];
+        for (int s_ = 0; s_ < 4; ++s_) v[s_] = wave_sum(v[s_]);
+        const TkTile& t = r.t[R];
+        if (lane == 0) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) part[t.pidx + s_ * t.pstep] = v[s_];
+        }
     }
     r.t[RN] = tn;
 }
-template <class SH, int K, int N, bool CLS>
+template <class SH, int K, int N, bool CLS, bool REQ0 = true>
 __device__ __forceinline__ void tk_steps(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
     if constexpr (N > 0) {
-        tk_step<SH, K, CLS>(r, a, l, c, sw, x, part, lane);
+        tk_step<SH, K, CLS, REQ0>(r, a, l, c, sw, x, part, lane);
         tk_steps<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, x, part, lane);
     }
 }
-template <class SH, int K0, int S, bool CLS, bool WIDE = false>
+// REQ0 = false: the first slot's request was issued in the window before the phase (tk_request)
+template <class SH, int K0, int S, bool CLS, bool WIDE = false, bool REQ0 = true>
 __device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
                                               float* part, int lane) {
     tk_barrier();
     TkX<SH> x;
     if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
     else x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
-    tk_steps<SH, K0, S, CLS>(r, a, l, c, sw, x, part, lane);
+    tk_steps<SH, K0, S, CLS, REQ0>(r, a, l, c, sw, x, part, lane);
     tk_barrier();
 }
 // the ring starts with tiles 0 .. NB-2 requested; slot 0 requests tile NB-1
@@ -1684,6 +1926,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const int my_head = c / HPC;                    // (its attention CU, or a part of it at long contexts: tk_att_role)
 
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF
+    char* annex = lds + ((LD::ATT_S + 2 * a.S * 4 + 15) & ~15);                  // LLMK_TK_ANNEX: behind the score rows
     TkRing<SH> r;
     tk_prime<SH, 0>(r, a, c, sw, lane);
 
@@ -1705,6 +1948,21 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
                 tk_barrier();
                 tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, nullptr, at0, at1);
                 tk_barrier();
+                // (the service wave publishes this head's output now, and stores share the memory pipeline with loads: the
+                // requests below wait a moment -- the lesson of the q4_0 kernel's LLMK_TK_ADV_HOP)
+                if constexpr (SH::ANNEX) __builtin_amdgcn_s_sleep(48);
+            }
+            if constexpr (SH::ANNEX) {
+                // the layer's w2 tiles into the annex, at the START of the attention hop: the one window in which this CU's
+                // memory pipeline idles.  Issued before the ring's own refill below, so every later ring tile is younger.
+                // (no branch around the loads -- hipcc drains vmcnt at such a join: a (wave, slot) pair without a tile reads the zero
+                // block into the annex's junk line)
+#pragma unroll
+                for (int k = 0; k < SH::SL_D; ++k) {
+                    const int slot = tk_annex_slot<SH>(sw, k);
+                    tk_annex_issue<SH>(annex + (slot >= 0 ? (size_t)slot * (TK_TCOLS * 1024) : (size_t)SH::ANNEX_TILES * (TK_TCOLS * 1024)), slot >= 0 ? 1024 : 0,
+                                       tk_w2_tile<SH>(a, l, c, sw, k), a.zeros, lane);
+                }
             }
             if constexpr (LLMK_TK_GF && !SH::GCOOP) {
                 constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
@@ -1718,7 +1976,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
         }
         tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 2);
         tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 3);
-        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 4);   // w2 slots + padding
+        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 4, annex);   // w2 slots + padding
     }
     // classifier: the ring index is 0 again (SLP is a multiple of NB); refills run off the stream's end
     tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
@@ -1747,6 +2005,10 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
 
     TkRing<SH> r;
     tk_prime_coop<SH, 0>(r, a, c, sw, lane);
+    constexpr bool ADVH = LLMK_TK_ADV_HOP != 0, ADVA = (LLMK_TK_ADV_GATHER & 2) != 0,
+                   ADVD = (LLMK_TK_ADV_GATHER & 4) != 0;
+    // (an attention CU gathers no x: its QKV slots keep their own requests, so ADVQ needs a run-time branch around a slot's loads
+    // and is only taken where every CU gathers -- the last layer's x, for the classifier -- see below)
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
@@ -1759,15 +2021,35 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
             tk_barrier();
             tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, nullptr, at0, at1);
             tk_barrier();
+            // the service wave now folds and PUBLISHES this head's output -- the one store the other 224 CUs wait for -- and
+            // stores share the CU's memory pipeline with loads: issued at once, the request below put 57 KB in front of it
+            // (first version: xb arrived 0.7 us later everywhere and the whole gain was gone)
+            if constexpr (ADVH) __builtin_amdgcn_s_sleep(48);
         }
-        if (!att_cu) { tk_xb_delay(); tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync); }
-        tk_phase_body<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane);
+        // the wo slot's request, in the window of the attention hop (behind this CU's own attention, if it has any)
+        if constexpr (ADVH) tk_request<SH, SC::KO, false>(r, a, l, c, sw, lane);
+        if (!att_cu) {
+            tk_xb_delay();
+            if constexpr (SH::XB_SENT) tk_wait_sentinels(tk_g_xb<SH>(a), sw * (SH::E / TK_WAVES) + SH::HS - 1, SH::HS, SH::E / TK_WAVES / SH::HS, e_att, a.err, lane, nosync);
+            tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        }
+        tk_phase_body<SH, SC::KO, SH::SL_O, false, false, !ADVH>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
-        tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
-        tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (ADVA) {
+            tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync,
+                                              [&]() { tk_request<SH, SC::KA, false>(r, a, l, c, sw, lane); });
+        } else {
+            tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
+        }
+        tk_phase_body<SH, SC::KA, SH::SL_A, false, false, !ADVA>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
-        tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
-        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);
+        if constexpr (ADVD) {
+            tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync,
+                                               [&]() { tk_request<SH, SC::KD, false>(r, a, l, c, sw, lane); });
+        } else {
+            tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        }
+        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true, !ADVD>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         if (l + 1 < L) {
             if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, a.err, sw, lane, nosync);

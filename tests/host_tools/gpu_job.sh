@@ -8,6 +8,8 @@
 #   poison [pytest args]     the same under LLMK_POISON=1 (every device allocation pre-filled with NaN bytes: an
 #                            uninitialised read fails every time instead of once in fifteen runs)  -> poison.log
 #   repeat N <pytest args>   N runs of the given tests, pass/fail per run        -> repeat.log (+ tp70_fail/ on a failure)
+#   nine N                   the control behind tests/test_tp70_gpu.py::_run_ranks: N runs of the jitter test with this pytest
+#                            process holding a GPU context, rank 0 in-process (8 GPU processes) and spawned (9)   -> nine.log
 #   dirty                    does a process see another (or its own earlier) process's freed VRAM?   -> dirty.log
 #   bench NAME [bench args]  python bench.py [args]                              -> NAME.json
 #   ab NAME N <env> -- [bench args]   N interleaved pairs of bench.py with / without the env setting   -> NAME.jsonl
@@ -24,6 +26,7 @@ TAG=${LLMK_JOB_TAG:-job}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd "$ROOT" || exit 1
+exec > >(tee -a "$OUT/job.log") 2>&1        # gpurun returns only the tail of stdout: the whole log comes back with gpurun_out/
 export TMPDIR=/tmp
 DBG=$ROOT/llm.f90_amd/csrc/libllmk_debug.so
 
@@ -106,6 +109,19 @@ for k, v in d.items():
 PY
   done
 }
+job_nine() {   # the same two tests, the first gives the pytest process a GPU context; 8 vs 9 processes on the GPU
+  local n=${1:-3} i v
+  : > $OUT/nine.log
+  for i in $(seq 1 $n); do
+    for v in eight nine; do
+      local t0=$(date +%s)
+      if [ $v = nine ]; then export LLMK_TP_TEST_SPAWN_ALL=1; else unset LLMK_TP_TEST_SPAWN_ALL; fi
+      if timeout 900 python -m pytest tests/test_decode_greedy_gpu.py tests/test_tp70_gpu.py -m gpu -q -k "returns_the_reference_ids or jitter" > /tmp/nine_$i$v.log 2>&1; then r=pass; else r=FAIL; fi
+      echo "run $i $v processes: $r in $(( $(date +%s) - t0 )) s; $(grep -h "never arrived" /tmp/nine_$i$v.log | head -1 | cut -c1-200)" | tee -a $OUT/nine.log
+    done
+  done
+  unset LLMK_TP_TEST_SPAWN_ALL
+}
 job_dirty() { timeout 300 python tests/host_tools/dirty_probe.py 2>&1 | tail -20 | tee $OUT/dirty.log; }
 job_repeat() {
   local n=$1 i; shift
@@ -144,6 +160,7 @@ while [ $# -gt 0 ]; do
     poison) LLMK_POISON=1 timeout 1500 python -m pytest tests -m gpu -q "${args[@]}" > $OUT/poison.log 2>&1; tail -25 $OUT/poison.log ;;
     repeat) job_repeat "${args[@]}" ;;
     dirty)  job_dirty ;;
+    nine)   job_nine "${args[@]}" ;;
     bench)  name=${args[0]}; timeout 600 python bench.py "${args[@]:1}" > $OUT/$name.json 2> $OUT/$name.err; cut -c1-1200 $OUT/$name.json ;;
     ab)     job_ab "${args[@]}" ;;
     prof)   OUT=$ROOT/gpurun_out/prof_${args[0]:-r04}; mkdir -p $OUT; job_prof ;;

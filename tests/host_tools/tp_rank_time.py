@@ -26,5 +26,7 @@ for k in range(6):
     print(f"  {names[k]:18s} {ms*1000:8.1f} us   {b/1e6:8.2f} MB   {b/ms/1e6:7.0f} GB/s")
     if k < 5:
         tot += ms
+ms, b = m.time_kernel(11, 20)
+print(f"  whole layer in a hipGraph (as the token pass runs it, no exchanges) {ms*1000:8.1f} us   {b/1e6:8.2f} MB   {b/ms/1e6:7.0f} GB/s")
 print(f"per layer {tot*1000:.1f} us -> 80 layers {tot*80:.2f} ms + classifier; weights per rank per layer "
       f"{sum(m.time_kernel(k,1)[1] for k in (0,2,3,4))/1e6:.1f} MB")

@@ -203,7 +203,7 @@ def test_cli_stream_load_prints_what_the_whole_file_load_prints(wtype, gguf, tmp
     if wtype == 0:
         ref = bytes(g["stdout"]).split(b"\n")
         assert streamed[1] == ref[1]
-    out = _run(args + ["--stream-load", "-v"], str(tmp_path))
+    out = _run(args + ["--stream-load", "--vx"], str(tmp_path))       # --vx: -v plus this loader's own lines
     assert b"streamed matmul weights" in out
 
 

@@ -362,9 +362,11 @@ def test_llama2_7b_q4_0_full_depth_matches_the_real_reference(flags, llama7b_q4_
     err = compact_err(logits, g)
     assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
     ok = safe_positions(g)
-    assert ok.sum() > n // 2
+    ok[:len(g["prompt_ids"])] = False                 # (`tokens` holds the PROMPT ids there, not the reference's greedy choice)
+    assert ok.sum() >= (n - len(g["prompt_ids"])) // 2
     assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][ok])
     # free-running: the device-side greedy loop reproduces the reference transcript up to its first near-tie
+    ok[:len(g["prompt_ids"])] = True
     first_unsafe = int(np.argmin(ok)) if not ok.all() else n
     toks, _ = m.generate(first_unsafe, prompt=g["prompt_ids"].tolist(), want_logits=False, greedy_on_device=True)
     assert np.array_equal(toks, g["tokens"][:first_unsafe])

@@ -143,8 +143,10 @@ def _rank_main(target, rank, args, conn, faildir):
     for it when a rank goes silent), an exception leaves its traceback in <faildir>/error_rank<r>.txt"""
     import faulthandler
     import signal
+    import threading
     import traceback
-    faulthandler.register(signal.SIGUSR1, file=open(os.path.join(faildir, f"stack_rank{rank}.txt"), "w"), all_threads=True)
+    if threading.current_thread() is threading.main_thread():
+        faulthandler.register(signal.SIGUSR1, file=open(os.path.join(faildir, f"stack_rank{rank}.txt"), "w"), all_threads=True)
     try:
         target(*args, conn)
     except BaseException:
@@ -154,17 +156,40 @@ def _rank_main(target, rank, args, conn, faildir):
 
 
 def _run_ranks(target, args_of, timeout):
-    """P rank processes; the parent relays their all-gathers until every rank has delivered its result.  A rank that dies is
+    """P ranks on this box's one GPU; the caller relays their all-gathers until every rank has delivered its result.
+
+    EIGHT PROCESSES, NOT NINE.  The driver runs at most 8 processes on a GPU at once (amdgpu hws_max_conc_proc: one VMID
+    each); a ninth makes the hardware scheduler time-slice whole processes, and a rank whose kernel spins on a peer that is
+    not scheduled waits for the scheduler, not for the peer.  That is what round 3's "one failure in fifteen whole-suite runs"
+    was (round 4: the jitter run reproduced it on every whole-suite run -- 35 rounds in 10 s, then `rank 0's partial never
+    arrived` after the 20 s wall-clock bound -- and never in a dedicated run): inside the suite THIS pytest process already
+    holds a GPU context from the tests before, so eight spawned ranks made nine.  Rank 0 therefore runs here, in a thread of
+    this process, and ranks 1..7 are spawned: eight GPU processes whether or not the suite ran first.  A rank that dies is
     named with its exit code and traceback; if a rank goes silent every rank's Python stack is dumped before they are killed."""
     import multiprocessing as mp
     import signal
+    import threading
     import time
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(P)]
     faildir = _fail_dir()
-    procs = [ctx.Process(target=_rank_main, args=(target, r, args_of(r), pipes[r][1], faildir)) for r in range(P)]
-    for p in procs:
+    procs = [None] + [ctx.Process(target=_rank_main, args=(target, r, args_of(r), pipes[r][1], faildir)) for r in range(1, P)]
+    if os.environ.get("LLMK_TP_TEST_SPAWN_ALL"):      # the control of tests/host_tools/gpu_job.sh nine: rank 0 spawned too (round 3's harness)
+        procs[0] = ctx.Process(target=_rank_main, args=(target, 0, args_of(0), pipes[0][1], faildir))
+    local_err = []
+
+    def local_rank():
+        try:
+            _rank_main(target, 0, args_of(0), pipes[0][1], faildir)
+        except BaseException as e:      # noqa: BLE001
+            local_err.append(e)
+    th = threading.Thread(target=local_rank, daemon=True)
+    for p in procs[1:]:
         p.start()
+    if procs[0] is not None:
+        procs[0].start()
+    else:
+        th.start()
 
     def read_file(name):
         try:
@@ -175,18 +200,21 @@ def _run_ranks(target, args_of, timeout):
     def get(r):
         t_end = time.time() + timeout
         while not pipes[r][0].poll(1.0):
-            dead = [(k, p.exitcode) for k, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            dead = [(k, p.exitcode) for k, p in enumerate(procs) if p is not None and p.exitcode not in (None, 0)]
+            if local_err:
+                dead.append((0, repr(local_err[0])))
             if dead or time.time() > t_end:
                 if not dead:
                     for p in procs:
-                        if p.is_alive():
+                        if p is not None and p.is_alive():
                             os.kill(p.pid, signal.SIGUSR1)
                     time.sleep(2)
                 for p in procs:
-                    p.terminate()
+                    if p is not None:
+                        p.terminate()
                 if dead:
                     pytest.fail(f"rank(s) died (rank, exit code): {dead}\n" + "\n".join(read_file(f"error_rank{k}.txt") for k, _ in dead))
-                pytest.fail(f"rank {r} went silent for {timeout} s; stacks:\n" + "\n".join(f"--- rank {k}\n" + read_file(f"stack_rank{k}.txt") for k in range(P)))
+                pytest.fail(f"rank {r} went silent for {timeout} s; stacks:\n" + "\n".join(f"--- rank {k}\n" + read_file(f"stack_rank{k}.txt") for k in range(1, P)))
         return pipes[r][0].recv()
     while True:
         msgs = [get(r) for r in range(P)]
@@ -196,9 +224,13 @@ def _run_ranks(target, args_of, timeout):
             break
         for r in range(P):
             pipes[r][0].send([obj for _, obj in msgs])
+    if procs[0] is None:
+        th.join(120)
+        assert not th.is_alive() and not local_err, local_err
     for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+        if p is not None:
+            p.join(120)
+            assert p.exitcode == 0
     return [obj for _, obj in msgs]
 
 
