@@ -182,7 +182,7 @@ int llmk_forward(llmk_ctx *ctx, int token, int pos, float *logits_out);
  * through MFMA GEMMs (a layer's weights cross HBM once per batch); tensor-parallel contexts, and shapes whose emb_dim /
  * hidden_dim is not a multiple of the GEMM's 64-column step, run the token-by-token pass inside.
  * The GEMMs multiply on the f16 matrix instruction with each f32 activation (and each f32 / q4_0 weight) as two f16 pieces
- * (exact products; |error| <= 2^-20 of an operand of magnitude >= 2^-3, 2^-24 absolute below: csrc/prefill.h); a prompt with an activation of magnitude >= 65504 is redone on the
+ * (exact products; |error| <= 2^-20 of an operand of magnitude >= 2^-3, 2^-24 absolute below: csrc/prefill.h); a prompt with an activation of magnitude >= 65504, or with a position whose whole row is below 2^-7, is redone on the
  * f32 instruction inside the same call, and the context stays there.  LLMK_PF_F32_MFMA=1 in the environment selects the
  * f32 instruction from the start. */
 int llmk_prefill(llmk_ctx* ctx, const int* tokens, int n, int pos0, float* logits_out);

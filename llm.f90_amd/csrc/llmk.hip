@@ -126,6 +126,9 @@ struct llmk_ctx {
     int* pf_tok = nullptr;
     hipEvent_t pf_start = nullptr;         // tokens are on the device (and everything before the prefill call is done)
     bool pf_ready = false;                 // pf_setup ran to its end
+    // uploads are staged through the shim's OWN pinned memory (upload_block): two buffers, an event each
+    void* up_stage[2] = {nullptr, nullptr};
+    hipEvent_t up_done[2] = {nullptr, nullptr};
     bool pf_hm = false;                    // GEMMs on v_mfma_f32_16x16x32_f16, activations (and f32 / q4_0 weights) as two f16 pieces (prefill.h)
     unsigned* pf_flag = nullptr;           // device word: an activation did not fit f16 (the call is redone on the f32 instruction)
 };
@@ -1068,13 +1071,18 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     return LLMK_OK;
 }
 
-// ---- every upload is verified --------------------------------------------------------------------------------------------------
-// Round 4: in ONE of ~20 runs of the 8-rank 70B-geometry test the w1|w3 shard of ONE rank reached the device damaged (its
-// llmk_tensor_checksum differed from the host-side image right after llmk_upload; logits off by 3.6e-3 on every rank; the
-// source was a read-only mmap of a /dev/shm file that eight processes copied from at once).  Whatever the layer at fault,
-// weights are copied once and read for the life of the ctx: the 64-bit sum of the 16-bit words the host handed over is
-// compared with the same sum of what arrived (the raw copy, before any re-packing), a mismatch is reported on stderr and the
-// block is copied again (three attempts, then LLMK_E_VERIFY).  ~0.2 s per GB of host time; LLMK_VERIFY_UPLOAD=0 skips it.
+// ---- every upload is staged through the shim's own pinned memory, and verified ------------------------------------------------
+// Round 4, found by checksums: twice in ~40 runs of the 8-rank 70B tests ONE block of ONE rank reached the device with
+// other bytes than the host held -- once from a read-only mmap of a /dev/shm file (logits 3.6e-3 off on every rank), once from
+// an anonymous numpy temporary, and that time THREE successive hipMemcpy2D calls from the same pointer delivered the same wrong
+// bytes (profiles/r04_tp70_upload_damage.txt): the address had just been freed and mapped again by the allocator (one 264 MB
+// temporary per layer), and a copy engine that reads pageable memory through a cached registration of the virtual range reads
+// the pages that USED to be there.  Weights are copied once and read for the life of the ctx, so the shim no longer lets
+// the device read caller memory at all: the CPU copies each chunk into one of two pinned staging buffers (8 MB, allocated with
+// the first upload), summing its 16-bit words on the way; the chunk goes to the device from there; and the 64-bit sum of what
+// arrived is compared with the host's.  A mismatch is printed and the block staged again (three attempts, then
+// LLMK_E_VERIFY).  ~0.15 s per GB on one host core; LLMK_VERIFY_UPLOAD=0 skips the comparison, never the staging.
+constexpr size_t UP_STAGE_BYTES = (size_t)8 << 20;
 __global__ void sum16_kernel(const unsigned* __restrict__ w, size_t nbytes, unsigned long long* out) {
     const size_t nwords = nbytes / 4;
     unsigned long long t = 0;
@@ -1086,12 +1094,14 @@ __global__ void sum16_kernel(const unsigned* __restrict__ w, size_t nbytes, unsi
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, t);
 }
-static unsigned long long host_sum16(const uint8_t* src, size_t spitch, size_t col_bytes, size_t nrows) {
+// rows [0, nrows) x col_bytes at pitch spitch -> dst (contiguous); returns the 64-bit sum of the 16-bit words copied
+static unsigned long long stage_rows(uint8_t* dst, const uint8_t* src, size_t spitch, size_t col_bytes, size_t nrows) {
     unsigned long long t = 0;
     for (size_t r = 0; r < nrows; ++r) {
         const uint16_t* p = reinterpret_cast<const uint16_t*>(src + r * spitch);    // rows of every encoding start 2-byte aligned
+        uint16_t* q = reinterpret_cast<uint16_t*>(dst + r * col_bytes);
         unsigned long long a = 0;
-        for (size_t i = 0; i < col_bytes / 2; ++i) a += p[i];
+        for (size_t i = 0; i < col_bytes / 2; ++i) { const uint16_t v = p[i]; q[i] = v; a += v; }
         t += a;
     }
     return t;
@@ -1122,20 +1132,38 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
     unsigned long long* d_acc = nullptr;
     if (verify) HIPCHK(dev_alloc(&d_acc, sizeof(*d_acc)));
     int rc = LLMK_OK;
-    // one chunk: `cr` rows from src_rows into dev_dst (pitch dpitch), checked and copied again on a mismatch
+    if (!c->up_stage[0]) {
+        for (int b = 0; b < 2; ++b) {
+            HIPCHK(hipHostMalloc(&c->up_stage[b], UP_STAGE_BYTES, hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&c->up_done[b], hipEventDisableTiming));
+        }
+    }
+    // `cr` rows from src_rows into dev_dst (contiguous, col_bytes per row): staged, sent, checked, staged again on a mismatch
     auto copy_checked = [&](void* dev_dst, size_t dpitch, const uint8_t* src_rows, size_t cr) -> int {
-        const unsigned long long want = verify ? host_sum16(src_rows + col_off, spitch, col_bytes, cr) : 0;
+        if (dpitch != col_bytes || col_bytes > UP_STAGE_BYTES) return LLMK_E_ARG;      // (every destination here is contiguous)
+        const size_t rows_per_chunk = UP_STAGE_BYTES / col_bytes;
         for (int attempt = 1;; ++attempt) {
-            hipError_t e = hipMemcpy2D(dev_dst, dpitch, src_rows + col_off, spitch, col_bytes, cr, hipMemcpyHostToDevice);
+            unsigned long long want = 0;
+            int b = 0;
+            for (size_t r = 0; r < cr; r += rows_per_chunk, b ^= 1) {
+                const size_t n = cr - r < rows_per_chunk ? cr - r : rows_per_chunk;
+                hipError_t e = hipEventSynchronize(c->up_done[b]);                     // the buffer's previous chunk has left it
+                if (e != hipSuccess) return LLMK_E_HIP + (int)e;
+                want += stage_rows((uint8_t*)c->up_stage[b], src_rows + r * spitch + col_off, spitch, col_bytes, n);
+                e = hipMemcpyAsync((char*)dev_dst + r * col_bytes, c->up_stage[b], n * col_bytes, hipMemcpyHostToDevice, 0);
+                if (e == hipSuccess) e = hipEventRecord(c->up_done[b], 0);
+                if (e != hipSuccess) return LLMK_E_HIP + (int)e;
+            }
+            hipError_t e = hipDeviceSynchronize();
             if (e != hipSuccess) return LLMK_E_HIP + (int)e;
-            if (!verify || dpitch != col_bytes) return LLMK_OK;          // (every destination here is contiguous: dpitch == col_bytes)
+            if (!verify) return LLMK_OK;
             unsigned long long got = 0;
             e = device_sum16(dev_dst, cr * col_bytes, d_acc, &got);
             if (e != hipSuccess) return LLMK_E_HIP + (int)e;
             if (got == want) return LLMK_OK;
             fprintf(stderr, "llmk: upload of tensor %d, layer %d, local rows %zu..%zu (%zu bytes) did not arrive intact: 16-bit word sum 0x%llx on the "
                             "device, 0x%llx on the host (attempt %d of 3)%s\n", tid, layer, first_row, first_row + cr - 1, cr * col_bytes, got, want,
-                    attempt, attempt < 3 ? " -- copying it again" : "");
+                    attempt, attempt < 3 ? " -- staging it again" : "");
             if (attempt == 3) return LLMK_E_VERIFY;
         }
     };
@@ -1922,6 +1950,10 @@ int llmk_destroy(llmk_ctx* c) {
                    c->d_gran, c->d_zeros, c->d_trace, c->d_part};
     for (void* p : dev)
         if (p) hipFree(p);
+    for (int b = 0; b < 2; ++b) {
+        if (c->up_stage[b]) hipHostFree(c->up_stage[b]);
+        if (c->up_done[b]) hipEventDestroy(c->up_done[b]);
+    }
     if (c->h_tokpos) hipHostFree(c->h_tokpos);
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_next) hipHostFree(c->h_next);

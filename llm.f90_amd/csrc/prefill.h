@@ -431,7 +431,11 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     // hi = both halves in one v_cvt_pkrtz (toward zero: the remainder then has up to 11 significant bits and the same sign),
     // x - hi through v_fma_mix_f32 with the f16 half as a source (no conversion back), lo = v_cvt_pkrtz of the two remainders
     // (|x - hi - lo| <= 2^-20 |x|), and the running max |x| for the range check.
-    float amax = 0.f;
+    // rmax[i]: running max |x| of the thread's i-th vector slot -- four columns of ONE position (row t of the tile) -- over every
+    // step of the block: the range check above 65504 and, round 4, the check at the LOW end (below)
+    float rmax[XV], wmax = 0.f;          // (wmax: the f32 weights' own range check)
+#pragma unroll
+    for (int i = 0; i < XV; ++i) rmax[i] = 0.f;
     auto xstore = [&](auto par, int buf, int lo_i, int hi_i) {
         constexpr int B_ = decltype(par)::value;
         _Float16* hi = xh + (size_t)(buf * 2) * TP * PF_HP;
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
                     "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
                     : "=&v"(d0), "=&v"(d1) : "v"(H.u[e / 2]), "v"(x0), "v"(x1));
                 L.h2[e / 2] = __builtin_amdgcn_cvt_pkrtz(d0, d1);
-                amax = fmaxf(fmaxf(amax, fabsf(x0)), fabsf(x1));
+                rmax[i] = fmaxf(fmaxf(rmax[i], fabsf(x0)), fabsf(x1));
             }
             *reinterpret_cast<pf_v4h*>(hi + xo[i]) = H.v;
             *reinterpret_cast<pf_v4h*>(lo + xo[i]) = L.v;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
                             const float4& wv = w[CUR][2 * (r * NJ + j) + d / 2];
                             w0 = (d & 1) ? wv.z : wv.x;
                             w1 = (d & 1) ? wv.w : wv.y;
-                            amax = fmaxf(fmaxf(amax, fabsf(w0)), fabsf(w1));
+                            wmax = fmaxf(fmaxf(wmax, fabsf(w0)), fabsf(w1));
                         } else {
                         t.h[d] = t.h[d] - (pf_h2){(_Float16)1032.0f, (_Float16)1032.0f};       // n - 8
                         if (j == 0)
@@ -602,7 +606,25 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     // two ring cycles per trip: the loop's back edge costs a drain of the weight prefetch (hipcc's waitcnt pass merges the
     // loop's two entries conservatively: s_waitcnt vmcnt(0) in the first step of a trip), and this path's GEMMs have <= 12 units per block
     for (int s = 0; s < nsteps; s += 2 * ST) pf_ring<0, 2 * ST, ST>(step, s, nsteps);
-    if (__any(!(amax < 65504.0f)) && lane == 0) atomicOr(flag, 1u);     // (NaN counts)
+    // Range checks of the two-piece split (advisor, round 3).  High end: an activation >= 65504 fits neither piece.  LOW end:
+    // below 2^-3 the lo piece is an f16 subnormal and the pair's error is 2^-24 ABSOLUTE, not 2^-20 relative -- harmless for
+    // the small elements of an O(1) row, but a position whose WHOLE row is small (attention output or SwiGLU output of a model
+    // with tiny values there) would carry 2^-24 / |row| into every product.  The 16 lanes that stage one position's 64 columns
+    // fold their running maxima (DPP row): a position whose largest element over all of this block's steps is below 2^-7 --
+    // and not an all-zero row -- raises the same flag, and llmk_prefill redoes the call on the f32 instruction.
+    float amax = wmax;
+    bool small = false;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        amax = fmaxf(amax, rmax[i]);
+        float r = rmax[i];
+        r = fmaxf(r, dpp_mov<0xB1, 0xf, false>(0.f, r));     // quad_perm [1,0,3,2]
+        r = fmaxf(r, dpp_mov<0x4E, 0xf, false>(0.f, r));     // quad_perm [2,3,0,1]
+        r = fmaxf(r, dpp_mov<0x141, 0xf, false>(0.f, r));    // row_half_mirror
+        r = fmaxf(r, dpp_mov<0x140, 0xf, false>(0.f, r));    // row_mirror: every lane of the row holds the row's maximum
+        small = small || (r > 0.f && r < 0.0078125f);
+    }
+    if (__any(!(amax < 65504.0f) || small) && lane == 0) atomicOr(flag, 1u);     // (NaN counts)
 #ifdef LLMK_PF_TRACE
     if (tid == 0) { tr[17] = wall_clock64(); tr[19] = __builtin_readcyclecounter(); }
 #endif

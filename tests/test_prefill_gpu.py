@@ -221,3 +221,27 @@ def test_prefill_range_guard_redoes_the_call_on_the_f32_instruction(wtype, gguf)
         assert rel_err(lg[None], ol[None]).max() <= REL_TOL
         tok = int(np.argmax(ol)) + 1
     m.close()
+
+
+@pytest.mark.parametrize("wtype", [0, 1], ids=["f32", "f16"])
+def test_prefill_small_activations_are_redone_on_the_f32_instruction(wtype, gguf):
+    """The LOW end of the two-piece split (advisor, round 3): below 2^-3 the lo piece is an f16 subnormal and a pair's error is
+    2^-24 absolute -- 2e-4 of a value of 3e-4.  Attention norm gains of 2^-10 put the QKV input, and with it the attention
+    output (the wo GEMM's input), at ~1e-3..1e-4 for every position; wo is scaled by 2^10 (exact in f32 and in f16) so the
+    residual stream keeps its size and the error would reach the logits.  The staging sees a position whose largest element
+    is below 2^-7, raises the range flag, and the call is redone on the f32 instruction: logits within 1e-4 of the oracle."""
+    s = gguf.SHAPES["tk-small16"]
+    fw = gguf.synth_fused(s, 78, wtype)
+    fw.rms_att_weight = (fw.rms_att_weight * np.float32(2.0 ** -10)).astype(np.float32)
+    fw.wo = (fw.wo * fw.wo.dtype.type(1024)).astype(fw.wo.dtype)
+    rng = np.random.default_rng(12)
+    n = 41
+    prompt = [2] + (rng.integers(3, s.vocab_size, n - 1) + 1).tolist()
+    o = Oracle(fw.as_f32() if wtype else fw, "omp")
+    for pos, tok in enumerate(prompt, 1):
+        ol = o.forward(tok, pos)
+    assert np.all(np.isfinite(ol))
+    m = llmk.Llmk(fw)
+    lg = m.prefill(prompt, 1)
+    assert rel_err(lg[None], ol[None]).max() <= REL_TOL
+    m.close()
