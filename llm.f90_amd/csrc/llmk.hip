@@ -128,6 +128,8 @@ struct llmk_ctx {
     bool pf_ready = false;                 // pf_setup ran to its end
     // uploads are staged through the shim's OWN pinned memory (upload_block): two buffers, an event each
     void* up_stage[2] = {nullptr, nullptr};
+    void* up_stage_dev[2] = {nullptr, nullptr};      // the same buffers as the device addresses them
+    void* up_tmp[2] = {nullptr, nullptr};            // device scratch of the q4_0 re-packing (written and read by kernels only)
     hipEvent_t up_done[2] = {nullptr, nullptr};
     bool pf_hm = false;                    // GEMMs on v_mfma_f32_16x16x32_f16, activations (and f32 / q4_0 weights) as two f16 pieces (prefill.h)
     unsigned* pf_flag = nullptr;           // device word: an activation did not fit f16 (the call is redone on the f32 instruction)
@@ -1079,9 +1081,14 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
 // temporary per layer), and a copy engine that reads pageable memory through a cached registration of the virtual range reads
 // the pages that USED to be there.  Weights are copied once and read for the life of the ctx, so the shim no longer lets
 // the device read caller memory at all: the CPU copies each chunk into one of two pinned staging buffers (8 MB, allocated with
-// the first upload), summing its 16-bit words on the way; the chunk goes to the device from there; and the 64-bit sum of what
-// arrived is compared with the host's.  A mismatch is printed and the block staged again (three attempts, then
-// LLMK_E_VERIFY).  ~0.15 s per GB on one host core; LLMK_VERIFY_UPLOAD=0 skips the comparison, never the staging.
+// the first upload), summing its 16-bit words on the way.  THAT was not it either: the third event came with the staging in
+// place, and all three have the same signature -- the device's sum is 7/8 of the host's to four digits, on every retry: an
+// eighth of a freshly copied 16.5 MB scratch buffer reads as zeros to the kernel that follows the copy (one of the chip's
+// eight XCDs, each with its own L2, seeing the buffer as it was before a copy ENGINE wrote it).  So now no kernel ever reads what
+// a copy engine wrote: a kernel moves each chunk out of the (device-mapped) staging buffer into the tensor (q4_0: via a scratch
+// the shim keeps, re-packed on the way), and the 64-bit sum of the tensor's rows AS THEY THEN ARE is compared with the host's.
+// A mismatch is printed and the block staged again (three attempts, then LLMK_E_VERIFY).  ~0.15 s per GB on one host core;
+// LLMK_VERIFY_UPLOAD=0 skips the comparison, never the staging.
 constexpr size_t UP_STAGE_BYTES = (size_t)8 << 20;
 __global__ void sum16_kernel(const unsigned* __restrict__ w, size_t nbytes, unsigned long long* out) {
     const size_t nwords = nbytes / 4;
@@ -1105,6 +1112,10 @@ static unsigned long long stage_rows(uint8_t* dst, const uint8_t* src, size_t sp
         t += a;
     }
     return t;
+}
+// staging buffer (host memory, device-mapped) -> tensor rows: f32 / f16 rows are contiguous on both sides
+__global__ void stage_copy_kernel(const unsigned* __restrict__ src, unsigned* __restrict__ dst, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 static bool verify_uploads() {
     static const bool on = !(getenv("LLMK_VERIFY_UPLOAD") && getenv("LLMK_VERIFY_UPLOAD")[0] == '0');
@@ -1134,62 +1145,52 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
     int rc = LLMK_OK;
     if (!c->up_stage[0]) {
         for (int b = 0; b < 2; ++b) {
-            HIPCHK(hipHostMalloc(&c->up_stage[b], UP_STAGE_BYTES, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc(&c->up_stage[b], UP_STAGE_BYTES, hipHostMallocMapped));
+            HIPCHK(hipHostGetDevicePointer(&c->up_stage_dev[b], c->up_stage[b], 0));
             HIPCHK(hipEventCreateWithFlags(&c->up_done[b], hipEventDisableTiming));
+            HIPCHK(dev_alloc(&c->up_tmp[b], UP_STAGE_BYTES));
         }
     }
-    // `cr` rows from src_rows into dev_dst (contiguous, col_bytes per row): staged, sent, checked, staged again on a mismatch
-    auto copy_checked = [&](void* dev_dst, size_t dpitch, const uint8_t* src_rows, size_t cr) -> int {
-        if (dpitch != col_bytes || col_bytes > UP_STAGE_BYTES) return LLMK_E_ARG;      // (every destination here is contiguous)
-        const size_t rows_per_chunk = UP_STAGE_BYTES / col_bytes;
-        for (int attempt = 1;; ++attempt) {
-            unsigned long long want = 0;
-            int b = 0;
-            for (size_t r = 0; r < cr; r += rows_per_chunk, b ^= 1) {
-                const size_t n = cr - r < rows_per_chunk ? cr - r : rows_per_chunk;
-                hipError_t e = hipEventSynchronize(c->up_done[b]);                     // the buffer's previous chunk has left it
-                if (e != hipSuccess) return LLMK_E_HIP + (int)e;
-                want += stage_rows((uint8_t*)c->up_stage[b], src_rows + r * spitch + col_off, spitch, col_bytes, n);
-                e = hipMemcpyAsync((char*)dev_dst + r * col_bytes, c->up_stage[b], n * col_bytes, hipMemcpyHostToDevice, 0);
-                if (e == hipSuccess) e = hipEventRecord(c->up_done[b], 0);
-                if (e != hipSuccess) return LLMK_E_HIP + (int)e;
+    if (col_bytes > UP_STAGE_BYTES || col_bytes % 2) { if (d_acc) hipFree(d_acc); return LLMK_E_ARG; }
+    const bool q4 = t.type == LLMK_TYPE_Q4_0;
+    const size_t blocks_per_row = col_bytes / 18;                       // (q4_0)
+    const size_t rows_per_chunk = UP_STAGE_BYTES / col_bytes;
+    char* dst0 = (char*)t.data + first_row * t.row_bytes;              // the block's rows in the tensor (contiguous: row_bytes apart)
+    for (int attempt = 1; rc == LLMK_OK; ++attempt) {
+        unsigned long long want = 0;
+        int b = 0;
+        for (size_t r = 0; r < (size_t)nrows && rc == LLMK_OK; r += rows_per_chunk, b ^= 1) {
+            const size_t n = (size_t)nrows - r < rows_per_chunk ? (size_t)nrows - r : rows_per_chunk;
+            hipError_t e = hipEventSynchronize(c->up_done[b]);             // the kernel that read this buffer's previous chunk has finished
+            if (e != hipSuccess) { rc = LLMK_E_HIP + (int)e; break; }
+            want += stage_rows((uint8_t*)c->up_stage[b], src + r * spitch + col_off, spitch, col_bytes, n);
+            // a KERNEL moves the chunk from the (device-mapped) staging buffer into the tensor -- re-packing q4_0 blocks on the
+            // way -- so nothing a copy engine wrote is ever read by a kernel
+            if (q4) {   // (wide loads over PCIe into a device scratch first: the re-packing reads 2 bytes at a time)
+                hipLaunchKernelGGL(stage_copy_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)c->up_stage_dev[b], (unsigned*)c->up_tmp[b],
+                                   (n * col_bytes + 3) / 4);
+                hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, (const uint8_t*)c->up_tmp[b], dst0 + r * t.row_bytes,
+                                   n * blocks_per_row, (int)blocks_per_row, t.row_bytes);
             }
-            hipError_t e = hipDeviceSynchronize();
-            if (e != hipSuccess) return LLMK_E_HIP + (int)e;
-            if (!verify) return LLMK_OK;
-            unsigned long long got = 0;
-            e = device_sum16(dev_dst, cr * col_bytes, d_acc, &got);
-            if (e != hipSuccess) return LLMK_E_HIP + (int)e;
-            if (got == want) return LLMK_OK;
-            fprintf(stderr, "llmk: upload of tensor %d, layer %d, local rows %zu..%zu (%zu bytes) did not arrive intact: 16-bit word sum 0x%llx on the "
-                            "device, 0x%llx on the host (attempt %d of 3)%s\n", tid, layer, first_row, first_row + cr - 1, cr * col_bytes, got, want,
-                    attempt, attempt < 3 ? " -- staging it again" : "");
-            if (attempt == 3) return LLMK_E_VERIFY;
+            else hipLaunchKernelGGL(stage_copy_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)c->up_stage_dev[b], (unsigned*)(dst0 + r * t.row_bytes),
+                                    n * col_bytes / 4);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(c->up_done[b], 0);
+            if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
         }
-    };
-    if (t.type == LLMK_TYPE_Q4_0) {
-        const size_t blocks_per_row = col_bytes / 18;
-        const size_t chunk_rows_max = ((size_t)256 << 20) / col_bytes + 1;
-        uint8_t* tmp = nullptr;
-        const size_t cr0 = (size_t)nrows < chunk_rows_max ? (size_t)nrows : chunk_rows_max;
-        hipError_t e = dev_alloc(&tmp, cr0 * col_bytes);
-        if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
-        for (size_t r = 0; r < (size_t)nrows && rc == LLMK_OK; r += cr0) {
-            const size_t cr = ((size_t)nrows - r) < cr0 ? ((size_t)nrows - r) : cr0;
-            const size_t nb = cr * blocks_per_row;
-            rc = copy_checked(tmp, col_bytes, src + r * spitch, cr);
-            if (rc == LLMK_OK) {
-                hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, tmp, (char*)t.data + (first_row + r) * t.row_bytes,
-                                   nb, (int)blocks_per_row, t.row_bytes);
-                e = hipGetLastError();
-                if (e == hipSuccess) e = hipDeviceSynchronize();
-                if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
-            }
-        }
-        if (tmp) hipFree(tmp);
-    } else {
-        rc = copy_checked((char*)t.data + first_row * t.row_bytes, t.row_bytes, src, (size_t)nrows);
+        if (rc != LLMK_OK || !verify) break;
+        // the tensor's rows as they now are: a q4_0 row's 16-bit words are its blocks' words in another order (8 nibble words and
+        // the scale per block, zero padding behind), so the sum of the re-packed image equals the sum of the bytes handed over
+        unsigned long long got = 0;
+        const hipError_t e = device_sum16(dst0, (size_t)nrows * t.row_bytes, d_acc, &got);
+        if (e != hipSuccess) { rc = LLMK_E_HIP + (int)e; break; }
+        if (got == want) break;
+        fprintf(stderr, "llmk: upload of tensor %d, layer %d, local rows %zu..%zu (%zu bytes) did not arrive intact: 16-bit word sum 0x%llx on the "
+                        "device, 0x%llx on the host (attempt %d of 3)%s\n", tid, layer, first_row, first_row + (size_t)nrows - 1, (size_t)nrows * col_bytes,
+                got, want, attempt, attempt < 3 ? " -- staging it again" : "");
+        if (attempt == 3) rc = LLMK_E_VERIFY;
     }
+    if (rc == LLMK_OK) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = LLMK_E_HIP + (int)e; }
     if (d_acc) hipFree(d_acc);
     if (rc) return rc;
     t.rows_uploaded += (size_t)nrows;
@@ -1952,6 +1953,7 @@ int llmk_destroy(llmk_ctx* c) {
         if (p) hipFree(p);
     for (int b = 0; b < 2; ++b) {
         if (c->up_stage[b]) hipHostFree(c->up_stage[b]);
+        if (c->up_tmp[b]) hipFree(c->up_tmp[b]);
         if (c->up_done[b]) hipEventDestroy(c->up_done[b]);
     }
     if (c->h_tokpos) hipHostFree(c->h_tokpos);
