@@ -66,7 +66,8 @@ def pmc_traffic(kernel_substr: str, shape_name: str, type_name: str):
     workload in their name: they are all TinyLlama f32.)"""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{shape_name}_{type_name}_pmc_fetch_size.csv")))
+    pat = re.compile(rf"r\d+[a-z]?_{re.escape(shape_name)}_{re.escape(type_name)}_pmc_fetch_size\.csv$")   # not r04_prefill512_<shape>_...
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_size.csv")) if pat.match(os.path.basename(f)))
     if not files and (shape_name, type_name) == ("tinyllama", "f32"):
         files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r01*_pmc_fetch_size.csv")))
     if not files:
