@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "q4_mfma.h"
 
 // ---- measurement knobs (defaults = the product; -D... builds a variant library for an A/B) ---------------------------
 // loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it).  H = 5632 is
@@ -182,6 +183,12 @@
 
 namespace llmk {
 
+// q4_0 dots on the matrix core (csrc/q4_mfma.h; round 4, experimental -- off in the product build): lane = (block, row) instead
+// of lane = block, x as an f16 hi/lo image in LDS read per block instead of a register fragment, v_mfma_f32_4x4x4_16B_f16
+// instead of v_fma_mix_f32.  Tiles, rows per CU, slots, partial sums and sweeps are unchanged.
+#ifndef LLMK_TK_Q4_MFMA
+#define LLMK_TK_Q4_MFMA 0
+#endif
 constexpr int TK_NCU = 256;               // one workgroup per CU
 constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
 // register tiles a streaming wave keeps requested ahead: TkShape::NB (5 x 8 KB for f32 / f16; 3 for q4_0, whose x fragment
@@ -271,6 +278,7 @@ struct TkShape {
     // fetches each block's f16 scale (stored right behind the row's nibbles) with its own 2-byte load (8 more loads per
     // tile, 1/8 of the bytes).  Rows need not be whole segments: see tk_issue.
     static constexpr bool Q4 = WT == WT_Q4_0;
+    static constexpr bool Q4M = Q4 && LLMK_TK_Q4_MFMA != 0;             // dots on v_mfma_f32_4x4x4_16B_f16 (q4_mfma.h)
     static constexpr int VPL = Q4 ? 32 : (WT == WT_F16 ? 8 : 4);         // weights per 16-byte lane load
     static constexpr int SEGW = WAVE * VPL;                              // weights per 1 KB segment
     // bytes between rows, K = E / K = H (q4_0 device row: K/2 nibble bytes, then the row's K/32 f16 scales, 16-byte aligned)
@@ -322,6 +330,11 @@ struct TkShape {
     static constexpr int R_C = RPT * (CB + (CX > 0 ? 1 : 0));
     static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU;
     static constexpr int TPR_H = (LPR_H + LPT - 1) / LPT;                // column parts of a w2 row
+    // Q4M: blocks of the f16 image of x in LDS (whole column parts: the blocks past a ragged K = H row end stay zero), and how
+    // the staging code is told which image to write: 0 natural order, > 0 the transposed float4 image at that pitch, < 0 the
+    // f16 image of -TR blocks (its block sums follow it)
+    static constexpr int NBI = (TPR_H * LPT > LPR_E ? TPR_H * LPT : LPR_E) * WAVE;
+    static constexpr int TR_E = Q4M ? -NBI : (Q4 ? NBP_E : 0), TR_H = Q4M ? -NBI : (Q4 ? NBP_H : 0);
     // a CU's row count need not be a multiple of RPT: the last tile then also covers rows of the NEXT CU (recomputed,
     // their partial sums land in slots nobody reads).  The weight allocations carry RPT rows of slack at their end.
     static constexpr int NG_A = (R_A / 2 + RPT - 1) / RPT;               // gate (= up) tiles per CU
@@ -380,7 +393,9 @@ struct TkLds {
     static constexpr int XS = 0;
     // q4_0: the streaming input is staged TRANSPOSED, xs4[m * NBP + b] = x[32 b + 4 m .. + 3], so the eight float4 a lane
     // needs for block b are lane-contiguous (conflict-free ds_read_b128); pitch NBP = blocks + 1
-    static constexpr int XS_BYTES = SH::Q4 ? 8 * (SH::NBP_H > SH::NBP_E ? SH::NBP_H : SH::NBP_E) * 16 : SH::H * 4;
+    // Q4M: the f16 image (q4_mfma.h: 128 bytes per block) followed by the blocks' 8 * sum x
+    static constexpr int XS_BYTES = SH::Q4M ? SH::NBI * (Q4M_BLK + 4) + WAVE * 4      // (+ 64 junk slots: tk_coop_part)
+                                            : (SH::Q4 ? 8 * (SH::NBP_H > SH::NBP_E ? SH::NBP_H : SH::NBP_E) * 16 : SH::H * 4);
     static constexpr int XRAW = XS + XS_BYTES;
     static constexpr int PART = XRAW + SH::E * 4;
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
@@ -606,6 +621,14 @@ __device__ __forceinline__ bool tk_gather3_pieces(__amdgpu_buffer_rsrc_t rs, uns
 // holds this CU's OWN rows cannot complete before the service wave has published them, i.e. after its epilogue has read
 // xraw -- so a wave may start on the next vector while the epilogue of the previous phase still runs.
 //   xraw (optional) <- x;  xs <- x * gains (NORM) or x;  *ss += sum x^2 (NORM)
+// sum over the 16 lanes of a DPP row (= the HS/4 lanes that share a timestep); valid in lane 15 of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1, 0xf, true>(0.f, v);
+    v += dpp_mov<0x4E, 0xf, true>(0.f, v);
+    v += dpp_mov<0x114, 0xf, true>(0.f, v);
+    v += dpp_mov<0x118, 0xf, true>(0.f, v);
+    return v;
+}
 struct TkNoop { __device__ __forceinline__ void operator()() const {} };
 // after_first(): issued right behind the loads of the FIRST pass (LLMK_TK_ADV_GATHER: a tile request that follows the sweep
 // into the CU's memory pipeline); straight-line code, so the tag check waits with vmcnt(<those loads>), not vmcnt(0)
@@ -622,6 +645,10 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
         }
         const int e0 = 2 * (first_pair + lane);
         const int d0 = tk_xoff<NBP>(e0);
+        // NBP < 0: where this lane's pair goes in the f16 image, its factor (1 or 1/16), and the row's block-sum slot (or the junk slot)
+        char* mp = NBP < 0 ? q4m_pair_ptr(reinterpret_cast<char*>(xs), e0) : nullptr;
+        const float msc = NBP < 0 ? q4m_pair_scale(e0) : 1.f;
+        float* m8 = reinterpret_cast<float*>(reinterpret_cast<char*>(xs) + (NBP < 0 ? -NBP : 0) * Q4M_BLK) + ((lane & 15) == 15 ? (e0 >> 5) : (NBP < 0 ? -NBP : 0) + lane);
         for (unsigned spin = 0;; ++spin) {
             tk_v4u r[NLW];
 #pragma unroll
@@ -636,12 +663,21 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                 for (int k = 0; k < NLW; ++k) {
                     const float x0 = __uint_as_float(r[k].x), x1 = __uint_as_float(r[k].z);
                     if (xraw) *reinterpret_cast<float2*>(xraw + e0 + k * 2 * WAVE) = make_float2(x0, x1);
+                    float y0 = x0, y1 = x1;
                     if constexpr (NORM) {
                         acc = fmaf(x0, x0, acc);
                         acc = fmaf(x1, x1, acc);
-                        *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0 * gn[k].x, x1 * gn[k].y);
+                        y0 = x0 * gn[k].x; y1 = x1 * gn[k].y;
+                    }
+                    if constexpr (NBP < 0) {
+                        // the f16 image (q4_mfma.h) and the block's 8 * sum x: a load's 64 lanes hold 4 whole blocks, one per DPP row;
+                        // load k lies 4 blocks = 512 bytes further (immediate offsets).  The sums leave without a branch: the lanes
+                        // that do not hold a row's total write a junk slot behind the array.
+                        q4m_put2_at(mp + k * 4 * Q4M_BLK, msc, y0, y1);
+                        const float bs = row16_sum(y0 + y1);
+                        m8[(lane & 15) == 15 ? k * 4 : 0] = 8.0f * bs;
                     } else {
-                        *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0, x1);
+                        *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(y0, y1);
                     }
                 }
                 if constexpr (NORM) *ss += acc;
@@ -709,6 +745,16 @@ struct TkNorm {
             o.y = x.y * w[k].y;
             o.z = x.z * w[k].z;
             o.w = x.w * w[k].w;
+            if constexpr (NBP < 0) {
+                // the f16 image (q4_mfma.h): eight lanes hold one block
+                const int e = 4 * (lane + k * WAVE);
+                q4m_put4(reinterpret_cast<char*>(xs), e, o);
+                float bs = (o.x + o.y) + (o.z + o.w);
+                bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
+                bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
+                bs += dpp_mov<0x114, 0xf, true>(0.f, bs);      // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
+                if ((lane & 7) == 7) reinterpret_cast<float*>(reinterpret_cast<char*>(xs) + (-NBP) * Q4M_BLK)[e >> 5] = 8.0f * bs;
+            } else
             *reinterpret_cast<float4*>(xs + xs0 + k * (NBP > 0 ? 32 : 4 * WAVE)) = o;
         }
         ss = wave_sum(ss);
@@ -737,8 +783,36 @@ struct TkSlot {
     unsigned short sc[SH::Q4 ? TK_TCOLS : 1];
 };
 
+// Q4M (q4_mfma.h): the same 4 rows x 2 segments, other lanes: lane (beta = lane / 4, m = lane % 4) takes row m, and of the
+// tile row's 128 blocks the blocks 16 g + beta, g = 0..7 -- one load instruction = 4 rows x 256 contiguous bytes.  Load g lies
+// in segment g / 4.
+template <class SH>
+__device__ __forceinline__ void tk_issue_m_w(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
+    static_assert(SH::RPT == 4 && SH::LPT == 2, "the q4_0 tile: 4 rows x 2 segments");
+#pragma unroll
+    for (int g = 0; g < TK_TCOLS; ++g) {
+        const bool real = (g / 4) < t.ncol;
+        const float4* pj = real ? t.p + (lane & 3) * t.rstride + g * 16 + (lane >> 2) : zp;
+        e.b[g] = ldg_nt(pj);
+    }
+}
+template <class SH>
+__device__ __forceinline__ void tk_issue_m_s(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
+#pragma unroll
+    for (int g = 0; g < TK_TCOLS; ++g) {
+        const bool real = (g / 4) < t.ncol;
+        const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(t.p + (lane & 3) * t.rstride) + t.soff) + g * 16 + (lane >> 2)
+                                        : reinterpret_cast<const unsigned short*>(zp);
+        e.sc[g] = __builtin_nontemporal_load(pj);
+    }
+}
 template <class SH>
 __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
+    if constexpr (SH::Q4M) {
+        tk_issue_m_w<SH>(e, t, zp, lane);
+        tk_issue_m_s<SH>(e, t, zp, lane);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
@@ -769,8 +843,17 @@ __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const f
 template <class SH>
 struct TkX {
     static constexpr int F4 = SH::VPL / 4;          // float4 of x per segment and lane: 1 (f32), 2 (f16), 8 (q4_0: one block)
-    float4 v[SH::LPT * F4];
-    float xs8[SH::Q4 ? SH::LPT : 1];                // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
+    float4 v[SH::Q4M ? 1 : SH::LPT * F4];
+    float xs8[SH::Q4 && !SH::Q4M ? SH::LPT : 1];    // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
+    // Q4M: no fragment -- this lane's piece (lane & 1: hi or lo; lanes 2, 3 of a group feed matrix rows nobody reads) of block
+    // seg0 * 64 + lane / 4 in the f16 image, and that block's 8 * sum x; load g of a tile is 16 g blocks further
+    const char* xp;
+    const float* x8;
+    __device__ __forceinline__ void load_q4m(const char* img, int seg0, int lane) {
+        const int b = seg0 * WAVE + (lane >> 2);
+        xp = img + b * Q4M_BLK + (lane & 1) * 64;
+        x8 = reinterpret_cast<const float*>(img + SH::NBI * Q4M_BLK) + b;
+    }
     // segments seg0 .. seg0+LPT-1 of a vector with nseg segments; segments past the end read as zero
     __device__ __forceinline__ void load(const float4* xs, int seg0, int nseg, int lane) {
 #pragma unroll
@@ -884,8 +967,46 @@ __device__ __forceinline__ float tk_q4_block(float tl, float th, float d, float 
     else return fmaf(d, t - xs8, acc);
 }
 
+// Q4M: loads G0 .. G0+N-1 of a tile against the image: acc += d (2^24 s - 8 sum x) per block, for the row lane & 3
+template <class SH, int G0, int N, bool PIPE = true>
+__device__ __forceinline__ float tk_dot_m(const TkSlot<SH>& e, const TkX<SH>& x, float acc) {
+    // PIPE: block g + 1's piece of x (16 registers) and the blocks' sums are on their way through LDS while block g is multiplied
+    // (the service wave, which carries the layer loop's state, reads one block at a time)
+    uint4 xv[PIPE ? 2 : 1][4];
+    float s8[N];
+    q4m_xload(xv[0], x.xp + G0 * 16 * Q4M_BLK);
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) s8[i] = x.x8[(G0 + i) * 16];
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int g = G0 + i;
+        if constexpr (PIPE) { if (i + 1 < N) q4m_xload(xv[(i + 1) & 1], x.xp + (g + 1) * 16 * Q4M_BLK); }
+        else { if (i > 0) q4m_xload(xv[0], x.xp + g * 16 * Q4M_BLK); s8[i] = x.x8[g * 16]; }
+        const float4& w = e.b[g];
+        const uint4 q = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w));
+        const float sm = q4m_block(q, xv[PIPE ? (i & 1) : 0]);
+        const unsigned short hs = e.sc[g];
+        const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
+        acc = fmaf(d, fmaf(sm, Q4M_RESCALE, -s8[i]), acc);
+        __builtin_amdgcn_sched_barrier(0);      // (hoisted further, the reads of all eight blocks spill the ring)
+    }
+    return acc;
+}
+// the sixteen lanes that share lane & 3 -> the row's sum (valid in lanes 12..15 of every DPP row), written by lanes 12..15
+template <class SH>
+__device__ __forceinline__ void tk_finish_m(float acc, const TkTile& t, float* part, int lane) {
+    acc += dpp_mov<0x114, 0xf, true>(0.f, acc);       // row_shr:4
+    acc += dpp_mov<0x118, 0xf, true>(0.f, acc);       // row_shr:8
+    acc += __shfl_xor(acc, 16, WAVE);
+    acc += __shfl_xor(acc, 32, WAVE);
+    if ((lane & ~3) == 12) part[t.pidx + (lane & 3) * t.pstep] = acc;
+}
+
 template <class SH>
 __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, float (&out)[SH::RPT]) {
+    static_assert(!SH::Q4M, "Q4M tiles go through tk_dot_m");
     const float4 (&b)[TK_TCOLS] = e.b;
     if constexpr (SH::Q4) {
         // sum_i (n_i - 8) d x_i = d (sum_i n_i x_i - 8 sum_i x_i): low nibbles are elements 0..15 of the block, high nibbles
@@ -933,13 +1054,17 @@ __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, fl
 }
 template <class SH>
 __device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t, const TkX<SH>& x, float* part, int lane) {
-    float v[SH::RPT];
-    tk_dot<SH>(b, x, v);
+    if constexpr (SH::Q4M) {
+        tk_finish_m<SH>(tk_dot_m<SH, 0, TK_TCOLS>(b, x, 0.f), t, part, lane);
+    } else {
+        float v[SH::RPT];
+        tk_dot<SH>(b, x, v);
 #pragma unroll
-    for (int s = 0; s < SH::RPT; ++s) v[s] = wave_sum(v[s]);
-    if (lane == 0) {
+        for (int s = 0; s < SH::RPT; ++s) v[s] = wave_sum(v[s]);
+        if (lane == 0) {
 #pragma unroll
-        for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = v[s];
+            for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = v[s];
+        }
     }
 }
 
@@ -949,6 +1074,11 @@ __device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t,
 template <class SH>
 __device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const TkTile& t, const float4* xs4, float* part, int lane) {
     static_assert(SH::Q4, "q4_0 tiles");
+    if constexpr (SH::Q4M) {
+        TkX<SH> x;
+        x.load_q4m(reinterpret_cast<const char*>(xs4), 0, lane);
+        tk_finish_m<SH>(tk_dot_m<SH, 0, TK_TCOLS, false>(e, x, 0.f), t, part, lane);
+    } else {
     float acc[SH::RPT];
 #pragma unroll
     for (int s = 0; s < SH::RPT; ++s) acc[s] = 0.f;
@@ -980,6 +1110,7 @@ __device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const Tk
     if (lane == 0) {
 #pragma unroll
         for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = acc[s];
+    }
     }
 }
 
@@ -1190,14 +1321,6 @@ __device__ __forceinline__ unsigned long long* tk_g_part(const TokenArgs& a, int
     return tk_g_x<SH>(a) + SH::E + ((size_t)h * (TkAttPlan<SH>::PMAX - 1) + (p - 1)) * (SH::HS + 2);
 }
 
-// sum over the 16 lanes of a DPP row (= the HS/4 lanes that share a timestep); valid in lane 15 of the row
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_mov<0xB1, 0xf, true>(0.f, v);
-    v += dpp_mov<0x4E, 0xf, true>(0.f, v);
-    v += dpp_mov<0x114, 0xf, true>(0.f, v);
-    v += dpp_mov<0x118, 0xf, true>(0.f, v);
-    return v;
-}
 // sum over the LPT = HS/4 lanes that share a timestep: one DPP row (head size 64) or two (head size 128: row_bcast:15
 // adds the even row's total into the odd row); valid in the LAST lane of the group
 template <int LPT>
@@ -1344,13 +1467,14 @@ __device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
 // instantiation because the f32 kernel sits at the register ceiling: with the candidate code compiled in, hipcc spills 20
 // bytes per lane in the STREAMING waves' loop (one s_waitcnt vmcnt(0) + scratch store per slot: the ring drains).
 template <class SH, bool GR>
-__device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c, int lane, int tid) {
+__device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c, int lane_in, int tid) {
+    int lane = lane_in;     // (Q4M: made opaque once per layer, so that what is derived from it is recomputed there, not spilled)
     typedef TkLds<SH> LD;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
     float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
     const float* part = reinterpret_cast<const float*>(lds + LD::PART);
     // q4_0: the streaming input is staged transposed (TkLds); 0 = natural order
-    constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
+    constexpr int TR_E = SH::TR_E, TR_H = SH::TR_H;
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
     // hb as {v0, v1, v2, tag} granules: the f32 / f16 kernels (the q4_0 kernel gathers with all eight waves, tk_coop_gather)
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF: gathers issued so far on this CU
@@ -1391,6 +1515,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
+        if constexpr (SH::Q4M) asm volatile("" : "+v"(lane));
         TK_STAMP(0);
 
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
@@ -1717,7 +1842,10 @@ __device__ __forceinline__ void tk_run(TkRing<SH>& r, const TokenArgs& a, int l,
 // scheduler can interleave), then ONE lane-0 block of LDS writes
 template <class SH, int K, int N>
 __device__ __forceinline__ void tk_eat(const TkRing<SH>& r, const TkX<SH>& x, float* part, int lane) {
-    if constexpr (N > 0) {
+    if constexpr (N > 0 && SH::Q4M) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) tk_consume<SH>(r.b[(K + i) % SH::NB], r.t[(K + i) % SH::NB], x, part, lane);
+    } else if constexpr (N > 0) {
         float v[N][SH::RPT];
 #pragma unroll
         for (int i = 0; i < N; ++i) tk_dot<SH>(r.b[(K + i) % SH::NB], x, v[i]);
@@ -1817,6 +1945,24 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
     // a padding slot (the layer's slots rounded up to the ring depth) holds no tile on any wave of any CU: it only keeps the
     // ring turning -- the request, no dots
     constexpr bool PAD = !CLS && (K % TkSched<SH>::SLP) >= TkSched<SH>::KP;
+    if constexpr (SH::Q4M) {
+        // the same interleaving on the matrix-core dots: half of the tile's blocks, the next tile's nibble vectors, the other half,
+        // its scales, then the reduction
+        float acc = 0.f;
+        if constexpr (!PAD) acc = tk_dot_m<SH, 0, 4>(e, x, acc);
+        if constexpr (REQ) {
+            __builtin_amdgcn_sched_barrier(0);
+            tk_issue_m_w<SH>(n, tn, a.zeros, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!PAD) acc = tk_dot_m<SH, 4, 4>(e, x, acc);
+        if constexpr (REQ) {
+            __builtin_amdgcn_sched_barrier(0);
+            tk_issue_m_s<SH>(n, tn, a.zeros, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!PAD) tk_finish_m<SH>(acc, r.t[R], part, lane);
+    } else {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     auto row = [&](int s_) {
         float acc = 0.f;
@@ -1873,6 +2019,7 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
             for (int s_ = 0; s_ < 4; ++s_) part[t.pidx + s_ * t.pstep] = v[s_];
         }
     }
+    }
     r.t[RN] = tn;
 }
 template <class SH, int K, int N, bool CLS, bool REQ0 = true>
@@ -1888,7 +2035,8 @@ __device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a,
                                               float* part, int lane) {
     tk_barrier();
     TkX<SH> x;
-    if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
+    if constexpr (SH::Q4M) x.load_q4m(reinterpret_cast<const char*>(xs4), WIDE ? (sw % SH::TPR_H) * SH::LPT : 0, lane);
+    else if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
     else x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
     tk_steps<SH, K0, S, CLS, REQ0>(r, a, l, c, sw, x, part, lane);
     tk_barrier();
@@ -1994,7 +2142,7 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
     const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
     float* part = reinterpret_cast<float*>(lds + LD::PART);
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);
-    constexpr int TR_E = SH::Q4 ? SH::NBP_E : 0, TR_H = SH::Q4 ? SH::NBP_H : 0;
+    constexpr int TR_E = SH::TR_E, TR_H = SH::TR_H;
     const int L = a.L;
     const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
     const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
@@ -2229,6 +2377,14 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         a.o0 = SH::RPT * (n * SH::OB + min(n, SH::OX));
         a.cn = SH::RPT * (SH::CB + (c < SH::CX ? 1 : 0));
         a.c0 = SH::RPT * (c * SH::CB + min(c, SH::CX));
+    }
+    if constexpr (SH::Q4M) {
+        // the image blocks past the end of a K = H row (whole column parts are read) and their sums: zero for the whole launch
+        // (nobody writes them; first read in layer 0's w2 phase, several barriers from here)
+        char* img = lds + TkLds<SH>::XS;
+        for (int i = SH::NBLK_H * Q4M_BLK + tid * 16; i < SH::NBI * Q4M_BLK; i += TK_THREADS * 16) *reinterpret_cast<uint4*>(img + i) = make_uint4(0u, 0u, 0u, 0u);
+        float* x8 = reinterpret_cast<float*>(img + SH::NBI * Q4M_BLK);
+        for (int i = SH::NBLK_H + tid; i < SH::NBI; i += TK_THREADS) x8[i] = 0.f;
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
     else if constexpr (SH::COOP) tk_stream_coop<SH>(a, lds, c, wid, lane, tid);

@@ -12,7 +12,7 @@
 #                            process holding a GPU context, rank 0 in-process (8 GPU processes) and spawned (9)   -> nine.log
 #   dirty                    does a process see another (or its own earlier) process's freed VRAM?   -> dirty.log
 #   bench NAME [bench args]  python bench.py [args]                              -> NAME.json
-#   ab NAME N <env> -- [bench args]   N interleaved pairs of bench.py with / without the env setting   -> NAME.jsonl
+#   ab NAME N <env>... : [bench args]   N interleaved pairs of bench.py with / without the env setting   -> NAME.jsonl
 #   prof TAG                 the evidence run: per single-GPU configuration of BASELINE.json a bench line, the pipelined-greedy
 #                            line, rocprofv3 --kernel-trace --stats and a FETCH_SIZE pass (separate runs); the 70B rank's
 #                            kernels; the prefill lines with their own stats + FETCH_SIZE; the KV-length curve
@@ -130,10 +130,10 @@ job_repeat() {
     if timeout 900 python -m pytest "$@" -m gpu -x -q > /tmp/rep_$i.log 2>&1; then echo "run $i: pass $(tail -1 /tmp/rep_$i.log)"; else echo "run $i: FAIL"; tail -40 /tmp/rep_$i.log; cp /tmp/rep_$i.log $OUT/repeat_fail_$i.log; fi | tee -a $OUT/repeat.log
   done
 }
-job_ab() {  # NAME N ENV... -- bench args
+job_ab() {  # NAME N ENV... : bench args     (":" -- the job list itself is split at "--")
   local name=$1 n=$2; shift 2
   local envs=()
-  while [ $# -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  while [ $# -gt 0 ] && [ "$1" != ":" ]; do envs+=("$1"); shift; done
   [ $# -gt 0 ] && shift
   : > $OUT/$name.jsonl
   local i line
