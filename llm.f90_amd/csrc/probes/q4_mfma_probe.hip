@@ -18,6 +18,7 @@ using namespace llmk;
 constexpr int K = 4096, NBLK = K / 32, ROWS = 4;
 constexpr int RB = K / 2 + NBLK * 2;              // device row: nibble plane, then the f16 scales
 constexpr int ITERS = 400;
+constexpr int PL = NBLK * Q4M_PB;             // bytes per plane of the image
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -37,7 +38,7 @@ __device__ __forceinline__ float dot_m(const TileM& t, const char* img, const fl
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const int b = 16 * g + (lane >> 2);
-        const float s = q4m_block(t.q[g], img + b * Q4M_BLK + (lane & 1) * 64);
+        const float s = q4m_block<PL>(t.q[g], img + b * Q4M_PB + (lane & 1) * 16);
         const float d = __half2float(*reinterpret_cast<const __half*>(&t.sc[g]));
         acc = fmaf(d, fmaf(s, Q4M_RESCALE, -xs8[b]), acc);
     }
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(64) void check_kernel(const char* W, const float* x
     __shared__ __attribute__((aligned(16))) char img[NBLK * Q4M_BLK];
     __shared__ float xs8[NBLK];
     const int lane = threadIdx.x;
-    if (PUT == 2) for (int e = 2 * lane; e < K; e += 128) q4m_put2(img, e, x[e], x[e + 1]);
-    else for (int e = 4 * lane; e < K; e += 256) q4m_put4(img, e, *reinterpret_cast<const float4*>(x + e));
+    if (PUT == 2) for (int e = 2 * lane; e < K; e += 128) q4m_put2<PL>(img, e, x[e], x[e + 1]);
+    else for (int e = 4 * lane; e < K; e += 256) q4m_put4<PL>(img, e, *reinterpret_cast<const float4*>(x + e));
     for (int b = lane; b < NBLK; b += 64) { float s = 0.f; for (int i = 0; i < 32; ++i) s += x[32 * b + i]; xs8[b] = 8.f * s; }
     __syncthreads();
     TileM t;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(512) void time_kernel(const char* W, const float* x
     __shared__ __attribute__((aligned(16))) char img[NBLK * Q4M_BLK];
     __shared__ float xs8[NBLK];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int e = 2 * tid; e < K; e += 1024) q4m_put2(img, e, x[e], x[e + 1]);
+    for (int e = 2 * tid; e < K; e += 1024) q4m_put2<PL>(img, e, x[e], x[e + 1]);
     for (int b = tid; b < NBLK; b += 512) { float s = 0.f; for (int i = 0; i < 32; ++i) s += x[32 * b + i]; xs8[b] = 8.f * s; }
     __syncthreads();
     float r = 0.f;
@@ -184,7 +185,7 @@ int main() {
         CK(hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost));
         double s = 0.0; unsigned long long mx = 0;
         for (auto t : c) { s += (double)t; mx = t > mx ? t : mx; }
-        printf("{\"probe\": \"q4_mfma\", \"variant\": \"%s\", \"cycles_per_tile_per_wave_avg\": %.1f, \"max\": %.1f, \"counter\": \"s_memtime (100 MHz ticks x ...: compare the two lines)\"}\n",
+        printf("{\"probe\": \"q4_mfma\", \"variant\": \"%s\", \"cycles_per_tile_per_wave_avg\": %.1f, \"max\": %.1f, \"counter\": \"s_memtime clocks, 8 waves per CU\"}\n",
                v == 0 ? "valu fma_mix, x in registers" : "mfma 4x4x4 f16, x from LDS", s / c.size() / ITERS, (double)mx / ITERS);
     }
     return 0;

@@ -646,7 +646,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
         const int e0 = 2 * (first_pair + lane);
         const int d0 = tk_xoff<NBP>(e0);
         // NBP < 0: where this lane's pair goes in the f16 image, its factor (1 or 1/16), and the row's block-sum slot (or the junk slot)
-        char* mp = NBP < 0 ? q4m_pair_ptr(reinterpret_cast<char*>(xs), e0) : nullptr;
+        char* mp = NBP < 0 ? q4m_pair_ptr<(NBP < 0 ? -NBP : 1) * Q4M_PB>(reinterpret_cast<char*>(xs), e0) : nullptr;
         const float msc = NBP < 0 ? q4m_pair_scale(e0) : 1.f;
         float* m8 = reinterpret_cast<float*>(reinterpret_cast<char*>(xs) + (NBP < 0 ? -NBP : 0) * Q4M_BLK) + ((lane & 15) == 15 ? (e0 >> 5) : (NBP < 0 ? -NBP : 0) + lane);
         for (unsigned spin = 0;; ++spin) {
@@ -671,9 +671,9 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                     }
                     if constexpr (NBP < 0) {
                         // the f16 image (q4_mfma.h) and the block's 8 * sum x: a load's 64 lanes hold 4 whole blocks, one per DPP row;
-                        // load k lies 4 blocks = 512 bytes further (immediate offsets).  The sums leave without a branch: the lanes
+                        // load k lies 4 blocks = 128 bytes further in every plane (immediate offsets).  The sums leave without a branch: the lanes
                         // that do not hold a row's total write a junk slot behind the array.
-                        q4m_put2_at(mp + k * 4 * Q4M_BLK, msc, y0, y1);
+                        q4m_put2_at(mp + k * 4 * Q4M_PB, msc, y0, y1);
                         const float bs = row16_sum(y0 + y1);
                         m8[(lane & 15) == 15 ? k * 4 : 0] = 8.0f * bs;
                     } else {
@@ -748,7 +748,7 @@ struct TkNorm {
             if constexpr (NBP < 0) {
                 // the f16 image (q4_mfma.h): eight lanes hold one block
                 const int e = 4 * (lane + k * WAVE);
-                q4m_put4(reinterpret_cast<char*>(xs), e, o);
+                q4m_put4<(NBP < 0 ? -NBP : 1) * Q4M_PB>(reinterpret_cast<char*>(xs), e, o);
                 float bs = (o.x + o.y) + (o.z + o.w);
                 bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
                 bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
@@ -846,12 +846,12 @@ struct TkX {
     float4 v[SH::Q4M ? 1 : SH::LPT * F4];
     float xs8[SH::Q4 && !SH::Q4M ? SH::LPT : 1];    // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
     // Q4M: no fragment -- this lane's piece (lane & 1: hi or lo; lanes 2, 3 of a group feed matrix rows nobody reads) of block
-    // seg0 * 64 + lane / 4 in the f16 image, and that block's 8 * sum x; load g of a tile is 16 g blocks further
+    // seg0 * 64 + lane / 4 in plane 0 of the f16 image, and that block's 8 * sum x; load g of a tile is 16 g blocks further
     const char* xp;
     const float* x8;
     __device__ __forceinline__ void load_q4m(const char* img, int seg0, int lane) {
         const int b = seg0 * WAVE + (lane >> 2);
-        xp = img + b * Q4M_BLK + (lane & 1) * 64;
+        xp = img + b * Q4M_PB + (lane & 1) * 16;
         x8 = reinterpret_cast<const float*>(img + SH::NBI * Q4M_BLK) + b;
     }
     // segments seg0 .. seg0+LPT-1 of a vector with nseg segments; segments past the end read as zero
@@ -974,7 +974,8 @@ __device__ __forceinline__ float tk_dot_m(const TkSlot<SH>& e, const TkX<SH>& x,
     // (the service wave, which carries the layer loop's state, reads one block at a time)
     uint4 xv[PIPE ? 2 : 1][4];
     float s8[N];
-    q4m_xload(xv[0], x.xp + G0 * 16 * Q4M_BLK);
+    constexpr int PL = SH::NBI * Q4M_PB;           // bytes per plane of the image
+    q4m_xload<PL>(xv[0], x.xp + G0 * 16 * Q4M_PB);
     if constexpr (PIPE) {
 #pragma unroll
         for (int i = 0; i < N; ++i) s8[i] = x.x8[(G0 + i) * 16];
@@ -982,8 +983,8 @@ __device__ __forceinline__ float tk_dot_m(const TkSlot<SH>& e, const TkX<SH>& x,
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int g = G0 + i;
-        if constexpr (PIPE) { if (i + 1 < N) q4m_xload(xv[(i + 1) & 1], x.xp + (g + 1) * 16 * Q4M_BLK); }
-        else { if (i > 0) q4m_xload(xv[0], x.xp + g * 16 * Q4M_BLK); s8[i] = x.x8[g * 16]; }
+        if constexpr (PIPE) { if (i + 1 < N) q4m_xload<PL>(xv[(i + 1) & 1], x.xp + (g + 1) * 16 * Q4M_PB); }
+        else { if (i > 0) q4m_xload<PL>(xv[0], x.xp + g * 16 * Q4M_PB); s8[i] = x.x8[g * 16]; }
         const float4& w = e.b[g];
         const uint4 q = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w));
         const float sm = q4m_block(q, xv[PIPE ? (i & 1) : 0]);
@@ -2134,7 +2135,8 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
 // the service wave is slice 7) gathers its eighth of each phase's input vector right after the phase before it.  Vector and
 // epoch of every gather mirror tk_service.
 template <class SH>
-__device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, int c, int sw, int lane, int tid) {
+__device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, int c, int sw, int lane_in, int tid) {
+    int lane = lane_in;     // (LLMK_TK_LAUNDER: opaque once per layer -- what is derived from it is recomputed, not carried)
     typedef TkLds<SH> LD;
     typedef TkSched<SH> SC;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
@@ -2160,6 +2162,9 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
+#if defined(LLMK_TK_LAUNDER) && LLMK_TK_LAUNDER
+        asm volatile("" : "+v"(lane));
+#endif
         // QKV phase (its input was gathered at the end of the previous layer; layer 0: the service wave stages the embedding row)
         tk_phase_body<SH, SC::KQ, SH::SL_Q, false>(r, a, l, c, sw, xs4, part, lane);
         int at0, at1;
@@ -2382,7 +2387,9 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         // the image blocks past the end of a K = H row (whole column parts are read) and their sums: zero for the whole launch
         // (nobody writes them; first read in layer 0's w2 phase, several barriers from here)
         char* img = lds + TkLds<SH>::XS;
-        for (int i = SH::NBLK_H * Q4M_BLK + tid * 16; i < SH::NBI * Q4M_BLK; i += TK_THREADS * 16) *reinterpret_cast<uint4*>(img + i) = make_uint4(0u, 0u, 0u, 0u);
+        for (int j = 0; j < 4; ++j)
+            for (int i = SH::NBLK_H * Q4M_PB + tid * 16; i < SH::NBI * Q4M_PB; i += TK_THREADS * 16)
+                *reinterpret_cast<uint4*>(img + j * SH::NBI * Q4M_PB + i) = make_uint4(0u, 0u, 0u, 0u);
         float* x8 = reinterpret_cast<float*>(img + SH::NBI * Q4M_BLK);
         for (int i = SH::NBLK_H + tid; i < SH::NBI; i += TK_THREADS) x8[i] = 0.f;
     }
