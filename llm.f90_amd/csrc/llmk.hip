@@ -213,7 +213,13 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
             // tests/host_tools/tp_rank_time.py: QKV, 640 pairs, 7.9 -> 6.8 us; w1|w3 13.3 -> 18.8 us and the classifier shard
             // 9.3 -> 12.0 us the OTHER way: four times the blocks each stage the whole x)
             const bool wide = (a.K % 8192) == 0 && ks_env != 0 && (npairs / GEMV_WAVES < n_cu || ks_env > 0);
-            if (wide) {
+            static const int np_env = getenv("LLMK_Q4_NP") ? atoi(getenv("LLMK_Q4_NP")) : 0;       // measurement aid: pairs per wave, forced
+            if (np_env > 0 && !wide) {
+                if (np_env >= 4) Q4_LAUNCH(4, 1);
+                else if (np_env >= 2) Q4_LAUNCH(2, 1);
+                else Q4_LAUNCH(1, 1);
+            }
+            else if (wide) {
                 if (npairs / 4 >= want) Q4_LAUNCH(4, 4);
                 else if (npairs / 2 >= want) Q4_LAUNCH(2, 4);
                 else Q4_LAUNCH(1, 4);

@@ -11,7 +11,12 @@
 //     = piece i of x for that block, D[i][j] lands in lane (beta, j), register i: the lane that holds row j's nibbles and its
 //     block scale receives row j's hi and lo sums.  Rows 2 and 3 of A are never read back (whatever lanes (beta, 2..3) hold).
 //   One dword of nibbles = 5 bit operations + 2 matrix instructions instead of 5 + 8 v_fma_mix_f32.
-// What it costs: x cannot live in registers any more (a lane meets 8 different blocks per tile): 4 ds_read_b128 per block.
+// What it costs: x cannot live in registers any more (a lane meets 8 different blocks per tile): 4 ds_read_b128 per block, and
+// activations beyond the f16 range (|x| >= 65504) are not representable in the hi piece (unchecked here: the instantiation is a
+// measurement, not the product path).
+// MEASURED (MI355X, profiles/r04_q4_mfma_probe.jsonl, r04_ab.jsonl): 2,930 clocks per tile and wave against 3,300 for the VALU
+// recipe, and in the kernel 850 tok/s against 890 (parity green): a 2-pass matrix instruction takes the issue slot like a VALU
+// operation.  NOT the product path (LLMK_TK_Q4_MFMA = 0); kept as the record of the experiment.
 //
 // Image of x in LDS (built by the gathers, q4m_put2 / q4m_put4): FOUR PLANES, one per dword j = 0..3 of a block; in a plane
 // 32 bytes per block = piece 0 (16 bytes) | piece 1, a piece = [L_j | H_j], L_j = x[4j], x[4j+2], x[4j+1], x[4j+3] (the order the
@@ -19,7 +24,7 @@
 // / 16 (the high nibbles stay where they are: 16 n 2^-24).  Planes, because the sixteen groups of a wave read the same j at the
 // same time: 16 blocks x 2 pieces x 16 bytes = 512 contiguous bytes per ds_read_b128, no bank conflict.  (First version: 128
 // contiguous bytes per block -- the 32 addresses of an instruction fell on 8 of the 32 banks: probes/q4_mfma_probe measured the
-// whole tile at 3,018 clocks per wave against 3,300 for the VALU recipe.)
+// whole tile at 3,018 clocks per wave, the planes at 2,930.)
 #pragma once
 #include <hip/hip_runtime.h>
 
