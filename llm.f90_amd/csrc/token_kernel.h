@@ -105,7 +105,7 @@
 #endif
 // 1: even the first tiles of a burst wait until the service wave has ISSUED the phase's publish stores (second LDS word)
 #ifndef LLMK_TK_GF_PUB
-#define LLMK_TK_GF_PUB 0
+#define LLMK_TK_GF_PUB -1           // -1 = per type (TkShape::GF_PUB): f16 yes, f32 no
 #endif
 #ifndef LLMK_TK_GF_LAST          // which pass releases the burst: the first piece's (0) or the last piece's (1); -1 = per type
 #define LLMK_TK_GF_LAST -1
@@ -316,6 +316,10 @@ struct TkShape {
     static constexpr int GF_NOW = LLMK_TK_GF_NOW >= 0 ? LLMK_TK_GF_NOW : 2;     // (f16: 3 until round 4 put a slot of w1|w3 early)
     static constexpr int GF_DELAY = LLMK_TK_GF_DELAY >= 0 ? LLMK_TK_GF_DELAY : (WT == WT_F16 ? 36 : 56);
     static constexpr bool GF_LAST = LLMK_TK_GF_LAST >= 0 ? LLMK_TK_GF_LAST != 0 : WT == WT_F16;
+    // the first tiles of a refill burst also wait until the service wave has PUBLISHED the phase's results (stores share the CU's
+    // memory pipeline with loads).  Round 4, interleaved on two boxes (profiles/r04_ab.jsonl): f16 +0.5 % four times out of four
+    // (kernel 475.3 vs 477.7 us), f32 -1 % twice and equal once (1,452 vs 1,466 tok/s)
+    static constexpr bool GF_PUB = LLMK_TK_GF_PUB >= 0 ? LLMK_TK_GF_PUB != 0 : WT == WT_F16;
     static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
     static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
     // rows per CU and tiles per CU for each phase
@@ -1524,7 +1528,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         const bool coop0 = SH::GCOOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
         if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane);
         float xn_att = 1.f;
-        if (GF && att_cu) { tk_flag_set(gflag, 4 * l + 1, lane); if (LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 1, lane); }   // no x and no xb gather on this CU: nothing for its bursts to wait for
+        if (GF && att_cu) { tk_flag_set(gflag, 4 * l + 1, lane); if (SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 1, lane); }   // no x and no xb gather on this CU: nothing for its bursts to wait for
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
             if (coop0) {
                 if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
@@ -1563,7 +1567,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
             tk_publish(a.g_qkv + r, e_q, outv);
         }
-        if (GF && LLMK_TK_GF_PUB && !att_cu) tk_flag_set(gflag + 1, 4 * l + 1, lane);
+        if (GF && SH::GF_PUB && !att_cu) tk_flag_set(gflag + 1, 4 * l + 1, lane);
         TK_STAMP(4);
         // ---- P1: attention, one CU per head                                     llama2.f90:572-598
         // long contexts: this CU's part of its head's timesteps (TkAttPlan; part 0 = the attention CU, one part at <= 256
@@ -1705,7 +1709,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = a.o0 + lane;
             tk_publish(tk_g_xa<SH>(a) + r, e_o, xraw[r] + v);
         }
-        if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 2, lane);
+        if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 2, lane);
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
         if constexpr (SH::GCOOP) {
@@ -1750,7 +1754,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const float v0 = __shfl(hbv, 3 * lane, WAVE), v1 = __shfl(hbv, 3 * lane + 1, WAVE), v2 = __shfl(hbv, 3 * lane + 2, WAVE);
             if (lane < GPC_A) tk_publish3(tk_g_hb<SH>(a), c * GPC_A + lane, e_a, v0, 3 * lane + 1 < SH::R_A / 2 ? v1 : 0.f, 3 * lane + 2 < SH::R_A / 2 ? v2 : 0.f);
         }
-        if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
+        if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
         if constexpr (SH::GCOOP) {
             if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
@@ -1775,7 +1779,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = c * SH::R_D + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
-        if (GF && LLMK_TK_GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
+        if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
         TK_STAMP(15);
     }
 #undef TK_STAMP
@@ -1910,7 +1914,7 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
     if constexpr (LLMK_TK_GF && !SH::GCOOP && !CLS) {
         // LLMK_TK_GF: a first part of the burst now, the rest once the service wave's next sweep is in the pipeline ahead of it
         constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
-        if (LLMK_TK_GF_PUB && gflag) tk_flag_wait(gflag + 1, seq);
+        if (SH::GF_PUB && gflag) tk_flag_wait(gflag + 1, seq);
         tk_refill<SH, K0 + EARLY, NOW, CLS>(r, a, l, c, sw, lane);
         if (gflag) tk_flag_wait(gflag, seq);
         tk_refill<SH, K0 + EARLY + NOW, LATE - NOW, CLS>(r, a, l, c, sw, lane);
@@ -2115,7 +2119,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
             }
             if constexpr (LLMK_TK_GF && !SH::GCOOP) {
                 constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
-                if (LLMK_TK_GF_PUB) tk_flag_wait(gflag + 1, 4 * l + 1);
+                if (SH::GF_PUB) tk_flag_wait(gflag + 1, 4 * l + 1);
                 tk_refill<SH, SC::KQ + EARLY, NOW, false>(r, a, l, c, sw, lane);
                 tk_flag_wait(gflag, 4 * l + 1);
                 tk_refill<SH, SC::KQ + EARLY + NOW, LATE - NOW, false>(r, a, l, c, sw, lane);
