@@ -199,7 +199,10 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
                      // too small to give every CU at least two workgroups that way
             const int npairs = (EPI == EPI_SWIGLU) ? a.H : a.rows / 2;
             const size_t smem = 16 + (size_t)a.K * sizeof(float) + 8 * 16 + (size_t)(a.K / 32) * sizeof(float);   // x (pitch nblk+1) + block sums
-            const int want = 2 * n_cu;
+            // workgroups wanted before a wave takes more pairs: two per CU -- one and a half where x is 32 KB or more (K >= 8192: every
+            // workgroup stages the whole x; the 70B rank's w1|w3, 3,584 pairs: 896 workgroups of one pair per wave 12.2 us, 448 of
+            // two 10.9 us, 224 of four 14.8 us; LLMK_Q4_NP sweep, profiles/r04_tp70_rank_kernels_pairs_per_wave.txt)
+            const int want = a.K >= 8192 ? 3 * n_cu / 2 : 2 * n_cu;
 #define Q4_LAUNCH(NP_, KS_)                                                                                      \
             do {                                                                                                 \
                 const int blocks = (npairs + (GEMV_WAVES / KS_) * NP_ - 1) / ((GEMV_WAVES / KS_) * NP_);         \
@@ -214,13 +217,16 @@ hipError_t launch_gemv_t(int wt, hipStream_t st, const GemvArgs& a, int n_cu) {
             // 9.3 -> 12.0 us the OTHER way: four times the blocks each stage the whole x)
             const bool wide = (a.K % 8192) == 0 && ks_env != 0 && (npairs / GEMV_WAVES < n_cu || ks_env > 0);
             static const int np_env = getenv("LLMK_Q4_NP") ? atoi(getenv("LLMK_Q4_NP")) : 0;       // measurement aid: pairs per wave, forced
-            if (np_env > 0 && !wide) {
+            if (np_env > 0 && !wide) {          // (in the column-sliced launches below too)
                 if (np_env >= 4) Q4_LAUNCH(4, 1);
                 else if (np_env >= 2) Q4_LAUNCH(2, 1);
                 else Q4_LAUNCH(1, 1);
             }
             else if (wide) {
-                if (npairs / 4 >= want) Q4_LAUNCH(4, 4);
+                if (np_env >= 4) Q4_LAUNCH(4, 4);
+                else if (np_env >= 2) Q4_LAUNCH(2, 4);
+                else if (np_env == 1) Q4_LAUNCH(1, 4);
+                else if (npairs / 4 >= want) Q4_LAUNCH(4, 4);
                 else if (npairs / 2 >= want) Q4_LAUNCH(2, 4);
                 else Q4_LAUNCH(1, 4);
             }
