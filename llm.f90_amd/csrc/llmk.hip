@@ -1191,6 +1191,15 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
             if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
         }
         if (rc != LLMK_OK || !verify) break;
+#ifdef LLMK_TK_DEBUG
+        {   // test aid of the debug library (tests/test_upload_verify_gpu.py): damage the first block the process uploads on its first
+            // LLMK_UPLOAD_INJECT attempts -- what the verification below exists to catch
+            static const int inject = getenv("LLMK_UPLOAD_INJECT") ? atoi(getenv("LLMK_UPLOAD_INJECT")) : 0;
+            static bool first_block = true;
+            if (first_block && attempt <= inject) (void)hipMemsetAsync(dst0, 0xA5, 64, 0);
+            if (attempt >= inject) first_block = false;
+        }
+#endif
         // the tensor's rows as they now are: a q4_0 row's 16-bit words are its blocks' words in another order (8 nibble words and
         // the scale per block, zero padding behind), so the sum of the re-packed image equals the sum of the bytes handed over
         unsigned long long got = 0;
