@@ -964,11 +964,58 @@ __device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const 
           [b2] "v"(xh.z), [b3] "v"(xh.w));
 #endif
 }
+// The FIRST dword of a block: the same operations with the constant 0 as the first addend of both chains instead of zeroed
+// registers (fma(a, b, 0) is the same number): two v_mov fewer per block, 16 per tile of the ~520 VALU operations that bound a
+// q4_0 phase.  LLMK_Q4_MIX only (the conversion recipe keeps its zeroed accumulators).
+__device__ __forceinline__ void tk_q4_dword_first(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
+#if LLMK_Q4_MIX
+    unsigned l0, h0, l1, h1, s;
+    asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
+        "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
+        "v_lshrrev_b32 %[s], 8, %[q]\n\t"
+        "v_and_b32 %[l1], 0x000f000f, %[s]\n\t"
+        "v_fma_mix_f32 %[lo], %[l0], %[a0], 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h0], %[b0], 0 op_sel_hi:[1,0,0]\n\t"
+        "v_and_b32 %[h1], 0x00f000f0, %[s]\n\t"
+        "v_fma_mix_f32 %[lo], %[l1], %[a1], %[lo] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h1], %[b1], %[hi] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[lo], %[l0], %[a2], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h0], %[b2], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[lo], %[l1], %[a3], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %[hi], %[h1], %[b3], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
+        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
+          [b2] "v"(xh.z), [b3] "v"(xh.w));
+#else
+    lo = 0.f; hi16 = 0.f;
+    tk_q4_dword(q, xl, xh, lo, hi16);
+#endif
+}
 // one block's contribution d * (sum n x - 8 sum x) from the two chains of tk_q4_dword (tl, th) and xs8 = 8 sum x
 __device__ __forceinline__ float tk_q4_block(float tl, float th, float d, float xs8, float acc) {
     const float t = fmaf(th, 0.0625f, tl);
     if constexpr (LLMK_Q4_MIX) return fmaf(d, fmaf(t, TK_Q4_RESCALE, -xs8), acc);   // t * 2^24 is exact: == d * (t_old - xs8) + acc
     else return fmaf(d, t - xs8, acc);
+}
+
+// a value per lane that belongs to tile row (lane & 3): the sum over the sixteen lanes that share lane & 3, written by lanes 12..15
+__device__ __forceinline__ void tk_rows4_finish(float acc, const TkTile& t, float* part, int lane) {
+    acc += dpp_mov<0x114, 0xf, true>(0.f, acc);       // row_shr:4
+    acc += dpp_mov<0x118, 0xf, true>(0.f, acc);       // row_shr:8: lanes 12..15 of every DPP row hold the row's four sums
+    acc += __shfl_xor(acc, 16, WAVE);
+    acc += __shfl_xor(acc, 32, WAVE);
+    if ((lane & ~3) == 12) part[t.pidx + (lane & 3) * t.pstep] = acc;
+}
+// FOUR per-lane partial sums (one per tile row) -> the four wave sums, in 5 selects + 5 DPP additions + the tail above instead
+// of four 64-lane reductions (24 DPP additions, 4 readlanes, 4 stores by lane 0): after two exchange steps inside each quad,
+// lane l holds the quad's sum of row l & 3 -- a transposition by halves, every addend still counted exactly once.
+// (round 4, end: the q4_0 phases are VALU-bound, ~520 operations per tile; this and tk_q4_dword_first remove ~36 of them.)
+__device__ __forceinline__ void tk_rows4_reduce(const float (&v)[4], const TkTile& t, float* part, int lane) {
+    const bool p = (lane & 1) != 0, q = (lane & 2) != 0;
+    const float s01 = (p ? v[1] : v[0]) + dpp_mov<0xB1, 0xf, true>(0.f, p ? v[0] : v[1]);      // quad_perm:[1,0,3,2]
+    const float s23 = (p ? v[3] : v[2]) + dpp_mov<0xB1, 0xf, true>(0.f, p ? v[2] : v[3]);
+    const float r = (q ? s23 : s01) + dpp_mov<0x4E, 0xf, true>(0.f, q ? s01 : s23);            // quad_perm:[2,3,0,1]
+    tk_rows4_finish(r, t, part, lane);
 }
 
 // Q4M: loads G0 .. G0+N-1 of a tile against the image: acc += d (2^24 s - 8 sum x) per block, for the row lane & 3
@@ -999,15 +1046,8 @@ __device__ __forceinline__ float tk_dot_m(const TkSlot<SH>& e, const TkX<SH>& x,
     }
     return acc;
 }
-// the sixteen lanes that share lane & 3 -> the row's sum (valid in lanes 12..15 of every DPP row), written by lanes 12..15
 template <class SH>
-__device__ __forceinline__ void tk_finish_m(float acc, const TkTile& t, float* part, int lane) {
-    acc += dpp_mov<0x114, 0xf, true>(0.f, acc);       // row_shr:4
-    acc += dpp_mov<0x118, 0xf, true>(0.f, acc);       // row_shr:8
-    acc += __shfl_xor(acc, 16, WAVE);
-    acc += __shfl_xor(acc, 32, WAVE);
-    if ((lane & ~3) == 12) part[t.pidx + (lane & 3) * t.pstep] = acc;
-}
+__device__ __forceinline__ void tk_finish_m(float acc, const TkTile& t, float* part, int lane) { tk_rows4_finish(acc, t, part, lane); }
 
 template <class SH>
 __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, float (&out)[SH::RPT]) {
@@ -1023,9 +1063,10 @@ __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, fl
             for (int jj = 0; jj < SH::LPT; ++jj) {
                 const float4& w = b[s * SH::LPT + jj];
                 const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-                float tl = 0.f, th = 0.f;
+                float tl, th;
+                tk_q4_dword_first(q[0], x.v[jj * 8], x.v[jj * 8 + 4], tl, th);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
+                for (int i = 1; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
                 const unsigned short hs = e.sc[s * SH::LPT + jj];
                 const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
                 acc = tk_q4_block(tl, th, d, x.xs8[jj], acc);
@@ -1102,20 +1143,17 @@ __device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const Tk
         for (int s = 0; s < SH::RPT; ++s) {
             const float4& w = e.b[s * SH::LPT + jj];
             const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-            float tl = 0.f, th = 0.f;
+            float tl, th;
+            tk_q4_dword_first(q[0], xv[0], xv[4], tl, th);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], xv[i], xv[4 + i], tl, th);
+            for (int i = 1; i < 4; ++i) tk_q4_dword(q[i], xv[i], xv[4 + i], tl, th);
             const unsigned short hs = e.sc[s * SH::LPT + jj];
             acc[s] = tk_q4_block(tl, th, __half2float(*reinterpret_cast<const __half*>(&hs)), xs8, acc[s]);
         }
         __builtin_amdgcn_sched_barrier(0);                   // (the second segment's x is read after the first's dots: 32 registers)
     }
-#pragma unroll
-    for (int s = 0; s < SH::RPT; ++s) acc[s] = wave_sum(acc[s]);
-    if (lane == 0) {
-#pragma unroll
-        for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = acc[s];
-    }
+    static_assert(SH::RPT == 4, "four rows per q4_0 tile");
+    tk_rows4_reduce(acc, t, part, lane);
     }
 }
 
@@ -1975,9 +2013,10 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
         for (int jj = 0; jj < 2; ++jj) {
             const float4& w = e.b[s_ * 2 + jj];
             const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-            float tl = 0.f, th = 0.f;
+            float tl, th;
+            tk_q4_dword_first(q[0], x.v[jj * 8], x.v[jj * 8 + 4], tl, th);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
+            for (int i = 1; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
             const unsigned short hs = e.sc[s_ * 2 + jj];
             const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
             acc = tk_q4_block(tl, th, d, x.xs8[jj], acc);
@@ -2015,15 +2054,7 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (!PAD) {
-#pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) v[s_] = wave_sum(v[s_]);
-        const TkTile& t = r.t[R];
-        if (lane == 0) {
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) part[t.pidx + s_ * t.pstep] = v[s_];
-        }
-    }
+    if constexpr (!PAD) tk_rows4_reduce(v, r.t[R], part, lane);
     }
     r.t[RN] = tn;
 }

@@ -16,6 +16,7 @@
 #   prof TAG                 the evidence run: per single-GPU configuration of BASELINE.json a bench line, the pipelined-greedy
 #                            line, rocprofv3 --kernel-trace --stats and a FETCH_SIZE pass (separate runs); the 70B rank's
 #                            kernels; the prefill lines with their own stats + FETCH_SIZE; the KV-length curve
+#   profcfg TAG NAME [args]  the evidence of ONE configuration (bench line, greedy line, stats, FETCH_SIZE, its KV-length curve)
 #   pmc KIND                 SQ counter passes (q4 | prefill), own runs, no --stats
 #   trace [args]             tests/host_tools/tk_trace.py on the debug library (LLMK_TK_TRACE=1)
 #   rank                     tests/host_tools/tp_rank_time.py 4 8: the 70B rank's kernels one by one
@@ -59,17 +60,17 @@ fetch_of() {  # name, kernel-name filter, bench args...: FETCH_SIZE per launch (
   local cc; cc=$(find /tmp/pm_$name -name "*counter_collection.csv" | head -1)
   [ -n "$cc" ] && python $ROOT/profiles/summarize_pmc.py "$cc" FETCH_SIZE $filt | head -8 | tee $OUT/${name}_pmc_fetch_size.csv
 }
+run_cfg() {  # name, cpu-baseline flag, bench args...: bench line, pipelined-greedy line, rocprofv3 stats, FETCH_SIZE pass
+  local name=$1 cb=$2; shift 2
+  echo "=== $name: $*"
+  timeout 400 python bench.py "$@" $cb > $OUT/${name}_bench.json 2> $OUT/${name}_bench.err; cut -c1-600 $OUT/${name}_bench.json
+  timeout 300 python bench.py "$@" --no-cpu-baseline --greedy-on-device > $OUT/${name}_bench_greedy_pipeline.json 2>> $OUT/${name}_bench.err
+  cut -c1-300 $OUT/${name}_bench_greedy_pipeline.json
+  stats_of $name "$@" --no-cpu-baseline --no-graph
+  fetch_of $name "" "$@" --no-cpu-baseline --steps 20 --warmup 4 --repeats 1
+}
 job_prof() {
   local cfg name
-  run_cfg() {  # name, cpu-baseline flag, bench args...
-    local name=$1 cb=$2; shift 2
-    echo "=== $name: $*"
-    timeout 400 python bench.py "$@" $cb > $OUT/${name}_bench.json 2> $OUT/${name}_bench.err; cut -c1-600 $OUT/${name}_bench.json
-    timeout 300 python bench.py "$@" --no-cpu-baseline --greedy-on-device > $OUT/${name}_bench_greedy_pipeline.json 2>> $OUT/${name}_bench.err
-    cut -c1-300 $OUT/${name}_bench_greedy_pipeline.json
-    stats_of $name "$@" --no-cpu-baseline --no-graph
-    fetch_of $name "" "$@" --no-cpu-baseline --steps 20 --warmup 4 --repeats 1
-  }
   run_cfg tinyllama_f32 ""
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/tinyllama_f32_bench_driver_workload.json 2>/dev/null; cut -c1-400 $OUT/tinyllama_f32_bench_driver_workload.json
   run_cfg tinyllama_f16 --no-cpu-baseline --type f16
@@ -164,6 +165,7 @@ while [ $# -gt 0 ]; do
     bench)  name=${args[0]}; timeout 600 python bench.py "${args[@]:1}" > $OUT/$name.json 2> $OUT/$name.err; cut -c1-1200 $OUT/$name.json ;;
     ab)     job_ab "${args[@]}" ;;
     prof)   OUT=$ROOT/gpurun_out/prof_${args[0]:-r04}; mkdir -p $OUT; job_prof ;;
+    profcfg) OUT=$ROOT/gpurun_out/prof_${args[0]}; mkdir -p $OUT; run_cfg "${args[1]}" --no-cpu-baseline "${args[@]:2}"; timeout 300 python tests/host_tools/tk_curve.py $(case "${args[1]}" in *f16*) echo --type f16;; *7b*) echo --shape llama2-7b;; esac) 1 256 512 1024 2048 2>&1 | tail -1 | tee $OUT/kv_length_curve_${args[1]}.txt ;;
     pmc)    job_pmc "${args[0]:-q4}" ;;
     trace)  LLMK_LIB=$DBG LLMK_TK_TRACE=1 timeout 300 python tests/host_tools/tk_trace.py "${args[@]}" 2>&1 | cut -c1-400 | tee $OUT/trace_$(echo "${args[*]}" | tr -c 'a-zA-Z0-9\n' _).txt | tail -70 ;;
     rank)   job_rank ;;
