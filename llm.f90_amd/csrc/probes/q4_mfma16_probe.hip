@@ -1,0 +1,360 @@
+// Hardware probe (not product code): the q4_0 dots of a 16-row tile on v_mfma_f32_16x16x32_f16 in a form whose VALU work is
+// ~5.75 operations per matrix instruction (64 dwords of nibbles) instead of the 13 per 64 dwords of the token kernel's recipe --
+// the form DESIGN.md section 8 leaves open after round 4's 4x4x4 attempt (csrc/q4_mfma.h: parity-green, 4 % slower).
+//
+//   * A = weights: lane (row m = lane % 16, k group g = lane / 16) holds dword g of (row m, block b): one q4_0 block IS the
+//     instruction's K = 32.  q & 0x000f000f, q & 0x00f000f0 and the same two masks on q >> 8 are the four operand registers as
+//     they are (a nibble at bits 0-3 of a half is the f16 subnormal n 2^-24, at bits 4-7 it is 16 n 2^-24): 5 VALU operations.
+//   * B = x: the block's 32 activations in the order the masks deliver the nibbles (high-nibble elements pre-divided by 16), as
+//     TWO f16 pieces hi + lo (exact products).  Block b = 8 c + t of a group of eight puts its pieces into COLUMNS 2 t and 2 t + 1
+//     and zeros into the other fourteen (a lane reads the image if lane % 16 / 2 == t and a zero line otherwise: eight
+//     loop-invariant addresses per lane, the block's position is the ds_read's immediate offset) -- so the EIGHT blocks of a group
+//     accumulate into ONE set of four accumulators, each in its own two columns.
+//   * the block scales reach the accumulator layout through the matrix core too: the group's 16 x 8 scales (the A operand of
+//     a second instruction: a lane's 16 bytes of its row's scale plane, the other k groups zeroed) times a constant selector
+//     SEL[k][n] = (k % 8 == n / 2) put d[row][8 c + n / 2] into column n -- exactly where that block's sums are.  ONE instruction
+//     and four v_fma_f32 per EIGHT blocks apply the scales.
+//   * -8 d sum(x): the scale plane (unmasked) times the blocks' sums of x (hi / lo pieces in columns 0 / 1): one instruction per
+//     32 blocks.
+// Per group of 8 blocks: 8 x 5 (masks) + 4 (scales) + 2 (zeroing k groups, amortised) = 46 VALU operations and 9 matrix
+// instructions (16 clocks each) for 128 (row, block) pairs; the VALU recipe spends 14 operations per 16 pairs = 112.
+// The probe checks the layout and the numerics against a double-precision dot on the host (all 16 rows, K = 4096) and times one
+// slot of 16 rows x 32 blocks (512 pairs: the work of the token kernel's 4-row x 128-block tile) held in registers, 8 waves per CU
+// on 256 workgroups, beside today's recipe on the same amount of work.
+//   hipcc --offload-arch=gfx950 -O3 q4_mfma16_probe.hip -o q4_mfma16_probe && ./q4_mfma16_probe
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../kernels.h"
+
+using namespace llmk;
+
+constexpr int K = 4096, NBLK = K / 32, ROWS = 16, NSLOT = NBLK / 32;
+constexpr int RB = K / 2 + NBLK * 2;              // reference layout of a row (today's device row): nibble plane, then the f16 scales
+constexpr int ITERS = 400;
+constexpr int IMG = NBLK * 128;                   // x image: [block][piece 2][k group 4][8 halves]
+constexpr int XSI = NSLOT * 128;                  // sums image: [slot][piece 2][32 blocks] halves
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ v8h as_v8h(const v4u& u) { return __builtin_bit_cast(v8h, u); }
+// the four operand registers of one dword of nibbles (5 VALU operations)
+__device__ __forceinline__ v8h unpack(unsigned q) {
+    const unsigned s = q >> 8;
+    const v4u u = {q & 0x000f000fu, q & 0x00f000f0u, s & 0x000f000fu, s & 0x00f000f0u};
+    return as_v8h(u);
+}
+__device__ __forceinline__ v4u lds_read16(const char* p) { return *reinterpret_cast<const v4u*>(p); }
+
+// LDS of one workgroup: x image | a zero area as large (every "other column" read lands there at the same immediate offset) | sums image | zeros
+struct Lds { char img[IMG]; char zero[IMG]; char xs[XSI]; char zx[XSI]; };
+
+// builds the images from x (f32, K values): called by all threads of the workgroup
+__device__ void build_images(Lds& L, const float* __restrict__ x, int tid, int nthreads) {
+    for (int i = tid; i < IMG / 4; i += nthreads) { reinterpret_cast<unsigned*>(L.zero)[i] = 0u; }
+    for (int i = tid; i < XSI / 4; i += nthreads) { reinterpret_cast<unsigned*>(L.zx)[i] = 0u; }
+    for (int idx = tid; idx < NBLK * 4; idx += nthreads) {       // (block, k group)
+        const int b = idx >> 2, g = idx & 3;
+        const float* xb = x + 32 * b;
+        const float e[8] = {xb[4 * g], xb[4 * g + 2], xb[16 + 4 * g] * 0.0625f, xb[16 + 4 * g + 2] * 0.0625f,
+                            xb[4 * g + 1], xb[4 * g + 3], xb[16 + 4 * g + 1] * 0.0625f, xb[16 + 4 * g + 3] * 0.0625f};
+        _Float16* hi = reinterpret_cast<_Float16*>(L.img + b * 128 + g * 16);
+        _Float16* lo = reinterpret_cast<_Float16*>(L.img + b * 128 + 64 + g * 16);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const _Float16 h = (_Float16)e[i]; hi[i] = h; lo[i] = (_Float16)(e[i] - (float)h); }
+    }
+    for (int b = tid; b < NBLK; b += nthreads) {
+        float s = 0.f;
+        for (int i = 0; i < 32; ++i) s += x[32 * b + i];
+        const _Float16 h = (_Float16)s;
+        const int slot = b >> 5, k = b & 31;
+        reinterpret_cast<_Float16*>(L.xs + slot * 128)[k] = h;
+        reinterpret_cast<_Float16*>(L.xs + slot * 128 + 64)[k] = (_Float16)(s - (float)h);
+    }
+}
+
+struct Lane {            // loop-invariant per-lane state
+    const char* xa[8];   // B operand of a block with t = 0..7: image address (block 0 of the group) or the zero area
+    const char* sa;      // B operand of the -8 sum(x) instruction
+    v8h sel;             // SEL[k][n] = (k % 8 == n / 2)
+};
+__device__ __forceinline__ void lane_init(Lane& ln, const Lds& L, int lane) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ln.xa[t] = (n >> 1) == t ? L.img + t * 128 + (n & 1) * 64 + g * 16 : L.zero;
+    ln.sa = n < 2 ? L.xs + n * 64 + g * 16 : L.zx;
+    v4u s = {0u, 0u, 0u, 0u};
+    const unsigned one = (n & 2) ? 0x3C000000u : 0x00003C00u;       // half (n / 2) % 2 of register (n / 2) / 2
+    if ((n >> 2) == 0) s.x = one; else if ((n >> 2) == 1) s.y = one; else if ((n >> 2) == 2) s.z = one; else s.w = one;
+    ln.sel = as_v8h(s);
+}
+
+// One slot: 16 rows x 32 blocks.  w[j] = the lane's dwords of blocks 4 j .. 4 j + 3 (k group g of row m), sc = the lane's 16 bytes of
+// its row's scale plane (blocks 8 g .. 8 g + 7 of the slot).  acc (lane (n, g), register j) += d[4 g + j][b] * 2^-24 sum n x of the
+// block b = 8 c + n / 2 whose piece n % 2 sits in column n; acc8 += the scale plane times the sums of x.
+template <int SLOT, int PIPE = 0>
+__device__ __forceinline__ void slot_dot(const v4u (&w)[8], const v4u& sc, const Lane& ln, int lane, v4f& acc, v4f& acc8) {
+    const int g = lane >> 4;
+    const v4f z = {0.f, 0.f, 0.f, 0.f};
+    const v4u zu = {0u, 0u, 0u, 0u};
+    acc8 = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8h(sc), as_v8h(lds_read16(ln.sa + SLOT * 128)), acc8, 0, 0, 0);
+    if constexpr (PIPE == 0) {          // left to the compiler: it interleaves the four groups and reads each operand one instruction ahead
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const v4u scv = g == c ? sc : zu;                                      // the group's eight scales, the other k groups zeroed
+            const v4f d = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8h(scv), ln.sel, z, 0, 0, 0);   // d[4 g + j][8 c + n / 2] in column n
+            v4f s = z;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int j = 2 * c + (t >> 2);
+                const unsigned q = (t & 3) == 0 ? w[j].x : (t & 3) == 1 ? w[j].y : (t & 3) == 2 ? w[j].z : w[j].w;
+                const v8h b = as_v8h(lds_read16(ln.xa[t] + (SLOT * 32 + c * 8) * 128));
+                s = __builtin_amdgcn_mfma_f32_16x16x32_f16(unpack(q), b, s, 0, 0, 0);
+            }
+            acc.x = fmaf(d.x, s.x, acc.x); acc.y = fmaf(d.y, s.y, acc.y); acc.z = fmaf(d.z, s.z, acc.z); acc.w = fmaf(d.w, s.w, acc.w);
+        }
+    } else {                            // the B operands of group c + 1 (8 reads, 32 registers) are requested before group c is multiplied
+        v4u bx[2][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bx[0][t] = lds_read16(ln.xa[t] + (SLOT * 32) * 128);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < 3) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) bx[(c + 1) & 1][t] = lds_read16(ln.xa[t] + (SLOT * 32 + (c + 1) * 8) * 128);
+            }
+            if constexpr (PIPE == 1 || PIPE == 3) __builtin_amdgcn_sched_barrier(0);
+            const v4u scv = g == c ? sc : zu;
+            const v4f d = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_v8h(scv), ln.sel, z, 0, 0, 0);
+            // two accumulator sets (even / odd blocks): consecutive instructions do not wait for each other
+            if constexpr (PIPE == 3) {      // ONE accumulator set per group: each instruction waits for the one before it (the partner wave fills in)
+                v4f s = z;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int j = 2 * c + (t >> 2);
+                    const unsigned q = (t & 3) == 0 ? w[j].x : (t & 3) == 1 ? w[j].y : (t & 3) == 2 ? w[j].z : w[j].w;
+                    s = __builtin_amdgcn_mfma_f32_16x16x32_f16(unpack(q), as_v8h(bx[c & 1][t]), s, 0, 0, 0);
+                }
+                acc.x = fmaf(d.x, s.x, acc.x); acc.y = fmaf(d.y, s.y, acc.y); acc.z = fmaf(d.z, s.z, acc.z); acc.w = fmaf(d.w, s.w, acc.w);
+            } else {
+            v4f s0 = z, s1 = z;
+#pragma unroll
+            for (int t = 0; t < 8; t += 2) {
+                const int j = 2 * c + (t >> 2);
+                const unsigned q0 = (t & 3) == 0 ? w[j].x : w[j].z, q1 = (t & 3) == 0 ? w[j].y : w[j].w;
+                s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(unpack(q0), as_v8h(bx[c & 1][t]), s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(unpack(q1), as_v8h(bx[c & 1][t + 1]), s1, 0, 0, 0);
+            }
+            acc.x = fmaf(d.x, s0.x + s1.x, acc.x); acc.y = fmaf(d.y, s0.y + s1.y, acc.y);
+            acc.z = fmaf(d.z, s0.z + s1.z, acc.z); acc.w = fmaf(d.w, s0.w + s1.w, acc.w);
+            }
+            if constexpr (PIPE == 1 || PIPE == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+// the sixteen columns of a row added up (lanes n = 0 .. 15 of each 16-lane row): every lane of the row gets the sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1, 0xf, true>(0.f, v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf, true>(0.f, v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf, true>(0.f, v);     // row_half_mirror
+    v += dpp_mov<0x140, 0xf, true>(0.f, v);     // row_mirror
+    return v;
+}
+
+// device layouts of the probe (what an upload would re-pack to): W16[slot][j 8][lane 64] dwordx4, S16[slot][lane 64] 16 bytes
+__device__ __forceinline__ void load_slot(const char* W16, const char* S16, int slot, int lane, v4u (&w)[8], v4u& sc) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = reinterpret_cast<const v4u*>(W16)[(slot * 8 + j) * 64 + lane];
+    sc = reinterpret_cast<const v4u*>(S16)[slot * 64 + lane];
+}
+
+template <int PIPE>
+__global__ __launch_bounds__(64) void check_kernel(const char* W16, const char* S16, const float* x, float* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds& L = *reinterpret_cast<Lds*>(smem);
+    const int lane = threadIdx.x;
+    build_images(L, x, lane, 64);
+    __syncthreads();
+    Lane ln; lane_init(ln, L, lane);
+    v4f acc = {0.f, 0.f, 0.f, 0.f}, acc8 = acc;
+    v4u w[8], sc;
+    load_slot(W16, S16, 0, lane, w, sc); slot_dot<0, PIPE>(w, sc, ln, lane, acc, acc8);
+    load_slot(W16, S16, 1, lane, w, sc); slot_dot<1, PIPE>(w, sc, ln, lane, acc, acc8);
+    load_slot(W16, S16, 2, lane, w, sc); slot_dot<2, PIPE>(w, sc, ln, lane, acc, acc8);
+    load_slot(W16, S16, 3, lane, w, sc); slot_dot<3, PIPE>(w, sc, ln, lane, acc, acc8);
+    const float a[4] = {acc.x, acc.y, acc.z, acc.w}, a8[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float y = row16_sum(a[j]) * 16777216.0f - 8.0f * row16_sum(a8[j]);
+        if ((lane & 15) == 0) out[4 * (lane >> 4) + j] = y;
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(512) void time_kernel(const char* W16, const char* S16, const char* Wref, const float* x, float* out, unsigned long long* cyc) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds& L = *reinterpret_cast<Lds*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    build_images(L, x, tid, 512);
+    __syncthreads();
+    float r = 0.f;
+    unsigned long long t0, t1;
+    if constexpr (V >= 1) {
+        Lane ln; lane_init(ln, L, lane);
+        v4u w[8], sc;
+        load_slot(W16, S16, 0, lane, w, sc);
+        v4f acc = {0.f, 0.f, 0.f, 0.f}, acc8 = acc;
+        t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(w[j].x), "+v"(w[j].y), "+v"(w[j].z), "+v"(w[j].w));
+            asm volatile("" : "+v"(sc.x), "+v"(sc.y), "+v"(sc.z), "+v"(sc.w) :: "memory");   // (memory: the image is read again every round)
+            slot_dot<0, V - 1>(w, sc, ln, lane, acc, acc8);
+        }
+        t1 = __builtin_readcyclecounter();
+        r = (acc.x + acc.y) + (acc.z + acc.w) + (acc8.x + acc8.y) + (acc8.z + acc8.w);
+    } else {
+        // today's recipe on the same 512 (row, block) pairs: 4 rows x 128 blocks, lane = blocks lane and lane + 64 of every row
+        uint4 q[8];
+        __half d[8];
+        float4 xv[16];
+        float x8[2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const char* row = Wref + (size_t)s * RB;
+                q[s * 2 + jj] = reinterpret_cast<const uint4*>(row)[jj * 64 + lane];
+                d[s * 2 + jj] = reinterpret_cast<const __half*>(row + K / 2)[jj * 64 + lane];
+            }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                xv[jj * 8 + m] = *reinterpret_cast<const float4*>(x + 32 * (jj * 64 + lane) + 4 * m);
+                s += xv[jj * 8 + m].x + xv[jj * 8 + m].y + xv[jj * 8 + m].z + xv[jj * 8 + m].w;
+            }
+            x8[jj] = 8.f * s;
+        }
+        t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) asm volatile("" : "+v"(q[g].x), "+v"(q[g].y), "+v"(q[g].z), "+v"(q[g].w));
+            float v[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float acc = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const unsigned w[4] = {q[s * 2 + jj].x, q[s * 2 + jj].y, q[s * 2 + jj].z, q[s * 2 + jj].w};
+                    float tl = 0.f, th = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q4_dword_dot(w[i], xv[jj * 8 + i], xv[jj * 8 + 4 + i], tl, th);
+                    acc = fmaf(__half2float(d[s * 2 + jj]), q4_block_fold(tl, th) - x8[jj], acc);
+                }
+                v[s] = wave_sum(acc);
+            }
+            r += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        t1 = __builtin_readcyclecounter();
+    }
+    if (lane == 0) cyc[blockIdx.x * 8 + (tid >> 6)] = t1 - t0;
+    if (r == 12345.678f) out[0] = r;
+}
+
+int main() {
+    srand(20260930);
+    std::vector<unsigned char> W((size_t)ROWS * RB);
+    std::vector<float> x(K);
+    std::vector<double> ref(ROWS, 0.0);
+    for (int i = 0; i < K; ++i) {
+        const float u = (float)(rand() & 0xffffff) / 16777216.f * 2.f - 1.f;
+        x[i] = u * expf(((float)(rand() & 0xffffff) / 16777216.f * 14.f) - 9.f);       // magnitudes from 1e-4 to 150
+    }
+    for (int r = 0; r < ROWS; ++r) {
+        unsigned char* row = W.data() + (size_t)r * RB;
+        for (int i = 0; i < K / 2; ++i) row[i] = (unsigned char)(rand() & 0xff);
+        for (int b = 0; b < NBLK; ++b) {
+            const __half d = __float2half(((float)(rand() & 0xffffff) / 16777216.f - 0.5f) * 0.05f);
+            reinterpret_cast<__half*>(row + K / 2)[b] = d;
+            double s = 0.0;
+            for (int i = 0; i < 16; ++i) {
+                s += ((row[b * 16 + i] & 15) - 8) * (double)x[32 * b + i];
+                s += ((row[b * 16 + i] >> 4) - 8) * (double)x[32 * b + 16 + i];
+            }
+            ref[r] += (double)__half2float(d) * s;
+        }
+    }
+    // the probe's device layouts
+    std::vector<unsigned> W16((size_t)NSLOT * 8 * 64 * 4);
+    std::vector<unsigned short> S16((size_t)NSLOT * 64 * 8);
+    for (int s = 0; s < NSLOT; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, g = lane >> 4;
+            const unsigned char* row = W.data() + (size_t)m * RB;
+            for (int j = 0; j < 8; ++j)
+                for (int i = 0; i < 4; ++i) {
+                    const int b = 32 * s + 4 * j + i;
+                    unsigned q; memcpy(&q, row + b * 16 + 4 * g, 4);
+                    W16[(((size_t)s * 8 + j) * 64 + lane) * 4 + i] = q;
+                }
+            for (int i = 0; i < 8; ++i) S16[((size_t)s * 64 + lane) * 8 + i] = reinterpret_cast<const unsigned short*>(row + K / 2)[32 * s + 8 * g + i];
+        }
+    char *dW16, *dS16, *dW; float *dx, *dout; unsigned long long* dc;
+    CK(hipMalloc(&dW16, W16.size() * 4)); CK(hipMalloc(&dS16, S16.size() * 2)); CK(hipMalloc(&dW, W.size()));
+    CK(hipMalloc(&dx, K * 4)); CK(hipMalloc(&dout, 256)); CK(hipMalloc(&dc, 256 * 8 * 8));
+    CK(hipMemcpy(dW16, W16.data(), W16.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dS16, S16.data(), S16.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, W.data(), W.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx, x.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute((const void*)check_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)check_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)time_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)time_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)time_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)time_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)time_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    double norm = 0.0;
+    for (int r = 0; r < ROWS; ++r) norm = fmax(norm, fabs(ref[r]));
+    for (int pipe = 0; pipe < 2; ++pipe) {
+        float out[ROWS];
+        if (pipe == 0) hipLaunchKernelGGL(check_kernel<0>, dim3(1), dim3(64), sizeof(Lds), 0, dW16, dS16, dx, dout);
+        else hipLaunchKernelGGL(check_kernel<1>, dim3(1), dim3(64), sizeof(Lds), 0, dW16, dS16, dx, dout);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(out, dout, sizeof(out), hipMemcpyDeviceToHost));
+        double worst = 0.0;
+        for (int r = 0; r < ROWS; ++r) worst = fmax(worst, fabs(out[r] - ref[r]) / norm);
+        printf("{\"probe\": \"q4_mfma16\", \"check\": \"16 rows x 4096, %s\", \"rows\": [", pipe ? "operands read ahead" : "compiler's order");
+        for (int r = 0; r < ROWS; ++r) printf("%s%.9g", r ? ", " : "", out[r]);
+        printf("], \"ref\": [");
+        for (int r = 0; r < ROWS; ++r) printf("%s%.9g", r ? ", " : "", ref[r]);
+        printf("], \"max_rel_err\": %.3e}\n", worst);
+    }
+    for (int v = 0; v < 5; ++v) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (v == 0) hipLaunchKernelGGL(time_kernel<0>, dim3(256), dim3(512), sizeof(Lds), 0, dW16, dS16, dW, dx, dout, dc);
+            else if (v == 1) hipLaunchKernelGGL(time_kernel<1>, dim3(256), dim3(512), sizeof(Lds), 0, dW16, dS16, dW, dx, dout, dc);
+            else if (v == 2) hipLaunchKernelGGL(time_kernel<2>, dim3(256), dim3(512), sizeof(Lds), 0, dW16, dS16, dW, dx, dout, dc);
+            else if (v == 3) hipLaunchKernelGGL(time_kernel<3>, dim3(256), dim3(512), sizeof(Lds), 0, dW16, dS16, dW, dx, dout, dc);
+            else hipLaunchKernelGGL(time_kernel<4>, dim3(256), dim3(512), sizeof(Lds), 0, dW16, dS16, dW, dx, dout, dc);
+            CK(hipDeviceSynchronize());
+        }
+        std::vector<unsigned long long> c(256 * 8);
+        CK(hipMemcpy(c.data(), dc, c.size() * 8, hipMemcpyDeviceToHost));
+        double s = 0.0; unsigned long long mx = 0;
+        for (auto t : c) { s += (double)t; mx = t > mx ? t : mx; }
+        printf("{\"probe\": \"q4_mfma16\", \"variant\": \"%s\", \"cycles_per_512_row_block_pairs_per_wave_avg\": %.1f, \"max\": %.1f, \"counter\": \"s_memtime clocks, 8 waves per CU\"}\n",
+               v == 0 ? "valu fma_mix, x in registers (4 rows x 128 blocks)" : v == 1 ? "mfma 16x16x32 f16, 8 blocks per accumulator set (16 rows x 32 blocks), scheduling left to the compiler"
+               : v == 2 ? "mfma 16x16x32 f16, operands of the next group of 8 blocks read ahead, two accumulator sets, groups fenced" : v == 3 ? "mfma 16x16x32 f16, operands read a group ahead, two accumulator sets, not fenced" : "mfma 16x16x32 f16, operands read a group ahead, one accumulator set, groups fenced", s / c.size() / ITERS, (double)mx / ITERS);
+    }
+    return 0;
+}
