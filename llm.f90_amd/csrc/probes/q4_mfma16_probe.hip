@@ -22,6 +22,8 @@
 // slot of 16 rows x 32 blocks (512 pairs: the work of the token kernel's 4-row x 128-block tile) held in registers, 8 waves per CU
 // on 256 workgroups, beside today's recipe on the same amount of work.
 //   hipcc --offload-arch=gfx950 -O3 q4_mfma16_probe.hip -o q4_mfma16_probe && ./q4_mfma16_probe
+// `./q4_mfma16_probe phase`: the same two recipes on a whole dot phase streamed from HBM (Llama-2-7B's w1|w3, 50.7 MB per launch,
+// one workgroup of 8 waves per CU, every wave's three slots requested up front), results of all 22,016 rows compared -- see phase_main.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
@@ -271,7 +273,222 @@ __global__ __launch_bounds__(512) void time_kernel(const char* W16, const char* 
     if (r == 12345.678f) out[0] = r;
 }
 
-int main() {
+
+// ---- "phase" mode: a whole dot phase of the persistent kernel's shape, streamed from HBM ---------------------------------------
+// Llama-2-7B's w1|w3 (22,016 rows x 4096: 49.5 MB of nibbles and scales), one workgroup of 8 waves per CU, no inter-CU traffic:
+// every wave requests ALL its slots up front (three of 9 KB) and multiplies them in order, (a) 16 rows x 32 blocks per slot on the
+// matrix core as above, (b) 4 rows x 128 blocks per slot with today's recipe (x fragment in registers).  Successive launches read
+// different 50 MB regions (8 of them: nothing comes from the Infinity Cache).  Both write per-slot partial sums; the host adds
+// (a)'s four column parts and compares them with (b)'s rows.
+constexpr int PH_ROWS = 22016, PH_NW = 2048;          // waves per launch = 256 workgroups x 8
+constexpr int PH_SLOTS = PH_ROWS / 16 * NSLOT;        // (a): 5,504 slots of 16 rows x 32 blocks; (b): 5,504 tiles of 4 rows x 128 blocks
+constexpr int PH_PER = (PH_SLOTS + PH_NW - 1) / PH_NW;
+
+template <bool COMPUTE>
+__global__ __launch_bounds__(512) void phase_m16_kernel(const char* W16, const char* S16, const float* x, float* part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Lds& L = *reinterpret_cast<Lds*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, gw = blockIdx.x * 8 + (tid >> 6);
+    // x FIRST (vmcnt retires in order: requested behind the weights it would arrive behind all 27 KB of them): thread (block b, k
+    // group g) = tid takes its 8 activations, threads 0..127 the 32 of block tid for its sum
+    const int ib = tid >> 2, ig = tid & 3;
+    const float4 xlo4 = *reinterpret_cast<const float4*>(x + 32 * ib + 4 * ig), xhi4 = *reinterpret_cast<const float4*>(x + 32 * ib + 16 + 4 * ig);
+    float4 xs4[8];
+    if (tid < NBLK) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) xs4[m] = *reinterpret_cast<const float4*>(x + 32 * tid + 4 * m);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    v4u w[PH_PER][8], sc[PH_PER];
+#pragma unroll
+    for (int i = 0; i < PH_PER; ++i) {
+        const int slot = min(gw + i * PH_NW, PH_SLOTS - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[i][j] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(W16) + ((size_t)slot * 8 + j) * 64 + lane);
+        sc[i] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(S16) + (size_t)slot * 64 + lane);
+        __builtin_amdgcn_sched_barrier(0);             // slot by slot, in this order: vmcnt retires in order, the first dot waits for slot 0 only
+    }
+    {   // the image (the persistent kernel's gathers would write it)
+        for (int i = tid; i < IMG / 16; i += 512) reinterpret_cast<v4u*>(L.zero)[i] = v4u{0u, 0u, 0u, 0u};
+        if (tid < XSI / 16) reinterpret_cast<v4u*>(L.zx)[tid] = v4u{0u, 0u, 0u, 0u};
+        const float e[8] = {xlo4.x, xlo4.z, xhi4.x * 0.0625f, xhi4.z * 0.0625f, xlo4.y, xlo4.w, xhi4.y * 0.0625f, xhi4.w * 0.0625f};
+        v8h hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hi[i] = (_Float16)e[i]; lo[i] = (_Float16)(e[i] - (float)hi[i]); }
+        *reinterpret_cast<v8h*>(L.img + ib * 128 + ig * 16) = hi;
+        *reinterpret_cast<v8h*>(L.img + ib * 128 + 64 + ig * 16) = lo;
+        if (tid < NBLK) {
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) sum += (xs4[m].x + xs4[m].y) + (xs4[m].z + xs4[m].w);
+            const _Float16 h = (_Float16)sum;
+            reinterpret_cast<_Float16*>(L.xs + (tid >> 5) * 128)[tid & 31] = h;
+            reinterpret_cast<_Float16*>(L.xs + (tid >> 5) * 128 + 64)[tid & 31] = (_Float16)(sum - (float)h);
+        }
+    }
+    __syncthreads();
+    Lane ln; lane_init(ln, L, lane);
+    const int quarter = gw & 3;                        // slot % 4 = the column part: the same for all of a wave's slots (PH_NW % 4 == 0)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ln.xa[t] += quarter * 32 * 128;
+    ln.sa += quarter * 128;
+#pragma unroll
+    for (int i = 0; i < PH_PER; ++i) {
+        const int slot = gw + i * PH_NW;
+        v4f acc = {0.f, 0.f, 0.f, 0.f}, acc8 = acc;
+        if (COMPUTE) slot_dot<0, 3>(w[i], sc[i], ln, lane, acc, acc8);
+        else {   // every byte requested is used
+            unsigned f = sc[i].x ^ sc[i].y ^ sc[i].z ^ sc[i].w;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f ^= w[i][j].x ^ w[i][j].y ^ w[i][j].z ^ w[i][j].w;
+            acc.x = __uint_as_float(f & 0x3fffffffu);
+        }
+        const float a[4] = {acc.x, acc.y, acc.z, acc.w}, a8[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float y = row16_sum(a[j]) * 16777216.0f - 8.0f * row16_sum(a8[j]);
+            if ((lane & 15) == 0 && slot < PH_SLOTS) part[(size_t)slot * 16 + 4 * (lane >> 4) + j] = y;
+        }
+    }
+}
+template <bool COMPUTE>
+__global__ __launch_bounds__(512) void phase_valu_kernel(const char* Wref, const float* x, float* part) {
+    const int tid = threadIdx.x, lane = tid & 63, gw = blockIdx.x * 8 + (tid >> 6);
+    // (the x fragment FIRST: vmcnt retires in order)
+    float4 xv[16];
+    float x8[2];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) xv[m] = *reinterpret_cast<const float4*>(x + 32 * ((m >> 3) * 64 + lane) + 4 * (m & 7));
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 q[PH_PER][8];
+    __half d[PH_PER][8];
+#pragma unroll
+    for (int i = 0; i < PH_PER; ++i) {
+        const int tile = min(gw + i * PH_NW, PH_SLOTS - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const char* row = Wref + ((size_t)tile * 4 + s) * RB;
+                q[i][s * 2 + jj] = ldg_nt(reinterpret_cast<const uint4*>(row) + jj * 64 + lane);
+                d[i][s * 2 + jj] = reinterpret_cast<const __half*>(row + K / 2)[jj * 64 + lane];
+            }
+        __builtin_amdgcn_sched_barrier(0);             // tile by tile, in this order
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        float s = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) s += xv[jj * 8 + m].x + xv[jj * 8 + m].y + xv[jj * 8 + m].z + xv[jj * 8 + m].w;
+        x8[jj] = 8.f * s;
+    }
+#pragma unroll
+    for (int i = 0; i < PH_PER; ++i) {
+        const int tile = gw + i * PH_NW;
+        float v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float acc = 0.f;
+            if (COMPUTE) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const unsigned w[4] = {q[i][s * 2 + jj].x, q[i][s * 2 + jj].y, q[i][s * 2 + jj].z, q[i][s * 2 + jj].w};
+                    float tl = 0.f, th = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q4_dword_dot(w[k], xv[jj * 8 + k], xv[jj * 8 + 4 + k], tl, th);
+                    acc = fmaf(__half2float(d[i][s * 2 + jj]), q4_block_fold(tl, th) - x8[jj], acc);
+                }
+            } else {
+                unsigned f = 0;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) f ^= q[i][s * 2 + jj].x ^ q[i][s * 2 + jj].y ^ q[i][s * 2 + jj].z ^ q[i][s * 2 + jj].w;
+                acc = __uint_as_float(f & 0x3fffffffu) + __half2float(d[i][s * 2]) + __half2float(d[i][s * 2 + 1]);
+            }
+            v[s] = wave_sum(acc);
+        }
+        if (lane == 0 && tile < PH_SLOTS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) part[(size_t)tile * 4 + s] = v[s];
+        }
+    }
+}
+
+static int phase_main() {
+    srand(20260930);
+    const int NREG = 8;
+    std::vector<float> x(K);
+    for (int i = 0; i < K; ++i) {
+        const float u = (float)(rand() & 0xffffff) / 16777216.f * 2.f - 1.f;
+        x[i] = u * expf(((float)(rand() & 0xffffff) / 16777216.f * 6.f) - 4.f);
+    }
+    // logical weights in today's device row layout, and the same weights in the 16-row layout
+    std::vector<unsigned char> W((size_t)PH_ROWS * RB);
+    for (size_t i = 0; i < W.size(); i += 4) { const unsigned r = (unsigned)rand() * 2654435761u ^ (unsigned)rand(); memcpy(&W[i], &r, 4); }
+    for (int r = 0; r < PH_ROWS; ++r)
+        for (int b = 0; b < NBLK; ++b) reinterpret_cast<__half*>(W.data() + (size_t)r * RB + K / 2)[b] = __float2half(((float)(rand() & 0xffff) / 65536.f - 0.5f) * 0.05f);
+    std::vector<unsigned> W16((size_t)PH_SLOTS * 8 * 64 * 4);
+    std::vector<unsigned short> S16((size_t)PH_SLOTS * 64 * 8);
+    for (int slot = 0; slot < PH_SLOTS; ++slot) {
+        const int tile = slot / NSLOT, sq = slot % NSLOT;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int m = lane & 15, g = lane >> 4;
+            const unsigned char* row = W.data() + ((size_t)tile * 16 + m) * RB;
+            for (int j = 0; j < 8; ++j)
+                for (int i = 0; i < 4; ++i) { unsigned qv; memcpy(&qv, row + (32 * sq + 4 * j + i) * 16 + 4 * g, 4); W16[(((size_t)slot * 8 + j) * 64 + lane) * 4 + i] = qv; }
+            for (int i = 0; i < 8; ++i) S16[((size_t)slot * 64 + lane) * 8 + i] = reinterpret_cast<const unsigned short*>(row + K / 2)[32 * sq + 8 * g + i];
+        }
+    }
+    char *dW16, *dS16, *dW; float *dx, *dpa, *dpb;
+    CK(hipMalloc(&dW16, W16.size() * 4 * NREG)); CK(hipMalloc(&dS16, S16.size() * 2 * NREG)); CK(hipMalloc(&dW, W.size() * NREG));
+    CK(hipMalloc(&dx, K * 4)); CK(hipMalloc(&dpa, (size_t)PH_SLOTS * 16 * 4)); CK(hipMalloc(&dpb, (size_t)PH_SLOTS * 4 * 4));
+    for (int r = 0; r < NREG; ++r) {
+        CK(hipMemcpy(dW16 + W16.size() * 4 * r, W16.data(), W16.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dS16 + S16.size() * 2 * r, S16.data(), S16.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dW + W.size() * r, W.data(), W.size(), hipMemcpyHostToDevice));
+    }
+    CK(hipMemcpy(dx, x.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute((const void*)phase_m16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void*)phase_m16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int N = 40;
+    const double mb = (W16.size() * 4 + S16.size() * 2) / 1e6;
+    for (int v = 0; v < 4; ++v) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) CK(hipEventRecord(e0, 0));
+            for (int it = 0; it < (pass ? N : 4); ++it) {
+                const int r = it % NREG;
+                if (v == 0) hipLaunchKernelGGL(phase_valu_kernel<true>, dim3(256), dim3(512), 0, 0, dW + W.size() * r, dx, dpb);
+                else if (v == 1) hipLaunchKernelGGL(phase_m16_kernel<true>, dim3(256), dim3(512), sizeof(Lds), 0, dW16 + W16.size() * 4 * r, dS16 + S16.size() * 2 * r, dx, dpa);
+                else if (v == 2) hipLaunchKernelGGL(phase_valu_kernel<false>, dim3(256), dim3(512), 0, 0, dW + W.size() * r, dx, dpb);
+                else hipLaunchKernelGGL(phase_m16_kernel<false>, dim3(256), dim3(512), sizeof(Lds), 0, dW16 + W16.size() * 4 * r, dS16 + S16.size() * 2 * r, dx, dpa);
+            }
+            if (pass) { CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); }
+        }
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1000.0 / N;
+        printf("{\"probe\": \"q4_phase\", \"variant\": \"%s\", \"us_per_launch\": %.2f, \"MB\": %.1f, \"TBps_including_launch\": %.2f}\n",
+               v == 0 ? "valu fma_mix, 4 rows x 128 blocks per slot" : v == 1 ? "mfma 16x16x32 f16, 16 rows x 32 blocks per slot"
+               : v == 2 ? "valu layout, loads only (no dots)" : "mfma layout, loads + image only (no dots)", us, mb, mb / us);
+        if (v == 1) {   // compare (a)'s column parts with (b)'s rows
+            CK(hipDeviceSynchronize());
+            std::vector<float> pa((size_t)PH_SLOTS * 16), pb((size_t)PH_SLOTS * 4);
+            CK(hipMemcpy(pa.data(), dpa, pa.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(pb.data(), dpb, pb.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0.0, norm = 0.0;
+            for (int r = 0; r < PH_ROWS; ++r) norm = fmax(norm, fabs((double)pb[r]));
+            for (int r = 0; r < PH_ROWS; ++r) {
+                const int tile = r / 16, m = r % 16;
+                double y = 0.0;
+                for (int sq = 0; sq < NSLOT; ++sq) y += (double)pa[((size_t)tile * NSLOT + sq) * 16 + m];
+                worst = fmax(worst, fabs(y - (double)pb[r]) / norm);
+            }
+            printf("{\"probe\": \"q4_phase\", \"check\": \"22016 rows, matrix-core form against today's recipe\", \"max_rel_diff\": %.3e, \"norm\": %.4g}\n", worst, norm);
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "phase")) return phase_main();
     srand(20260930);
     std::vector<unsigned char> W((size_t)ROWS * RB);
     std::vector<float> x(K);
