@@ -403,11 +403,7 @@ __device__ __forceinline__ float cvt_ubyte(unsigned v) {
 // through v_fma_mix_f32 (f16 source half selected by op_sel, f32 multiplicand and accumulator): 1 shift + 4 ands + 8
 // fma_mix per dword instead of 2 ands + 8 half-rate v_cvt_f32_ubyteN + 8 fmas; chains in element order, every partial sum
 // is the old one times 2^-24 exactly, so q4_block_fold's rescale gives bit-identical results (probes/q4_mix_probe.hip).
-#ifndef LLMK_Q4_MIX
-#define LLMK_Q4_MIX 1
-#endif
 __device__ __forceinline__ void q4_dword_dot(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
-#if LLMK_Q4_MIX
     unsigned l0, h0, l1, h1, s;
     asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
         "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
@@ -425,22 +421,11 @@ __device__ __forceinline__ void q4_dword_dot(unsigned q, const float4& xl, const
         : [lo] "+v"(lo), [hi] "+v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
         : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
           [b2] "v"(xh.z), [b3] "v"(xh.w));
-#else
-    const unsigned l = q & 0x0F0F0F0Fu, h = q & 0xF0F0F0F0u;
-    lo = fmaf(cvt_ubyte<0>(l), xl.x, lo);
-    lo = fmaf(cvt_ubyte<1>(l), xl.y, lo);
-    lo = fmaf(cvt_ubyte<2>(l), xl.z, lo);
-    lo = fmaf(cvt_ubyte<3>(l), xl.w, lo);
-    hi16 = fmaf(cvt_ubyte<0>(h), xh.x, hi16);
-    hi16 = fmaf(cvt_ubyte<1>(h), xh.y, hi16);
-    hi16 = fmaf(cvt_ubyte<2>(h), xh.z, hi16);
-    hi16 = fmaf(cvt_ubyte<3>(h), xh.w, hi16);
-#endif
 }
 // the two chains of a block (tl: low nibbles, th: 16 x high nibbles) -> sum n x, on the old recipe's scale
 __device__ __forceinline__ float q4_block_fold(float tl, float th) {
     const float t = fmaf(th, 0.0625f, tl);
-    return LLMK_Q4_MIX ? t * 16777216.0f : t;       // exact (a power of two)
+    return t * 16777216.0f;       // exact (a power of two)
 }
 
 template <int EPI, bool NORM, int NP, int KS = 1>

@@ -405,8 +405,8 @@ int tk_setup(llmk_ctx* c, int id) {
     if (c->use_tk || g.emb_dim != TK::E || g.hidden_dim != TK::H || g.n_heads != TK::NH || g.n_kv_heads != TK::NKV ||
         g.vocab_size != TK::V || g.weight_type != TK::WT)
         return LLMK_OK;
-    // scores + exp(scores), then the LDS annex (f16: the layer's w2 tiles, token_kernel.h LLMK_TK_ANNEX)
-    const size_t lds = (((size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float) + 15) & ~(size_t)15) + TK::ANNEX_BYTES;
+    // scores + exp(scores)
+    const size_t lds = ((size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float) + 15) & ~(size_t)15;
     c->tk_lds = lds < 96 * 1024 ? 96 * 1024 : lds;   // > 80 KB: never two workgroups on one CU
     if (c->tk_lds > 160 * 1024) return LLMK_OK;      // context too long for the in-LDS score row: multi-kernel path
     // The kernel spins on its peers, so all TK_NCU workgroups must be co-resident: one per CU by construction (the LDS

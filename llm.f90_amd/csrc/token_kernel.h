@@ -30,7 +30,6 @@
 #include <type_traits>
 
 #include "kernels.h"
-#include "q4_mfma.h"
 
 // ---- measurement knobs (defaults = the product; -D... builds a variant library for an A/B) ---------------------------
 // loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it).  H = 5632 is
@@ -39,16 +38,6 @@
 // 6 x 8: 561 / 743; E-vectors in pieces of 8: 563 / 724.  Nothing beats two pieces by more than the box-to-box noise.
 #ifndef LLMK_TK_HB_NL
 #define LLMK_TK_HB_NL 32
-#endif
-// hb as 16-byte {v0, v1, v2, tag} granules (f32 / f16 kernels): 1 = on; loads per lane per pass of that gather.
-// MEASURED AND LEFT OFF (round 3, profiles/r03_hb3_granule16_ab.jsonl; parity green with it on): kernel 555 -> 595 us on
-// TinyLlama f16, 713 -> 740 us on f32, whatever the piece size (32 / 16 / 11 loads per pass).  A third fewer sweep bytes do
-// not pay for the 16-byte sc1 stores and the three predicated LDS writes per load: the flat 8-byte {value, tag} sweep stays.
-#ifndef LLMK_TK_HB3
-#define LLMK_TK_HB3 0
-#endif
-#ifndef LLMK_TK_HB3_NL
-#define LLMK_TK_HB3_NL 16
 #endif
 // the same for the E-vectors x / xa (rmsnorm gains are held across these) and xb
 #ifndef LLMK_TK_E_NL
@@ -60,9 +49,6 @@
 // s_sleep argument between two polling passes of a gather (units of 64 clocks)
 #ifndef LLMK_TK_POLL_SLEEP
 #define LLMK_TK_POLL_SLEEP 1
-#endif
-#ifndef LLMK_TK_STAMP_MODE
-#define LLMK_TK_STAMP_MODE 0
 #endif
 // "Gather first" (f32 / f16 kernels).  A CU's memory pipeline is a FIFO: the refill burst a phase ends with (up to NB tiles
 // x 7 waves = 224-280 KB) is issued right after barrier B, the service wave's gather of the NEXT phase's input a moment
@@ -88,14 +74,6 @@
 #ifndef LLMK_TK_GF_NOW
 #define LLMK_TK_GF_NOW -1
 #endif
-// f16 kernel: ALL eight waves gather (an eighth of the vector each, like the q4_0 kernel), every streaming wave ordering its
-// own loads: sweep slice first, then its first tiles, the rest of its burst after the slice has arrived (or failed once)
-// MEASURED AND LEFT OFF (round 3, profiles/r03_gather_first_sweep.jsonl run "gc"; parity green with it on): 509 -> 565 us.  Seven
-// more gather slices, their gains and the refill descriptors inside the sweep take the f16 kernel from 214 to 256 VGPRs with
-// scratch traffic inside the layer loop; the service wave alone, with the bursts ordered behind its sweep (LLMK_TK_GF), wins.
-#ifndef LLMK_TK_F16_COOP
-#define LLMK_TK_F16_COOP 0
-#endif
 // q4_0 kernel: s_sleep units every wave lets the producers have before the first pass of its x / xa / hb slice: the two
 // tiles each wave still has in flight drain meanwhile and the pass, now likely to succeed, finds a short queue.
 // Round 3 (profiles/r03_gather_first_sweep.jsonl run "cd", Llama-2-7B q4_0 kernel us): 0: 1,316-1,320; 12 / 24 / 40: 1,236-1,239;
@@ -113,18 +91,10 @@
 #ifndef LLMK_TK_GF_DELAY
 #define LLMK_TK_GF_DELAY -1
 #endif
-// s_sleep units a non-attention CU lets pass before its FIRST poll of xb (it polls 7 times on average while attention runs:
-// 16 KB of fabric reads per CU and pass).  Measured round 3: 0 ... -1.5 % for 32 / 64 / 100 / 150 units: left at 0.
 #ifndef LLMK_TK_ATT_SPLIT
 #define LLMK_TK_ATT_SPLIT 1          // contexts longer than 256 timesteps: a head's attention in parts on the CUs of its group (TkAttPlan)
 #endif
-#ifndef LLMK_TK_ATT_STEP
-#define LLMK_TK_ATT_STEP 0           // timesteps per attention part before another part is added (0: the prefetched tile, 256 or 128)
-#endif
-#ifndef LLMK_TK_XB_DELAY
-#define LLMK_TK_XB_DELAY 0
-#endif
-// f32 / f16 kernels, round 4: slots at the START of the w1|w3 (A) / w2 (D) phase that are refilled inside the phase, right after
+// f32 / f16 kernels, round 4: slots at the START of the w1|w3 (A) phase that are refilled inside the phase, right after
 // they are consumed, instead of in the burst behind barrier B.  The tiles they request are the NEXT phase's first (w2's,
 // the next layer's QKV / wo), so they get a head start of a phase, and the burst that the following sweep has to share the
 // CU's memory pipeline with is that much shorter.  (All refills were late since round 1, when a refill issued inside a
@@ -136,34 +106,6 @@
 #ifndef LLMK_TK_EARLY_A
 #define LLMK_TK_EARLY_A -1
 #endif
-#ifndef LLMK_TK_EARLY_D
-#define LLMK_TK_EARLY_D 0
-#endif
-// The xb gather is the one whose first passes are CERTAIN to fail: every non-attention CU starts polling the moment its QKV
-// phase ends and attention takes another ~5 us, so 224 CUs sweep the whole 16-32 KB vector six times on average (f16 trace:
-// "gather xb: passes mean 6.2") through the L2 channels the attention CUs' q polls, K/V rows and publishes need.  1: poll ONE
-// granule per head -- the last one its CU publishes -- until all carry the epoch, THEN sweep (the sweep still checks every
-// tag and retries: the granules of a head are two store instructions, and nothing orders their arrival).
-// MEASURED AND LEFT OFF (round 4, same box, profiles/r04_ab.jsonl): Llama-2-7B q4_0 893-894 tok/s with it against 896-897
-// without, TinyLlama f16 2,068-2,090 against 2,107, f32 1,475 either way.  The failed sweeps are not what the hop waits for.
-#ifndef LLMK_TK_XB_SENTINEL
-#define LLMK_TK_XB_SENTINEL 0
-#endif
-// f16 kernel, round 4: the LDS ANNEX (round-3 verdict: "the 80 KB of idle LDS per CU as a second-level tile ring").  The kernel
-// uses 57 KB of the CU's 160 KB of LDS; with LLMK_TK_ANNEX=1 the layer's w2 tiles (12 per CU, 96 KB) are requested at the start
-// of the attention hop -- the one window in which the CU's memory pipeline idles -- with LDS-direct loads
-// (global_load_lds_dwordx4: no registers), dotted from LDS in the w2 phase, and the ring's two w2 slots become padding.
-// BUILT, PARITY GREEN (27 tests), MEASURED SLOWER AND LEFT OFF (profiles/r04_ab.jsonl, r04_trace_tinyllama_f16_annex.txt):
-// 2,010-2,022 tok/s against 2,063-2,064 without it on the same box; kernel 472 / 500 / 593 us at KV length 1 / 256 / 2,048
-// against 449 / 479 / 547.  The trace says where it goes: the hb window does not shrink (gathHB 4.85 -> 4.80 us: its sweep still
-// queues behind the burst of the NEXT layer's tiles) and the wo phase on the attention CUs grows from 1.1 to 4.1 us --
-// their annex requests, issued behind their attention, are still streaming when the wo phase's barrier needs the ring tile
-// that was requested behind them (in-order return) -- and hipcc drains vmcnt before every LDS access that follows an LDS-direct
-// load it cannot prove complete, so the streaming waves sit out the hop instead of polling the gather flag.  The window is real;
-// filling it needs the requests on the non-attention CUs only and a completion the compiler can see.
-#ifndef LLMK_TK_ANNEX
-#define LLMK_TK_ANNEX 0
-#endif
 // q4_0 kernel, round 4.  Its phases are bound by how fast the CU's memory pipeline ACCEPTS the tile requests issued from
 // inside the dots (one request per consumed tile: 57 KB per slot and CU at the CU's 25 KB/us share of HBM = the 2.3 us a slot
 // takes, whatever the ALU needs -- an attention CU, whose QKV slots are empty, spends the same 4.5 us in them), while in the
@@ -174,21 +116,9 @@
 #ifndef LLMK_TK_ADV_HOP
 #define LLMK_TK_ADV_HOP 1
 #endif
-// The same for the first slot of the QKV / w1|w3 / w2 phases, with the sweep in the lead: the request follows the loads of
-// the FIRST pass of the wave's slice of the x / xa / hb gather into the pipeline (a failed first pass retries behind it).
-// bit 0: QKV (x gather), bit 1: w1|w3 (xa gather), bit 2: w2 (hb gather).
-#ifndef LLMK_TK_ADV_GATHER
-#define LLMK_TK_ADV_GATHER 0
-#endif
 
 namespace llmk {
 
-// q4_0 dots on the matrix core (csrc/q4_mfma.h; round 4, experimental -- off in the product build): lane = (block, row) instead
-// of lane = block, x as an f16 hi/lo image in LDS read per block instead of a register fragment, v_mfma_f32_4x4x4_16B_f16
-// instead of v_fma_mix_f32.  Tiles, rows per CU, slots, partial sums and sweeps are unchanged.
-#ifndef LLMK_TK_Q4_MFMA
-#define LLMK_TK_Q4_MFMA 0
-#endif
 constexpr int TK_NCU = 256;               // one workgroup per CU
 constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
 // register tiles a streaming wave keeps requested ahead: TkShape::NB (5 x 8 KB for f32 / f16; 3 for q4_0, whose x fragment
@@ -278,7 +208,6 @@ struct TkShape {
     // fetches each block's f16 scale (stored right behind the row's nibbles) with its own 2-byte load (8 more loads per
     // tile, 1/8 of the bytes).  Rows need not be whole segments: see tk_issue.
     static constexpr bool Q4 = WT == WT_Q4_0;
-    static constexpr bool Q4M = Q4 && LLMK_TK_Q4_MFMA != 0;             // dots on v_mfma_f32_4x4x4_16B_f16 (q4_mfma.h)
     static constexpr int VPL = Q4 ? 32 : (WT == WT_F16 ? 8 : 4);         // weights per 16-byte lane load
     static constexpr int SEGW = WAVE * VPL;                              // weights per 1 KB segment
     // bytes between rows, K = E / K = H (q4_0 device row: K/2 nibble bytes, then the row's K/32 f16 scales, 16-byte aligned)
@@ -307,9 +236,6 @@ struct TkShape {
     // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills
     // that the next phase does not need until its input vector has been gathered (1,675).
     static constexpr bool COOP = Q4;
-    // GCOOP: gathers by all eight waves.  q4_0 (with the lagged refill, COOP) and, round 3, f16 (with bursts ordered behind
-    // each wave's own sweep slice: tk_stream_gc) -- the f32 kernel has no registers left for a slice per streaming wave
-    static constexpr bool GCOOP = Q4 || (WT == WT_F16 && LLMK_TK_F16_COOP);
     // "gather first" (LLMK_TK_GF): tiles per wave a phase's refill burst issues before the next sweep is in the pipeline, and
     // s_sleep units the service wave lets the producers have before the first pass of the x / xa / hb sweeps
     static constexpr int EARLY_A = LLMK_TK_EARLY_A >= 0 ? LLMK_TK_EARLY_A : (WT == WT_F16 ? 1 : 0);
@@ -334,11 +260,9 @@ struct TkShape {
     static constexpr int R_C = RPT * (CB + (CX > 0 ? 1 : 0));
     static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU;
     static constexpr int TPR_H = (LPR_H + LPT - 1) / LPT;                // column parts of a w2 row
-    // Q4M: blocks of the f16 image of x in LDS (whole column parts: the blocks past a ragged K = H row end stay zero), and how
-    // the staging code is told which image to write: 0 natural order, > 0 the transposed float4 image at that pitch, < 0 the
-    // f16 image of -TR blocks (its block sums follow it)
-    static constexpr int NBI = (TPR_H * LPT > LPR_E ? TPR_H * LPT : LPR_E) * WAVE;
-    static constexpr int TR_E = Q4M ? -NBI : (Q4 ? NBP_E : 0), TR_H = Q4M ? -NBI : (Q4 ? NBP_H : 0);
+    // how the staging code is told which image of the input vector to write: 0 natural order, > 0 the transposed float4 image
+    // at that pitch (q4_0)
+    static constexpr int TR_E = Q4 ? NBP_E : 0, TR_H = Q4 ? NBP_H : 0;
     // a CU's row count need not be a multiple of RPT: the last tile then also covers rows of the NEXT CU (recomputed,
     // their partial sums land in slots nobody reads).  The weight allocations carry RPT rows of slack at their end.
     static constexpr int NG_A = (R_A / 2 + RPT - 1) / RPT;               // gate (= up) tiles per CU
@@ -352,7 +276,6 @@ struct TkShape {
 #define LLMK_TK_SVC_A 1
 #endif
     static constexpr bool SVC_A = Q4 && LLMK_TK_SVC_A && (NT_A % TK_NS == 1);
-    static constexpr bool XB_SENT = LLMK_TK_XB_SENTINEL != 0;           // xb: poll one granule per head first (left off)
     static constexpr int NT_A_S = NT_A - (SVC_A ? 1 : 0);                // w1|w3 tiles of the streaming waves
     static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
                          SL_A = (NT_A_S + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
@@ -363,9 +286,6 @@ struct TkShape {
     static constexpr int RA_P = 2 * RPT * NG_A, RQ_P = RPT * NT_Q;       // partial slots incl. the recomputed neighbour rows
     static constexpr int MAXP00 = RA_P > R_C ? RA_P : R_C, MAXP0 = MAXP00 > RQ_P ? MAXP00 : RQ_P, MAXP1 = R_D * TPR_H,
                          MAXP = MAXP0 > MAXP1 ? MAXP0 : MAXP1;           // partial sums per phase
-    static constexpr bool ANNEX = LLMK_TK_ANNEX && WT == WT_F16;        // the CU's w2 tiles wait in LDS (see LLMK_TK_ANNEX)
-    static constexpr int ANNEX_TILES = ANNEX ? NT_D : 0;                 // live (wave, slot) pairs of the w2 phase: compacted
-    static constexpr int ANNEX_BYTES = ANNEX ? ANNEX_TILES * TK_TCOLS * 1024 + 1024 : 0;   // + one junk line: what pairs without a tile write
     static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % RPT == 0, "rows must split over CUs");
     static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
     static_assert(LPR_E <= LPT && (Q4 || (R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
@@ -397,9 +317,7 @@ struct TkLds {
     static constexpr int XS = 0;
     // q4_0: the streaming input is staged TRANSPOSED, xs4[m * NBP + b] = x[32 b + 4 m .. + 3], so the eight float4 a lane
     // needs for block b are lane-contiguous (conflict-free ds_read_b128); pitch NBP = blocks + 1
-    // Q4M: the f16 image (q4_mfma.h: 128 bytes per block) followed by the blocks' 8 * sum x
-    static constexpr int XS_BYTES = SH::Q4M ? SH::NBI * (Q4M_BLK + 4) + WAVE * 4      // (+ 64 junk slots: tk_coop_part)
-                                            : (SH::Q4 ? 8 * (SH::NBP_H > SH::NBP_E ? SH::NBP_H : SH::NBP_E) * 16 : SH::H * 4);
+    static constexpr int XS_BYTES = SH::Q4 ? 8 * (SH::NBP_H > SH::NBP_E ? SH::NBP_H : SH::NBP_E) * 16 : SH::H * 4;
     static constexpr int XRAW = XS + XS_BYTES;
     static constexpr int PART = XRAW + SH::E * 4;
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
@@ -411,11 +329,6 @@ struct TkLds {
     static constexpr int ATT_S = ATT_P + TK_WAVES * 32 * 4;                // scores [S], then exp(score - max) [S]
 };
 
-__device__ __forceinline__ void tk_xb_delay() {
-#pragma unroll
-    for (int i = 0; i < LLMK_TK_XB_DELAY / 127; ++i) __builtin_amdgcn_s_sleep(127);
-    if constexpr (LLMK_TK_XB_DELAY % 127 > 0) __builtin_amdgcn_s_sleep(LLMK_TK_XB_DELAY % 127);
-}
 __device__ __forceinline__ void tk_barrier() {
     // LDS traffic ordered by lgkmcnt; outstanding global LOADS deliberately stay in flight across it
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -542,84 +455,6 @@ __device__ __forceinline__ bool tk_gather(const unsigned long long* g, unsigned 
     return tk_gather_pieces<NL, NBP, MAXNL, 0, GFLAST>(rs, epoch, dst, err, lane, nowait, dbg, flag, seq);
 }
 
-// LLMK_TK_XB_SENTINEL: lanes 0 .. n-1 poll granule first + lane * stride each until all n tags match (bounded like every spin)
-__device__ __forceinline__ bool tk_wait_sentinels(const unsigned long long* g, int first, int stride, int n, unsigned epoch, unsigned* err,
-                                                  int lane, bool nowait) {
-    const unsigned long long* p = g + first + (lane < n ? lane : 0) * stride;
-    for (unsigned spin = 0;; ++spin) {
-        const unsigned long long x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((unsigned)(x >> 32) == epoch) || nowait) return true;
-        if ((spin & 63) == 63) {
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (spin > TK_SPIN_LIMIT) {
-                if (lane == 0) __hip_atomic_store(err, 0x700u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-        __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
-    }
-}
-
-// ---- 16-byte granules {v0, v1, v2, tag} for the hb vector (round 3; probes/granule16_probe: a 16-byte sc1 store is never
-// seen torn by a 16-byte sc1 load) ------------------------------------------------------------------------------------------
-// The hb exchange is the longest edge of a layer (H = 2.75 E values: 44 loads per lane as {v, tag} pairs): three values per
-// 16 bytes instead of two make it 32.  Every CU publishes its UPC = H / 256 hidden units as GPC = ceil(UPC / 3) granules
-// (the last one padded), granule G = c * GPC + i holds units 3i .. 3i+2 of CU c.  GPC divides 64, so the granules a lane
-// reads in one pass (G, G + 64, ...) all have the same i: their LDS destinations differ by a compile-time stride and the
-// "which of the three values are real" mask is per lane, as in tk_gather_part.
-__device__ __forceinline__ void tk_publish3(void* g, int index, unsigned epoch, float v0, float v1, float v2) {
-    const tk_v4u d = {__float_as_uint(v0), __float_as_uint(v1), __float_as_uint(v2), epoch};
-    __builtin_amdgcn_raw_buffer_store_b128(d, tk_rsrc(g, (index + 1) * 16), index * 16, 0, 16);   // aux 16 = sc1 (agent scope, write-through)
-}
-template <int NL, int GPC, int UPC>
-__device__ __forceinline__ bool tk_gather3_part(__amdgpu_buffer_rsrc_t rs, int first, unsigned epoch, float* dst, unsigned* err,
-                                                int lane, bool nowait, unsigned long long* dbg) {
-    static_assert(WAVE % GPC == 0, "granules of one lane share their position inside a CU's group");
-    const int G = first + lane, i = G % GPC;
-    const int dst0 = (G / GPC) * UPC + 3 * i;
-    const bool m1 = 3 * i + 1 < UPC, m2 = 3 * i + 2 < UPC;
-    for (unsigned spin = 0;; ++spin) {
-        const unsigned long long tp0 = (TK_DEBUG && dbg) ? wall_clock64() : 0;
-        tk_v4u r[NL];
-#pragma unroll
-        for (int k = 0; k < NL; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, G * 16, k * WAVE * 16, 16);
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            ok = ok & (r[k].w == epoch);
-            float* d = dst + dst0 + k * (WAVE / GPC) * UPC;
-            d[0] = __uint_as_float(r[k].x);
-            if (m1) d[1] = __uint_as_float(r[k].y);
-            if (m2) d[2] = __uint_as_float(r[k].z);
-        }
-        if (__all(ok) || nowait) {
-            if (TK_DEBUG && dbg && lane == 0) { dbg[0] = spin + 1; dbg[1] = wall_clock64() - tp0; }
-            return true;
-        }
-        if ((spin & 63) == 63) {
-            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (spin > TK_SPIN_LIMIT) {
-                if (lane == 0) __hip_atomic_store(err, 0x500u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-        __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
-    }
-}
-template <int NL, int GPC, int UPC, int MAXNL, int FIRST = 0>
-__device__ __forceinline__ bool tk_gather3_pieces(__amdgpu_buffer_rsrc_t rs, unsigned epoch, float* dst, unsigned* err, int lane,
-                                                  bool nowait, unsigned long long* dbg) {
-    constexpr int NP = (NL + MAXNL - 1) / MAXNL, THIS = (NL + NP - 1) / NP;
-    const bool a = tk_gather3_part<THIS, GPC, UPC>(rs, FIRST * WAVE, epoch, dst, err, lane, nowait, dbg);
-    if constexpr (NL > THIS) {
-        const bool b = tk_gather3_pieces<NL - THIS, GPC, UPC, MAXNL, FIRST + THIS>(rs, epoch, dst, err, lane, nowait,
-                                                                                   (dbg && FIRST == 0) ? dbg + 2 : nullptr);
-        return a && b;
-    } else {
-        return a;
-    }
-}
-
 // ---- cooperative gather (TkShape::COOP): wave w of 8 takes a contiguous eighth of the vector's 16-byte loads ----------
 // NLW loads per lane, all in flight per pass.  Values reach LDS only once the whole slice carries the epoch: a slice that
 // holds this CU's OWN rows cannot complete before the service wave has published them, i.e. after its epilogue has read
@@ -633,14 +468,10 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0x118, 0xf, true>(0.f, v);
     return v;
 }
-struct TkNoop { __device__ __forceinline__ void operator()() const {} };
-// after_first(): issued right behind the loads of the FIRST pass (LLMK_TK_ADV_GATHER: a tile request that follows the sweep
-// into the CU's memory pipeline); straight-line code, so the tag check waits with vmcnt(<those loads>), not vmcnt(0)
-template <int NLW, int NBP, bool NORM, class F = TkNoop>
+template <int NLW, int NBP, bool NORM>
 __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
-                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait,
-                                             F after_first = F()) {
-    if constexpr (NLW == 0) { after_first(); return true; }
+                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait) {
+    if constexpr (NLW == 0) { return true; }
     else {
         float2 gn[NORM ? NLW : 1];
         if constexpr (NORM) {
@@ -649,15 +480,10 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
         }
         const int e0 = 2 * (first_pair + lane);
         const int d0 = tk_xoff<NBP>(e0);
-        // NBP < 0: where this lane's pair goes in the f16 image, its factor (1 or 1/16), and the row's block-sum slot (or the junk slot)
-        char* mp = NBP < 0 ? q4m_pair_ptr<(NBP < 0 ? -NBP : 1) * Q4M_PB>(reinterpret_cast<char*>(xs), e0) : nullptr;
-        const float msc = NBP < 0 ? q4m_pair_scale(e0) : 1.f;
-        float* m8 = reinterpret_cast<float*>(reinterpret_cast<char*>(xs) + (NBP < 0 ? -NBP : 0) * Q4M_BLK) + ((lane & 15) == 15 ? (e0 >> 5) : (NBP < 0 ? -NBP : 0) + lane);
         for (unsigned spin = 0;; ++spin) {
             tk_v4u r[NLW];
 #pragma unroll
             for (int k = 0; k < NLW; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);
-            if constexpr (!std::is_same<F, TkNoop>::value) { if (spin == 0) after_first(); }
             bool ok = true;
 #pragma unroll
             for (int k = 0; k < NLW; ++k) ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
@@ -673,16 +499,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                         acc = fmaf(x1, x1, acc);
                         y0 = x0 * gn[k].x; y1 = x1 * gn[k].y;
                     }
-                    if constexpr (NBP < 0) {
-                        // the f16 image (q4_mfma.h) and the block's 8 * sum x: a load's 64 lanes hold 4 whole blocks, one per DPP row;
-                        // load k lies 4 blocks = 128 bytes further in every plane (immediate offsets).  The sums leave without a branch: the lanes
-                        // that do not hold a row's total write a junk slot behind the array.
-                        q4m_put2_at(mp + k * 4 * Q4M_PB, msc, y0, y1);
-                        const float bs = row16_sum(y0 + y1);
-                        m8[(lane & 15) == 15 ? k * 4 : 0] = 8.0f * bs;
-                    } else {
-                        *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(y0, y1);
-                    }
+                    *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(y0, y1);
                 }
                 if constexpr (NORM) *ss += acc;
                 return true;
@@ -699,16 +516,16 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
     }
 }
 // wave w (0..7) of the workgroup; red8[w] receives the slice's sum of squares when NORM
-template <int N, int NBP, bool NORM, class F = TkNoop>
+template <int N, int NBP, bool NORM>
 __device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsigned epoch, float* xraw, float* xs, const float* gains,
-                                               float* red8, unsigned* err, int w, int lane, bool nowait, F after_first = F()) {
+                                               float* red8, unsigned* err, int w, int lane, bool nowait) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
     constexpr int NL = N / 128, B = NL / TK_WAVES, X = NL % TK_WAVES;      // waves < X take B + 1 loads per lane, the others B
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     float ss = 0.f;
     bool ok;
-    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM, F>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, after_first);
-    else ok = tk_coop_part<B, NBP, NORM, F>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, after_first);
+    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
+    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
     if constexpr (NORM) {
         ss = wave_sum(ss);
         if (lane == 0) red8[w] = ss;
@@ -749,16 +566,6 @@ struct TkNorm {
             o.y = x.y * w[k].y;
             o.z = x.z * w[k].z;
             o.w = x.w * w[k].w;
-            if constexpr (NBP < 0) {
-                // the f16 image (q4_mfma.h): eight lanes hold one block
-                const int e = 4 * (lane + k * WAVE);
-                q4m_put4<(NBP < 0 ? -NBP : 1) * Q4M_PB>(reinterpret_cast<char*>(xs), e, o);
-                float bs = (o.x + o.y) + (o.z + o.w);
-                bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
-                bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
-                bs += dpp_mov<0x114, 0xf, true>(0.f, bs);      // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
-                if ((lane & 7) == 7) reinterpret_cast<float*>(reinterpret_cast<char*>(xs) + (-NBP) * Q4M_BLK)[e >> 5] = 8.0f * bs;
-            } else
             *reinterpret_cast<float4*>(xs + xs0 + k * (NBP > 0 ? 32 : 4 * WAVE)) = o;
         }
         ss = wave_sum(ss);
@@ -787,36 +594,8 @@ struct TkSlot {
     unsigned short sc[SH::Q4 ? TK_TCOLS : 1];
 };
 
-// Q4M (q4_mfma.h): the same 4 rows x 2 segments, other lanes: lane (beta = lane / 4, m = lane % 4) takes row m, and of the
-// tile row's 128 blocks the blocks 16 g + beta, g = 0..7 -- one load instruction = 4 rows x 256 contiguous bytes.  Load g lies
-// in segment g / 4.
-template <class SH>
-__device__ __forceinline__ void tk_issue_m_w(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
-    static_assert(SH::RPT == 4 && SH::LPT == 2, "the q4_0 tile: 4 rows x 2 segments");
-#pragma unroll
-    for (int g = 0; g < TK_TCOLS; ++g) {
-        const bool real = (g / 4) < t.ncol;
-        const float4* pj = real ? t.p + (lane & 3) * t.rstride + g * 16 + (lane >> 2) : zp;
-        e.b[g] = ldg_nt(pj);
-    }
-}
-template <class SH>
-__device__ __forceinline__ void tk_issue_m_s(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
-#pragma unroll
-    for (int g = 0; g < TK_TCOLS; ++g) {
-        const bool real = (g / 4) < t.ncol;
-        const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(t.p + (lane & 3) * t.rstride) + t.soff) + g * 16 + (lane >> 2)
-                                        : reinterpret_cast<const unsigned short*>(zp);
-        e.sc[g] = __builtin_nontemporal_load(pj);
-    }
-}
 template <class SH>
 __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
-    if constexpr (SH::Q4M) {
-        tk_issue_m_w<SH>(e, t, zp, lane);
-        tk_issue_m_s<SH>(e, t, zp, lane);
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
@@ -847,17 +626,8 @@ __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const f
 template <class SH>
 struct TkX {
     static constexpr int F4 = SH::VPL / 4;          // float4 of x per segment and lane: 1 (f32), 2 (f16), 8 (q4_0: one block)
-    float4 v[SH::Q4M ? 1 : SH::LPT * F4];
-    float xs8[SH::Q4 && !SH::Q4M ? SH::LPT : 1];    // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
-    // Q4M: no fragment -- this lane's piece (lane & 1: hi or lo; lanes 2, 3 of a group feed matrix rows nobody reads) of block
-    // seg0 * 64 + lane / 4 in plane 0 of the f16 image, and that block's 8 * sum x; load g of a tile is 16 g blocks further
-    const char* xp;
-    const float* x8;
-    __device__ __forceinline__ void load_q4m(const char* img, int seg0, int lane) {
-        const int b = seg0 * WAVE + (lane >> 2);
-        xp = img + b * Q4M_PB + (lane & 1) * 16;
-        x8 = reinterpret_cast<const float*>(img + SH::NBI * Q4M_BLK) + b;
-    }
+    float4 v[SH::LPT * F4];
+    float xs8[SH::Q4 ? SH::LPT : 1];                // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
     // segments seg0 .. seg0+LPT-1 of a vector with nseg segments; segments past the end read as zero
     __device__ __forceinline__ void load(const float4* xs, int seg0, int nseg, int lane) {
 #pragma unroll
@@ -915,12 +685,8 @@ __device__ __forceinline__ float4 tk_h2f_hi(const float4& w) {   // halves 4..7
 // every partial sum is the old recipe's times 2^-24 (a power of two commutes with rounding), so after the exact rescale
 // in tk_q4_block the results are BIT-IDENTICAL (probes/q4_mix_probe.hip: 65,536 random dword chains, zero differences;
 // cycles per dword there).  lo += 2^-24 sum n_lo x, hi16 += 2^-24 sum (16 n_hi) x.
-#ifndef LLMK_Q4_MIX
-#define LLMK_Q4_MIX 1
-#endif
-constexpr float TK_Q4_RESCALE = LLMK_Q4_MIX ? 16777216.0f : 1.0f;
+constexpr float TK_Q4_RESCALE = 16777216.0f;
 __device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
-#if LLMK_Q4_MIX
     unsigned l0, h0, l1, h1, s;
     asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
         "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
@@ -938,37 +704,11 @@ __device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const 
         : [lo] "+v"(lo), [hi] "+v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
         : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
           [b2] "v"(xh.z), [b3] "v"(xh.w));
-#else
-    unsigned l, h;
-    float t0, t1;
-    asm("v_and_b32 %[l], 0x0f0f0f0f, %[q]\n\t"
-        "v_and_b32 %[h], 0xf0f0f0f0, %[q]\n\t"
-        "v_cvt_f32_ubyte0 %[t0], %[l]\n\t"
-        "v_cvt_f32_ubyte0 %[t1], %[h]\n\t"
-        "v_fmac_f32 %[lo], %[t0], %[a0]\n\t"
-        "v_fmac_f32 %[hi], %[t1], %[b0]\n\t"
-        "v_cvt_f32_ubyte1 %[t0], %[l]\n\t"
-        "v_cvt_f32_ubyte1 %[t1], %[h]\n\t"
-        "v_fmac_f32 %[lo], %[t0], %[a1]\n\t"
-        "v_fmac_f32 %[hi], %[t1], %[b1]\n\t"
-        "v_cvt_f32_ubyte2 %[t0], %[l]\n\t"
-        "v_cvt_f32_ubyte2 %[t1], %[h]\n\t"
-        "v_fmac_f32 %[lo], %[t0], %[a2]\n\t"
-        "v_fmac_f32 %[hi], %[t1], %[b2]\n\t"
-        "v_cvt_f32_ubyte3 %[t0], %[l]\n\t"
-        "v_cvt_f32_ubyte3 %[t1], %[h]\n\t"
-        "v_fmac_f32 %[lo], %[t0], %[a3]\n\t"
-        "v_fmac_f32 %[hi], %[t1], %[b3]"
-        : [lo] "+v"(lo), [hi] "+v"(hi16), [l] "=&v"(l), [h] "=&v"(h), [t0] "=&v"(t0), [t1] "=&v"(t1)
-        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
-          [b2] "v"(xh.z), [b3] "v"(xh.w));
-#endif
 }
 // The FIRST dword of a block: the same operations with the constant 0 as the first addend of both chains instead of zeroed
 // registers (fma(a, b, 0) is the same number): two v_mov fewer per block, 16 per tile of the ~520 VALU operations that bound a
-// q4_0 phase.  LLMK_Q4_MIX only (the conversion recipe keeps its zeroed accumulators).
+// q4_0 phase.
 __device__ __forceinline__ void tk_q4_dword_first(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
-#if LLMK_Q4_MIX
     unsigned l0, h0, l1, h1, s;
     asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
         "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
@@ -986,16 +726,11 @@ __device__ __forceinline__ void tk_q4_dword_first(unsigned q, const float4& xl, 
         : [lo] "=&v"(lo), [hi] "=&v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
         : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
           [b2] "v"(xh.z), [b3] "v"(xh.w));
-#else
-    lo = 0.f; hi16 = 0.f;
-    tk_q4_dword(q, xl, xh, lo, hi16);
-#endif
 }
 // one block's contribution d * (sum n x - 8 sum x) from the two chains of tk_q4_dword (tl, th) and xs8 = 8 sum x
 __device__ __forceinline__ float tk_q4_block(float tl, float th, float d, float xs8, float acc) {
     const float t = fmaf(th, 0.0625f, tl);
-    if constexpr (LLMK_Q4_MIX) return fmaf(d, fmaf(t, TK_Q4_RESCALE, -xs8), acc);   // t * 2^24 is exact: == d * (t_old - xs8) + acc
-    else return fmaf(d, t - xs8, acc);
+    return fmaf(d, fmaf(t, TK_Q4_RESCALE, -xs8), acc);   // t * 2^24 is exact: == d * (t_conv - xs8) + acc
 }
 
 // a value per lane that belongs to tile row (lane & 3): the sum over the sixteen lanes that share lane & 3, written by lanes 12..15
@@ -1018,40 +753,8 @@ __device__ __forceinline__ void tk_rows4_reduce(const float (&v)[4], const TkTil
     tk_rows4_finish(r, t, part, lane);
 }
 
-// Q4M: loads G0 .. G0+N-1 of a tile against the image: acc += d (2^24 s - 8 sum x) per block, for the row lane & 3
-template <class SH, int G0, int N, bool PIPE = true>
-__device__ __forceinline__ float tk_dot_m(const TkSlot<SH>& e, const TkX<SH>& x, float acc) {
-    // PIPE: block g + 1's piece of x (16 registers) and the blocks' sums are on their way through LDS while block g is multiplied
-    // (the service wave, which carries the layer loop's state, reads one block at a time)
-    uint4 xv[PIPE ? 2 : 1][4];
-    float s8[N];
-    constexpr int PL = SH::NBI * Q4M_PB;           // bytes per plane of the image
-    q4m_xload<PL>(xv[0], x.xp + G0 * 16 * Q4M_PB);
-    if constexpr (PIPE) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) s8[i] = x.x8[(G0 + i) * 16];
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const int g = G0 + i;
-        if constexpr (PIPE) { if (i + 1 < N) q4m_xload<PL>(xv[(i + 1) & 1], x.xp + (g + 1) * 16 * Q4M_PB); }
-        else { if (i > 0) q4m_xload<PL>(xv[0], x.xp + g * 16 * Q4M_PB); s8[i] = x.x8[g * 16]; }
-        const float4& w = e.b[g];
-        const uint4 q = make_uint4(__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w));
-        const float sm = q4m_block(q, xv[PIPE ? (i & 1) : 0]);
-        const unsigned short hs = e.sc[g];
-        const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
-        acc = fmaf(d, fmaf(sm, Q4M_RESCALE, -s8[i]), acc);
-        __builtin_amdgcn_sched_barrier(0);      // (hoisted further, the reads of all eight blocks spill the ring)
-    }
-    return acc;
-}
-template <class SH>
-__device__ __forceinline__ void tk_finish_m(float acc, const TkTile& t, float* part, int lane) { tk_rows4_finish(acc, t, part, lane); }
-
 template <class SH>
 __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, float (&out)[SH::RPT]) {
-    static_assert(!SH::Q4M, "Q4M tiles go through tk_dot_m");
     const float4 (&b)[TK_TCOLS] = e.b;
     if constexpr (SH::Q4) {
         // sum_i (n_i - 8) d x_i = d (sum_i n_i x_i - 8 sum_i x_i): low nibbles are elements 0..15 of the block, high nibbles
@@ -1100,17 +803,13 @@ __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, fl
 }
 template <class SH>
 __device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t, const TkX<SH>& x, float* part, int lane) {
-    if constexpr (SH::Q4M) {
-        tk_finish_m<SH>(tk_dot_m<SH, 0, TK_TCOLS>(b, x, 0.f), t, part, lane);
-    } else {
-        float v[SH::RPT];
-        tk_dot<SH>(b, x, v);
+    float v[SH::RPT];
+    tk_dot<SH>(b, x, v);
 #pragma unroll
-        for (int s = 0; s < SH::RPT; ++s) v[s] = wave_sum(v[s]);
-        if (lane == 0) {
+    for (int s = 0; s < SH::RPT; ++s) v[s] = wave_sum(v[s]);
+    if (lane == 0) {
 #pragma unroll
-            for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = v[s];
-        }
+        for (int s = 0; s < SH::RPT; ++s) part[t.pidx + s * t.pstep] = v[s];
     }
 }
 
@@ -1120,11 +819,6 @@ __device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t,
 template <class SH>
 __device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const TkTile& t, const float4* xs4, float* part, int lane) {
     static_assert(SH::Q4, "q4_0 tiles");
-    if constexpr (SH::Q4M) {
-        TkX<SH> x;
-        x.load_q4m(reinterpret_cast<const char*>(xs4), 0, lane);
-        tk_finish_m<SH>(tk_dot_m<SH, 0, TK_TCOLS, false>(e, x, 0.f), t, part, lane);
-    } else {
     float acc[SH::RPT];
 #pragma unroll
     for (int s = 0; s < SH::RPT; ++s) acc[s] = 0.f;
@@ -1154,7 +848,6 @@ __device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const Tk
     }
     static_assert(SH::RPT == 4, "four rows per q4_0 tile");
     tk_rows4_reduce(acc, t, part, lane);
-    }
 }
 
 // Static per-wave schedule: SLP slots per layer (padded to an even count so the 2-deep ring has the
@@ -1232,45 +925,6 @@ __device__ __forceinline__ TkTile tk_w2_tile(const TokenArgs& a, int l, int c, i
     t.soff = SH::H / 2 - part * SH::LPT * WAVE * 14;   // p is part * LPT segments (1 KB each) into the row; its scales 128 B each
     return t;
 }
-// ---- the LDS annex (LLMK_TK_ANNEX) -------------------------------------------------------------------------------------------
-// slot of (wave sw, w2 slot k) in the annex: the rank of the pair among the LIVE pairs in (k, sw) order (7 x SL_D pairs, NT_D of
-// them live: 12 of 14 on TinyLlama), -1 when the pair has no tile.  A handful of scalar operations, once per wave and token.
-template <class SH>
-__device__ __forceinline__ int tk_annex_slot(int sw, int k) {
-    constexpr int P = SH::TPR_H, NRG = SH::R_D / SH::RPT;
-    int n = 0, mine = -1;
-#pragma unroll
-    for (int kk = 0; kk < SH::SL_D; ++kk)
-#pragma unroll
-        for (int w = 0; w < TK_NS; ++w) {
-            const int part = w % P, nw = (TK_NS - part + P - 1) / P;
-            const bool live = kk * nw + w / P < NRG;
-            if (w == sw && kk == k) mine = live ? n : -1;
-            n += live ? 1 : 0;
-        }
-    return mine;
-}
-typedef __attribute__((address_space(3))) void* tk_lds_ptr;
-typedef const __attribute__((address_space(1))) void* tk_glb_ptr;
-// one tile HBM -> LDS, no registers: 8 x global_load_lds_dwordx4 (lane i's 16 bytes land at dst + 16 i: a segment is 1 KB,
-// contiguous).  Segments past a ragged row end read the zero block, as in tk_issue (their x fragment is zero, but what they are
-// multiplied with must be finite).  The loads count in vmcnt like any other; they are older than every ring tile requested after
-// them, so a phase that has consumed such a ring tile has them in LDS (in-order return).
-template <class SH>
-__device__ __forceinline__ void tk_annex_issue(char* dst, int seg_pitch, const TkTile& t, const float4* zp, int lane) {
-#pragma unroll
-    for (int j = 0; j < TK_TCOLS; ++j) {
-        const int s = j / SH::LPT, jj = j % SH::LPT;
-        const bool real = jj < t.ncol;
-        const float4* pj = real ? t.p + s * t.rstride + jj * WAVE + lane : zp;            // (one 16-byte access for the wave, as in tk_issue)
-        __builtin_amdgcn_global_load_lds((tk_glb_ptr)pj, (tk_lds_ptr)(dst + j * seg_pitch), 16, 0, 0);   // (pitch 0: the junk line)
-    }
-}
-template <class SH>
-__device__ __forceinline__ void tk_annex_read(TkSlot<SH>& e, const char* src, int lane) {
-#pragma unroll
-    for (int j = 0; j < TK_TCOLS; ++j) e.b[j] = reinterpret_cast<const float4*>(src + j * 1024)[lane];
-}
 // descriptor of slot K (compile-time) of layer l; K >= SLP looks into layer l+1; past the last
 // layer the stream continues with the classifier slots
 template <class SH, int K>
@@ -1291,8 +945,7 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
             const int ti = (K - SC::KA) * TK_NS + sw;
             return tk_w13_tile<SH>(a, l, c, ti, ti < SH::NT_A_S);
         } else if constexpr (K < SC::KP) {
-            if constexpr (SH::ANNEX) return tk_null<SH>(a.zeros);          // the w2 tiles wait in LDS: the ring's w2 slots are padding
-            else return tk_w2_tile<SH>(a, l, c, sw, K - SC::KD);
+            return tk_w2_tile<SH>(a, l, c, sw, K - SC::KD);
         } else {
             return tk_null<SH>(a.zeros);
         }
@@ -1335,11 +988,12 @@ template <class SH>
 struct TkAttPlan {
     static constexpr int HPC = TK_NCU / SH::NH, TILE = TkAtt<SH>::TILE, TPB = TkAtt<SH>::TPB;
     static constexpr int PMAX = HPC < 8 ? HPC : 8;       // parts per head at most
-    static constexpr int STEP = LLMK_TK_ATT_STEP > 0 ? LLMK_TK_ATT_STEP : TILE;   // one more part per STEP timesteps
+    static constexpr int STEP = TILE;                    // one more part per STEP timesteps (a part per 128 / 64 / 32: measured
+                                                         // slower, profiles/r03_att_part_step_sweep.txt)
     int P, chunk;
     __device__ __forceinline__ TkAttPlan(int pos) {
         P = min(PMAX, (pos + STEP - 1) / STEP);
-        if (LLMK_TK_ATT_SPLIT == 0 || (SH::GCOOP && !SH::COOP) || P < 1) P = 1;   // (tk_stream_gc, an experiment left off, knows no parts)
+        if (LLMK_TK_ATT_SPLIT == 0 || P < 1) P = 1;
         chunk = (((pos + P - 1) / P) + TPB - 1) / TPB * TPB;
         while (P > 1 && (P - 1) * chunk >= pos) --P;          // (cannot happen for pos > TILE * (P - 1); kept as a guard)
     }
@@ -1511,7 +1165,7 @@ __device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
 // bytes per lane in the STREAMING waves' loop (one s_waitcnt vmcnt(0) + scratch store per slot: the ring drains).
 template <class SH, bool GR>
 __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c, int lane_in, int tid) {
-    int lane = lane_in;     // (Q4M: made opaque once per layer, so that what is derived from it is recomputed there, not spilled)
+    const int lane = lane_in;
     typedef TkLds<SH> LD;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
     float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
@@ -1519,14 +1173,11 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // q4_0: the streaming input is staged transposed (TkLds); 0 = natural order
     constexpr int TR_E = SH::TR_E, TR_H = SH::TR_H;
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
-    // hb as {v0, v1, v2, tag} granules: the f32 / f16 kernels (the q4_0 kernel gathers with all eight waves, tk_coop_gather)
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF: gathers issued so far on this CU
-    constexpr bool GF = LLMK_TK_GF && !SH::GCOOP;
-    constexpr bool GCD = (SH::GCOOP && !SH::COOP && SH::GF_DELAY > 0) || (SH::COOP && LLMK_TK_COOP_DELAY > 0);   // coop: the same head start for the producers
-    constexpr int GCDN = SH::COOP ? LLMK_TK_COOP_DELAY : SH::GF_DELAY;
+    constexpr bool GF = LLMK_TK_GF && !SH::COOP;
+    constexpr bool GCD = SH::COOP && LLMK_TK_COOP_DELAY > 0;      // coop: the same head start for the producers
+    constexpr int GCDN = LLMK_TK_COOP_DELAY;
     if (GF) { tk_flag_set(gflag, -1, lane); tk_flag_set(gflag + 1, -1, lane); }
-    constexpr int GPC_A = (SH::R_A / 2 + 2) / 3;
-    constexpr bool HB3 = LLMK_TK_HB3 && !SH::GCOOP && WAVE % GPC_A == 0 && (TK_NCU * GPC_A) % WAVE == 0 && TK_NCU * GPC_A * 16 <= SH::H * 8;
     const int L = a.L;
     const int tok = tk_token<GR, SH::V>(a, c, lane);
     const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
@@ -1546,24 +1197,15 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     }
     unsigned long long* tr = (TK_DEBUG && tk_trace(a)) ? tk_trace(a) + (size_t)c * TK_TRACE_N : nullptr;
     const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
-// LLMK_TK_STAMP_MODE (product build; an experiment knob of round 3's A/B): what a stamp site leaves behind when the
-// stamps are compiled out -- 0 nothing, 1 a scheduling barrier, 2 a compiler memory barrier
-#if defined(LLMK_TK_DEBUG) || LLMK_TK_STAMP_MODE == 0
 #define TK_STAMP(i) do { if (tr && lane == 0 && l < 64) tr[l * 16 + (i)] = wall_clock64(); } while (0)
-#elif LLMK_TK_STAMP_MODE == 1
-#define TK_STAMP(i) __builtin_amdgcn_sched_barrier(0)
-#else
-#define TK_STAMP(i) asm volatile("" ::: "memory")
-#endif
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
-        if constexpr (SH::Q4M) asm volatile("" : "+v"(lane));
         TK_STAMP(0);
 
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
         TkNorm<SH::E> nrm;
-        const bool coop0 = SH::GCOOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
+        const bool coop0 = SH::COOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
         if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane);
         float xn_att = 1.f;
         if (GF && att_cu) { tk_flag_set(gflag, 4 * l + 1, lane); if (SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 1, lane); }   // no x and no xb gather on this CU: nothing for its bursts to wait for
@@ -1726,16 +1368,10 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
-        if constexpr (SH::GCOOP) {
-            if (!att_cu) {
-                tk_xb_delay();
-                // (this wave's slice is the last eighth of the vector: heads (E - E/8) / HS onwards)
-                if constexpr (SH::XB_SENT) ok = tk_wait_sentinels(tk_g_xb<SH>(a), TK_NS * (SH::E / TK_WAVES) + SH::HS - 1, SH::HS, SH::E / TK_WAVES / SH::HS, e_att, a.err, lane, nosync) && ok;
-                ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
-            }
+        if constexpr (SH::COOP) {
+            // (this wave's slice is the last eighth of the vector: heads (E - E/8) / HS onwards)
+            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         } else {
-            if (!att_cu) tk_xb_delay();
-            if constexpr (SH::XB_SENT) { if (!att_cu) ok = tk_wait_sentinels(tk_g_xb<SH>(a), SH::HS - 1, SH::HS, SH::NH, e_att, a.err, lane, nosync) && ok; }
             if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr, gflag, 4 * l + 1) && ok;
         }
         TK_STAMP(7);
@@ -1750,7 +1386,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 2, lane);
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
-        if constexpr (SH::GCOOP) {
+        if constexpr (SH::COOP) {
             if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
             ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             TK_STAMP(9);
@@ -1779,28 +1415,19 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         TK_STAMP(10);
         tk_barrier();
         TK_STAMP(11);
-        float hbv = 0.f;
         if (lane < SH::R_A / 2) {
             float gsum = part[2 * lane], usum = part[2 * lane + 1];
             gsum = gsum / xn_ffn;
             usum = usum / xn_ffn;
             const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
-            if constexpr (!HB3) tk_publish(tk_g_hb<SH>(a) + c * (SH::R_A / 2) + lane, e_a, hb * usum);
-            else hbv = hb * usum;
-        }
-        if constexpr (HB3) {   // three units per 16-byte granule: lane i < GPC collects units 3i .. 3i+2 (pads: 0)
-            const float v0 = __shfl(hbv, 3 * lane, WAVE), v1 = __shfl(hbv, 3 * lane + 1, WAVE), v2 = __shfl(hbv, 3 * lane + 2, WAVE);
-            if (lane < GPC_A) tk_publish3(tk_g_hb<SH>(a), c * GPC_A + lane, e_a, v0, 3 * lane + 1 < SH::R_A / 2 ? v1 : 0.f, 3 * lane + 2 < SH::R_A / 2 ? v2 : 0.f);
+            tk_publish(tk_g_hb<SH>(a) + c * (SH::R_A / 2) + lane, e_a, hb * usum);
         }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
-        if constexpr (SH::GCOOP) {
+        if constexpr (SH::COOP) {
             if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
             ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         }
-        else if constexpr (HB3)
-            ok = tk_gather3_pieces<TK_NCU * GPC_A / WAVE, GPC_A, SH::R_A / 2, LLMK_TK_HB3_NL>(tk_rsrc(tk_g_hb<SH>(a), TK_NCU * GPC_A * 16), e_a, xs, a.err, lane,
-                                                                                             nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr) && ok;
         else {
             if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
             ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL, SH::GF_LAST>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr, gflag, 4 * l + 3) && ok;
@@ -1823,7 +1450,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 #undef TK_STAMP
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     float xn_fin;
-    if constexpr (SH::GCOOP) {
+    if constexpr (SH::COOP) {
         if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
         ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
         tk_barrier();
@@ -1885,10 +1512,7 @@ __device__ __forceinline__ void tk_run(TkRing<SH>& r, const TokenArgs& a, int l,
 // scheduler can interleave), then ONE lane-0 block of LDS writes
 template <class SH, int K, int N>
 __device__ __forceinline__ void tk_eat(const TkRing<SH>& r, const TkX<SH>& x, float* part, int lane) {
-    if constexpr (N > 0 && SH::Q4M) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) tk_consume<SH>(r.b[(K + i) % SH::NB], r.t[(K + i) % SH::NB], x, part, lane);
-    } else if constexpr (N > 0) {
+    if constexpr (N > 0) {
         float v[N][SH::RPT];
 #pragma unroll
         for (int i = 0; i < N; ++i) tk_dot<SH>(r.b[(K + i) % SH::NB], x, v[i]);
@@ -1918,9 +1542,9 @@ __device__ __forceinline__ void tk_refill(TkRing<SH>& r, const TokenArgs& a, int
 // (consume), [barrier B], late refills
 template <class SH, int K0, int S, bool CLS, bool WIDE = false>
 __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
-                                         float* part, int lane, volatile int* gflag = nullptr, int seq = 0, const char* annex = nullptr) {
+                                         float* part, int lane, volatile int* gflag = nullptr, int seq = 0) {
     constexpr int LATE0 = S < SH::NB ? S : SH::NB;
-    constexpr int WANT = CLS ? 0 : (K0 == TkSched<SH>::KA ? SH::EARLY_A : (K0 == TkSched<SH>::KD ? LLMK_TK_EARLY_D : 0));   // leading slots refilled in-phase
+    constexpr int WANT = (!CLS && K0 == TkSched<SH>::KA) ? SH::EARLY_A : 0;   // leading slots refilled in-phase
     constexpr int EARLY = (S - LATE0) > (WANT < S ? WANT : S - 1) ? (S - LATE0) : (WANT < S ? WANT : S - 1), LATE = S - EARLY;
     tk_barrier();
     TkX<SH> x;
@@ -1931,25 +1555,10 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
         if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
         else x.load(xs4, 0, SH::LPR_E, lane);
     }
-    if constexpr (SH::ANNEX && WIDE && !CLS) {
-        // the w2 phase with its tiles in LDS (LLMK_TK_ANNEX): the ring's slots of this phase are padding, consumed by doing nothing
-        static_assert(EARLY == 0, "the padding slots are refilled behind barrier B");
-#pragma unroll
-        for (int k = 0; k < SH::SL_D; ++k) {
-            const int slot = tk_annex_slot<SH>(sw, k);
-            if (slot >= 0) {                               // wave-uniform; no global loads inside
-                const TkTile t = tk_w2_tile<SH>(a, l, c, sw, k);
-                TkSlot<SH> e;
-                tk_annex_read<SH>(e, annex + (size_t)slot * (TK_TCOLS * 1024), lane);
-                tk_consume<SH>(e, t, x, part, lane);
-            }
-        }
-    } else {
-        tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
-        tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
-    }
+    tk_run<SH, K0, EARLY, CLS>(r, a, l, c, sw, x, part, lane);
+    tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
     tk_barrier();
-    if constexpr (LLMK_TK_GF && !SH::GCOOP && !CLS) {
+    if constexpr (LLMK_TK_GF && !SH::COOP && !CLS) {
         // LLMK_TK_GF: a first part of the burst now, the rest once the service wave's next sweep is in the pipeline ahead of it
         constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
         if (SH::GF_PUB && gflag) tk_flag_wait(gflag + 1, seq);
@@ -1967,7 +1576,7 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
 // does, there is no refill burst anywhere (the f32 / f16 kernels place theirs behind the exchange instead, section 3b), and
 // a wave that polls after its phase has at most one tile of its own in flight.  Prefetch distance NB - 1 = 2 tiles.
 // the request slot K of a phase would issue from inside its dots (tile K + NB - 1 into the entry slot K - 1 has freed), as a
-// statement of its own: LLMK_TK_ADV_HOP / LLMK_TK_ADV_GATHER issue it in the window BEFORE the phase, and the slot issues none
+// statement of its own: LLMK_TK_ADV_HOP issues it in the window BEFORE the phase, and the slot issues none
 template <class SH, int K, bool CLS>
 __device__ __forceinline__ void tk_request(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, int lane) {
     constexpr int RN = (K + SH::NB - 1) % SH::NB;
@@ -1988,24 +1597,6 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
     // a padding slot (the layer's slots rounded up to the ring depth) holds no tile on any wave of any CU: it only keeps the
     // ring turning -- the request, no dots
     constexpr bool PAD = !CLS && (K % TkSched<SH>::SLP) >= TkSched<SH>::KP;
-    if constexpr (SH::Q4M) {
-        // the same interleaving on the matrix-core dots: half of the tile's blocks, the next tile's nibble vectors, the other half,
-        // its scales, then the reduction
-        float acc = 0.f;
-        if constexpr (!PAD) acc = tk_dot_m<SH, 0, 4>(e, x, acc);
-        if constexpr (REQ) {
-            __builtin_amdgcn_sched_barrier(0);
-            tk_issue_m_w<SH>(n, tn, a.zeros, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (!PAD) acc = tk_dot_m<SH, 4, 4>(e, x, acc);
-        if constexpr (REQ) {
-            __builtin_amdgcn_sched_barrier(0);
-            tk_issue_m_s<SH>(n, tn, a.zeros, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (!PAD) tk_finish_m<SH>(acc, r.t[R], part, lane);
-    } else {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     auto row = [&](int s_) {
         float acc = 0.f;
@@ -2055,7 +1646,6 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (!PAD) tk_rows4_reduce(v, r.t[R], part, lane);
-    }
     r.t[RN] = tn;
 }
 template <class SH, int K, int N, bool CLS, bool REQ0 = true>
@@ -2071,8 +1661,7 @@ __device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a,
                                               float* part, int lane) {
     tk_barrier();
     TkX<SH> x;
-    if constexpr (SH::Q4M) x.load_q4m(reinterpret_cast<const char*>(xs4), WIDE ? (sw % SH::TPR_H) * SH::LPT : 0, lane);
-    else if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
+    if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
     else x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
     tk_steps<SH, K0, S, CLS, REQ0>(r, a, l, c, sw, x, part, lane);
     tk_barrier();
@@ -2110,7 +1699,6 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
     const int my_head = c / HPC;                    // (its attention CU, or a part of it at long contexts: tk_att_role)
 
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF
-    char* annex = lds + ((LD::ATT_S + 2 * a.S * 4 + 15) & ~15);                  // LLMK_TK_ANNEX: behind the score rows
     TkRing<SH> r;
     tk_prime<SH, 0>(r, a, c, sw, lane);
 
@@ -2132,23 +1720,8 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
                 tk_barrier();
                 tk_attention<SH>(a, lds, l, my_head, pos, tid, pa, nullptr, at0, at1);
                 tk_barrier();
-                // (the service wave publishes this head's output now, and stores share the memory pipeline with loads: the
-                // requests below wait a moment -- the lesson of the q4_0 kernel's LLMK_TK_ADV_HOP)
-                if constexpr (SH::ANNEX) __builtin_amdgcn_s_sleep(48);
             }
-            if constexpr (SH::ANNEX) {
-                // the layer's w2 tiles into the annex, at the START of the attention hop: the one window in which this CU's
-                // memory pipeline idles.  Issued before the ring's own refill below, so every later ring tile is younger.
-                // (no branch around the loads -- hipcc drains vmcnt at such a join: a (wave, slot) pair without a tile reads the zero
-                // block into the annex's junk line)
-#pragma unroll
-                for (int k = 0; k < SH::SL_D; ++k) {
-                    const int slot = tk_annex_slot<SH>(sw, k);
-                    tk_annex_issue<SH>(annex + (slot >= 0 ? (size_t)slot * (TK_TCOLS * 1024) : (size_t)SH::ANNEX_TILES * (TK_TCOLS * 1024)), slot >= 0 ? 1024 : 0,
-                                       tk_w2_tile<SH>(a, l, c, sw, k), a.zeros, lane);
-                }
-            }
-            if constexpr (LLMK_TK_GF && !SH::GCOOP) {
+            if constexpr (LLMK_TK_GF && !SH::COOP) {
                 constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
                 if (SH::GF_PUB) tk_flag_wait(gflag + 1, 4 * l + 1);
                 tk_refill<SH, SC::KQ + EARLY, NOW, false>(r, a, l, c, sw, lane);
@@ -2160,7 +1733,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
         }
         tk_phase<SH, SC::KO, SH::SL_O, false>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 2);
         tk_phase<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 3);
-        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 4, annex);   // w2 slots + padding
+        tk_phase<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane, gflag, 4 * l + 4);   // w2 slots + padding
     }
     // classifier: the ring index is 0 again (SLP is a multiple of NB); refills run off the stream's end
     tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
@@ -2171,7 +1744,7 @@ __device__ __forceinline__ void tk_stream(const TokenArgs& a, char* lds, int c, 
 // epoch of every gather mirror tk_service.
 template <class SH>
 __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, int c, int sw, int lane_in, int tid) {
-    int lane = lane_in;     // (LLMK_TK_LAUNDER: opaque once per layer -- what is derived from it is recomputed, not carried)
+    const int lane = lane_in;
     typedef TkLds<SH> LD;
     typedef TkSched<SH> SC;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
@@ -2190,16 +1763,10 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
 
     TkRing<SH> r;
     tk_prime_coop<SH, 0>(r, a, c, sw, lane);
-    constexpr bool ADVH = LLMK_TK_ADV_HOP != 0, ADVA = (LLMK_TK_ADV_GATHER & 2) != 0,
-                   ADVD = (LLMK_TK_ADV_GATHER & 4) != 0;
-    // (an attention CU gathers no x: its QKV slots keep their own requests, so ADVQ needs a run-time branch around a slot's loads
-    // and is only taken where every CU gathers -- the last layer's x, for the classifier -- see below)
+    constexpr bool ADVH = LLMK_TK_ADV_HOP != 0;
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
-#if defined(LLMK_TK_LAUNDER) && LLMK_TK_LAUNDER
-        asm volatile("" : "+v"(lane));
-#endif
         // QKV phase (its input was gathered at the end of the previous layer; layer 0: the service wave stages the embedding row)
         tk_phase_body<SH, SC::KQ, SH::SL_Q, false>(r, a, l, c, sw, xs4, part, lane);
         int at0, at1;
@@ -2216,28 +1783,14 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
         }
         // the wo slot's request, in the window of the attention hop (behind this CU's own attention, if it has any)
         if constexpr (ADVH) tk_request<SH, SC::KO, false>(r, a, l, c, sw, lane);
-        if (!att_cu) {
-            tk_xb_delay();
-            if constexpr (SH::XB_SENT) tk_wait_sentinels(tk_g_xb<SH>(a), sw * (SH::E / TK_WAVES) + SH::HS - 1, SH::HS, SH::E / TK_WAVES / SH::HS, e_att, a.err, lane, nosync);
-            tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
-        }
+        if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KO, SH::SL_O, false, false, !ADVH>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
-        if constexpr (ADVA) {
-            tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync,
-                                              [&]() { tk_request<SH, SC::KA, false>(r, a, l, c, sw, lane); });
-        } else {
-            tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
-        }
-        tk_phase_body<SH, SC::KA, SH::SL_A, false, false, !ADVA>(r, a, l, c, sw, xs4, part, lane);
+        tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
+        tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
-        if constexpr (ADVD) {
-            tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync,
-                                               [&]() { tk_request<SH, SC::KD, false>(r, a, l, c, sw, lane); });
-        } else {
-            tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
-        }
-        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true, !ADVD>(r, a, l, c, sw, xs4, part, lane);
+        tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         if (l + 1 < L) {
             if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, a.err, sw, lane, nosync);
@@ -2246,156 +1799,6 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
         }
     }
     tk_phase_body<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
-}
-
-
-// ---- f16: streaming waves that gather (GCOOP without the q4_0 lagged refill) ------------------------------------------------
-// One wave's slice of a gather with the loads ORDERED: the first pass's loads, then `after_first()` (the wave's first refill
-// tiles -- straight-line code, so hipcc checks the tags with s_waitcnt vmcnt(<those tiles>), not vmcnt(0)), then the tags.
-// If the first pass fails, `on_fail()` (the rest of the burst: HBM must not idle while e.g. attention runs) and the ordinary
-// polling loop.  Returns true if on_fail ran.
-template <int NLW, int NBP, bool NORM, class F1, class F2>
-__device__ __forceinline__ bool tk_gc_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
-                                           const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait, F1 after_first,
-                                           F2 on_fail) {
-    if constexpr (NLW == 0) { after_first(); return false; }
-    else {
-        float2 gn[NORM ? NLW : 1];
-        if constexpr (NORM) {
-#pragma unroll
-            for (int k = 0; k < NLW; ++k) gn[k] = *reinterpret_cast<const float2*>(gains + 2 * (first_pair + lane + k * WAVE));
-        }
-        const int e0 = 2 * (first_pair + lane);
-        const int d0 = tk_xoff<NBP>(e0);
-        auto pass = [&](auto first) -> bool {
-            tk_v4u r[NLW];
-#pragma unroll
-            for (int k = 0; k < NLW; ++k) r[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (first_pair + lane) * 16, k * WAVE * 16, 16);
-            if constexpr (decltype(first)::value) after_first();
-            bool ok = true;
-#pragma unroll
-            for (int k = 0; k < NLW; ++k) ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
-            if (!(__all(ok) || nowait)) return false;
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < NLW; ++k) {
-                const float x0 = __uint_as_float(r[k].x), x1 = __uint_as_float(r[k].z);
-                if (xraw) *reinterpret_cast<float2*>(xraw + e0 + k * 2 * WAVE) = make_float2(x0, x1);
-                if constexpr (NORM) {
-                    acc = fmaf(x0, x0, acc);
-                    acc = fmaf(x1, x1, acc);
-                    *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0 * gn[k].x, x1 * gn[k].y);
-                } else {
-                    *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(x0, x1);
-                }
-            }
-            if constexpr (NORM) *ss += acc;
-            return true;
-        };
-        if (pass(std::true_type())) return false;
-        on_fail();
-        for (unsigned spin = 1;; ++spin) {
-            if ((spin & 63) == 63) {
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
-                if (spin > TK_SPIN_LIMIT) {
-                    if (lane == 0) __hip_atomic_store(err, 0x600u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return true;
-                }
-            }
-            __builtin_amdgcn_s_sleep(LLMK_TK_POLL_SLEEP);
-            if (pass(std::false_type())) return true;
-        }
-    }
-}
-// streaming wave sw's slice of vector g (N granules), ring slots K .. K+LATE-1 of the phase just finished to refill around it
-template <class SH, int N, bool NORM, int K, int LATE, bool CLS>
-__device__ __forceinline__ void tk_gc_gather(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const unsigned long long* g, unsigned epoch,
-                                             float* xraw, float* xs, const float* gains, float* red8, int lane, bool nowait) {
-    static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
-    constexpr int NL = N / 128, B = NL / TK_WAVES, X = NL % TK_WAVES;
-    constexpr int NOW = SH::GF_NOW < LATE ? SH::GF_NOW : LATE;
-    const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
-    float ss = 0.f;
-    auto first = [&]() { tk_refill<SH, K, NOW, CLS>(r, a, l, c, sw, lane); };
-    auto rest = [&]() { tk_refill<SH, K + NOW, LATE - NOW, CLS>(r, a, l, c, sw, lane); };
-    bool rest_done;
-    if (sw < X) rest_done = tk_gc_part<B + 1, 0, NORM>(rs, sw * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, a.err, lane, nowait, first, rest);
-    else rest_done = tk_gc_part<B, 0, NORM>(rs, (X * (B + 1) + (sw - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, a.err, lane, nowait, first, rest);
-    if (!rest_done) rest();
-    if constexpr (NORM) {
-        ss = wave_sum(ss);
-        if (lane == 0) red8[sw] = ss;
-    }
-}
-// barrier A, x fragment, the phase's slots, barrier B -- WITHOUT the late refills (tk_gc_gather orders them)
-template <class SH, int K0, int S, bool WIDE = false>
-__device__ __forceinline__ void tk_gc_phase(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4, float* part, int lane) {
-    constexpr int LATE = S < SH::NB ? S : SH::NB, EARLY = S - LATE;
-    tk_barrier();
-    TkX<SH> x;
-    if constexpr (WIDE) x.load(xs4, (sw % SH::TPR_H) * SH::LPT, SH::LPR_H, lane);
-    else x.load(xs4, 0, SH::LPR_E, lane);
-    tk_run<SH, K0, EARLY, false>(r, a, l, c, sw, x, part, lane);
-    tk_eat<SH, K0 + EARLY, LATE>(r, x, part, lane);
-    tk_barrier();
-}
-template <class SH>
-__device__ __forceinline__ void tk_stream_gc(const TokenArgs& a, char* lds, int c, int sw, int lane, int tid) {
-    typedef TkLds<SH> LD;
-    typedef TkSched<SH> SC;
-    static_assert(!SH::Q4, "natural-order staging");
-    float* xs = reinterpret_cast<float*>(lds + LD::XS);
-    float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
-    const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
-    float* part = reinterpret_cast<float*>(lds + LD::PART);
-    float* red8 = reinterpret_cast<float*>(lds + LD::RED8);
-    const int L = a.L;
-    const int pos = a.tokpos ? a.tokpos[1] : a.pos_imm;
-    const unsigned ebase = (unsigned)(a.tokpos ? a.tokpos[2] : a.serial_imm) * (unsigned)(5 * L + 2);
-    const bool nosync = TK_DEBUG && (a.gflags & TKG_NOSYNC) != 0;
-    constexpr int HPC = TK_NCU / SH::NH;
-    const bool att_cu = (c % HPC) == ((c / HPC / SH::KVMUL) % HPC);
-    const int my_head = c / HPC;
-    constexpr int LQ = SH::SL_Q < SH::NB ? SH::SL_Q : SH::NB, LO = SH::SL_O < SH::NB ? SH::SL_O : SH::NB,
-                  LA = SH::SL_A < SH::NB ? SH::SL_A : SH::NB, SD = SC::SLP - SC::KD, LDD = SD < SH::NB ? SD : SH::NB;
-    constexpr int D = SH::GF_DELAY;
-
-    TkRing<SH> r;
-    tk_prime<SH, 0>(r, a, c, sw, lane);
-    for (int l = 0; l < L; ++l) {
-        const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
-        tk_gc_phase<SH, SC::KQ, SH::SL_Q>(r, a, l, c, sw, xs4, part, lane);
-        if (att_cu) {
-            TkAtt<SH> pa;
-            pa.prefetch(a, l, my_head, pos, tid);
-            tk_barrier();
-            tk_attention<SH>(a, lds, l, my_head, pos, tid, pa);
-            tk_barrier();
-            tk_refill<SH, SC::KQ + SH::SL_Q - LQ, LQ, false>(r, a, l, c, sw, lane);
-        } else {
-            tk_xb_delay();
-            tk_gc_gather<SH, SH::E, false, SC::KQ + SH::SL_Q - LQ, LQ, false>(r, a, l, c, sw, tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, lane, nosync);
-        }
-        tk_gc_phase<SH, SC::KO, SH::SL_O>(r, a, l, c, sw, xs4, part, lane);
-        if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
-        tk_gc_gather<SH, SH::E, true, SC::KO + SH::SL_O - LO, LO, false>(r, a, l, c, sw, tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, lane, nosync);
-        tk_gc_phase<SH, SC::KA, SH::SL_A>(r, a, l, c, sw, xs4, part, lane);
-        if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
-        tk_gc_gather<SH, SH::H, false, SC::KA + SH::SL_A - LA, LA, false>(r, a, l, c, sw, tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, lane, nosync);
-        tk_gc_phase<SH, SC::KD, SD, true>(r, a, l, c, sw, xs4, part, lane);
-        if (l + 1 < L) {
-            if (!att_cu) {
-                if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
-                tk_gc_gather<SH, SH::E, true, SC::KD + SD - LDD, LDD, false>(r, a, l, c, sw, tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, lane, nosync);
-            } else {
-                tk_refill<SH, SC::KD + SD - LDD, LDD, false>(r, a, l, c, sw, lane);
-            }
-        } else {
-            if constexpr (D > 0) __builtin_amdgcn_s_sleep(D);
-            tk_gc_gather<SH, SH::E, true, SC::KD + SD - LDD, LDD, false>(r, a, l, c, sw, tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_final(a, SH::E), red8, lane, nosync);
-        }
-    }
-    tk_phase<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
 template <class SH, bool GR = false>
@@ -2418,19 +1821,8 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         a.cn = SH::RPT * (SH::CB + (c < SH::CX ? 1 : 0));
         a.c0 = SH::RPT * (c * SH::CB + min(c, SH::CX));
     }
-    if constexpr (SH::Q4M) {
-        // the image blocks past the end of a K = H row (whole column parts are read) and their sums: zero for the whole launch
-        // (nobody writes them; first read in layer 0's w2 phase, several barriers from here)
-        char* img = lds + TkLds<SH>::XS;
-        for (int j = 0; j < 4; ++j)
-            for (int i = SH::NBLK_H * Q4M_PB + tid * 16; i < SH::NBI * Q4M_PB; i += TK_THREADS * 16)
-                *reinterpret_cast<uint4*>(img + j * SH::NBI * Q4M_PB + i) = make_uint4(0u, 0u, 0u, 0u);
-        float* x8 = reinterpret_cast<float*>(img + SH::NBI * Q4M_BLK);
-        for (int i = SH::NBLK_H + tid; i < SH::NBI; i += TK_THREADS) x8[i] = 0.f;
-    }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
     else if constexpr (SH::COOP) tk_stream_coop<SH>(a, lds, c, wid, lane, tid);
-    else if constexpr (SH::GCOOP) tk_stream_gc<SH>(a, lds, c, wid, lane, tid);
     else tk_stream<SH>(a, lds, c, wid, lane, tid);
 }
 

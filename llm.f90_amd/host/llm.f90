@@ -7,7 +7,7 @@
 !
 !   ./llm -m model.gguf [-p prompt] [-n tokens] [-t temperature] [-s tokenizer.bin] [-v]
 !         [--ak] [-d device] [--device-argmax] [--prefill] [--timings] [--seed N] [--stream-load] [--ngpu N]
-!         [--ngpu N [--tp-rccl]] [--gguf-eps] [--gguf-rope-base]
+!         [--ngpu N [--tp-rccl]] [--gguf-eps] [--gguf-rope-base] [--encode]
 !
 ! --ngpu N (the 70B configuration, SURVEY.md section 8e): this process becomes rank 0 of N, starts N-1 copies of itself
 ! (one process per GPU, devices d..d+N-1), every rank loads the file and keeps its shard, the ranks meet through a
@@ -36,6 +36,7 @@ module arg_parse
      logical :: tp_rccl           ! extension: RCCL ring collectives instead of the one-shot peer-memory ones
      logical :: gguf_eps, gguf_rope_base   ! extension: honour the file's rms epsilon / RoPE base (the reference hard-codes
                                            ! 1e-5 and 10000, llama2.f90:454,545)
+     logical :: encode_only       ! extension: print the prompt's 1-based token ids (bpe_encode) and stop -- no device needed
   end type args
 
 contains
@@ -65,6 +66,7 @@ contains
     a%tp_rccl = .false.
     a%gguf_eps = .false.
     a%gguf_rope_base = .false.
+    a%encode_only = .false.
 
     nargs = command_argument_count()
     i = 1
@@ -93,6 +95,7 @@ contains
        case ("--tp-rccl");           a%tp_rccl = .true.;       i = i + 1
        case ("--gguf-eps");          a%gguf_eps = .true.;      i = i + 1
        case ("--gguf-rope-base");    a%gguf_rope_base = .true.; i = i + 1
+       case ("--encode");            a%encode_only = .true.;   i = i + 1
        case default
           print *, "Unrecognized option:", trim(opt)
           stop
@@ -128,17 +131,13 @@ module token_stream
   character(:), dimension(:), allocatable :: ts_vocab
   integer(4), allocatable :: ts_len(:)
   logical :: ts_print = .true.
-  real :: ts_first = 0                  ! the host's time_ms() at the first streamed token (0: none yet)
+  integer(8) :: ts_first = 0            ! the host's clock_ticks() at the first streamed token (0: none yet)
 contains
   subroutine ts_on_token(idx, tok, user) bind(C)
     integer(c_int), value :: idx, tok
     type(c_ptr), value :: user
-    integer(4) :: ticks
     if (ts_print) write (*, fmt="(A)", advance="no") ts_vocab(tok)(1:ts_len(tok))
-    if (ts_first == 0) then
-       call system_clock(ticks)          ! the same clock as time_ms() (llama2.f90:417-425)
-       ts_first = real(ticks)
-    end if
+    if (ts_first == 0) call system_clock(ts_first)        ! the same clock as clock_ticks()
   end subroutine
 end module token_stream
 
@@ -171,7 +170,8 @@ program llm
   integer :: pos0, k, loop_end
   integer :: seq_len, pos, token, next_tok, l, hs, j, max_len
   integer(c_int) :: flags, rc
-  real(kind=wp) :: t_start, t_end
+  integer(8) :: t_start, t_end                      ! clock_ticks(): see elapsed_ms
+  real(kind=wp) :: dt_ms
   real(c_float) :: ktimes(5)
   logical :: lead                                   ! this rank prints (rank 0, or the only process)
   integer, allocatable :: hash_tab(:)               ! open-addressing index over vocab (lookup)
@@ -199,6 +199,11 @@ program llm
   if (opts%tokenizer /= "") call read_tokenizer_bin(opts%tokenizer)
   max_len = maxval(vocab_len)
   call build_lookup()
+  if (opts%encode_only) then                        ! the tokenizer alone (llama2.f90:372): ids on one line, no device
+     prompt_tokens = bpe_encode(opts%prompt)
+     print '(*(I0,1X))', prompt_tokens
+     stop
+  end if
   if (opts%seed >= 0) call seed_sampler(opts%seed)
 
   ! ---- device context + one-time weight upload (the host arrays are not needed afterwards) -----
@@ -260,7 +265,7 @@ program llm
      allocate(batch(k + 1))
      batch(1) = 2
      batch(2:) = int(prompt_tokens, c_int)
-     t_start = time_ms()       ! the clock covers the prompt pass: tokens/second counts those positions too (llama2.f90:405)
+     t_start = clock_ticks()   ! the clock covers the prompt pass: tokens/second counts those positions too (llama2.f90:405)
      call llmk_check(llmk_prefill(ctx, batch, int(k + 1, c_int), 1_c_int, logits), "llmk_prefill")
      if (lead) then
         do pos = 1, k
@@ -296,7 +301,7 @@ program llm
      end if
      token = next_tok
      if (lead) write (*, fmt="(A)", advance="no") vocab(token)(1:vocab_len(token))
-     if (t_start == 0) t_start = time_ms()           ! clock starts after the first token
+     if (t_start == 0) t_start = clock_ticks()       ! clock starts after the first token
   end do
   if (loop_end < seq_len) then
      allocate(stream_ids(seq_len - loop_end))
@@ -308,14 +313,15 @@ program llm
      token = stream_ids(size(stream_ids))
      if (t_start == 0) t_start = ts_first
   end if
-  t_end = time_ms()
+  t_end = clock_ticks()
+  dt_ms = elapsed_ms(t_start, t_end)
 
   call llmk_check(llmk_timings(ctx, ktimes), "llmk_timings")
   s%times = ktimes
   if (lead) then
      print *, ""
-     print *, "Inference time: ", (t_end - t_start) / 1000, " seconds"
-     print *, 1000 * (seq_len - 1) / (t_end - t_start), "tokens/second"
+     print *, "Inference time: ", dt_ms / 1000, " seconds"
+     print *, 1000 * (seq_len - 1) / dt_ms, "tokens/second"
      print *, "Timings"
      do l = 1, 5
         print *, l, s%times(l) / seq_len
@@ -372,13 +378,22 @@ contains
     deallocate(weights%token_embedding_table)
   end subroutine upload_weights
 
-  ! wall clock in ms, 4-byte count like the reference (llama2.f90:417-423)
-  function time_ms() result(t_ms)
-    real(kind=wp) :: t_ms
-    integer(4) :: ticks
-    call system_clock(ticks)
-    t_ms = real(ticks)
-  end function time_ms
+  ! Wall clock.  The reference converts a 4-byte millisecond count to real(4) BEFORE subtracting (llama2.f90:417-423):
+  ! a count of ~1e9 has a 64-128 ms quantum as a float, which is nothing against its 60 s runs and everything against a
+  ! 0.17 s run of 256 tokens on the GPU.  Same two printed lines, same real(4) list-directed format; the difference is taken
+  ! in 8-byte ticks first (microseconds or finer with amdflang).
+  function clock_ticks() result(t)
+    integer(8) :: t
+    call system_clock(t)
+    if (t == 0) t = 1                    ! 0 means "clock not started yet" in the generation loop
+  end function clock_ticks
+  function elapsed_ms(t0, t1) result(ms)
+    integer(8), intent(in) :: t0, t1
+    real(kind=wp) :: ms
+    integer(8) :: rate
+    call system_clock(count_rate=rate)
+    ms = real(1000.0d0 * real(t1 - t0, 8) / real(rate, 8), kind=wp)
+  end function elapsed_ms
 
   ! llama2.c tokenizer.bin: max_len, then (f32 score, i32 len, bytes) per token (llama2.f90:321-356)
   subroutine read_tokenizer_bin(path)

@@ -422,6 +422,34 @@ def vocab_strings(V: int) -> List[bytes]:
     return out
 
 
+# A vocabulary with real merges (round-4 verdict: `bpe_encode`'s greedy best-score loop, llama2.f90:658-724, was never run on a
+# vocabulary where a merge exists).  The single characters stay where vocab_strings puts them; these strings replace the
+# placeholder tokens from id 100 on.  What each group pins:
+#   * plain merges at several levels ("t"+"h" -> "th", "th"+"e" -> "the", " "+"the" -> " the"): the best score ANYWHERE in the
+#     text wins, not the leftmost pair;
+#   * "in" / "ng" carry EQUAL scores and "ing" does not exist: "ing" must end as ["in", "g"] (strict `>` keeps the FIRST pair,
+#     llama2.f90:694); "an" / "nd" are equal too but "and" exists through "an"+"d" only;
+#   * "er" is in the vocabulary TWICE with different scores: the linear scan of `lookup` (llama2.f90:643-655) returns the
+#     first index, so the first entry's score decides ("er" outranks "he" only with the SECOND entry's score).
+MERGE_TOKENS = [
+    (b"th", -1.0), (b"he", -2.0), (b"the", -1.5), (b" the", -0.5), (b"in", -3.0), (b"ng", -3.0), (b"an", -4.0), (b"nd", -4.0),
+    (b"and", -3.5), (b"er", -6.0), (b"er", -0.25), (b"ot", -5.0), (b"oth", -4.5), (b"other", -0.75), (b" a", -7.0), (b"sa", -8.0),
+    (b"nn", -9.0), (b"hi", -2.5), (b"thi", -9.5), (b" t", -10.0),
+]
+MERGE_FIRST = 100
+
+
+def merge_vocab(V: int):
+    """(tokens, scores) = vocab_strings with MERGE_TOKENS from id MERGE_FIRST on; every other score stays -id."""
+    assert V >= MERGE_FIRST + len(MERGE_TOKENS) and V >= 200
+    vocab = vocab_strings(V)
+    scores = -np.arange(V, dtype="<f4")
+    for k, (t, sc) in enumerate(MERGE_TOKENS):
+        vocab[MERGE_FIRST + k] = t
+        scores[MERGE_FIRST + k] = sc
+    return vocab, scores
+
+
 def _tensor_source(fw: "FusedWeights", name: str) -> np.ndarray:
     """Encoded bytes of one GGUF tensor, sliced out of the fused arrays (inverse of load_fused)."""
     s = fw.shape
@@ -597,9 +625,9 @@ def write_tokenizer_bin(path: str, vocab: List[bytes], scores=None) -> None:
 
 
 def write_synth_gguf(path: str, shape: LlamaShape, seed: int, ggml_type: int = GGML_F32,
-                     alignment: int = 32, version: int = 3) -> None:
+                     alignment: int = 32, version: int = 3, vocab: List[bytes] = None, scores=None) -> None:
     """Synthetic Llama GGUF: tensor bytes are a pure function of (shape, seed, type)."""
-    write_gguf(path, synth_fused(shape, seed, ggml_type), alignment, version)
+    write_gguf(path, synth_fused(shape, seed, ggml_type), alignment, version, vocab=vocab, scores=scores)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -97,3 +97,27 @@ class Oracle:
         if rc:
             raise ValueError(f"oracle_generate rc={rc}")
         return toks, logits
+
+
+def bpe_encode_ref(text: bytes, vocab, scores):
+    """TEST INFRASTRUCTURE -- the reference's tokenizer restated (llama2.f90:643-724), 1-based ids.
+
+    lookup (:643-655) is a linear scan that returns the FIRST entry with the same bytes and length;
+    bpe_encode starts from one token per byte (:666-668), then repeatedly replaces the adjacent pair whose
+    concatenation is the best-scoring vocabulary entry -- `score > best_score` from -1e10, so among equal
+    scores the FIRST pair wins (:689-700) -- until no pair is in the vocabulary (:703-705).
+    Pinned by tests/golden/make_golden.py: the real reference fed these ids must print this text AND the
+    oracle teacher-forced with them must reproduce the reference's logits (tests/test_oracle.py)."""
+    first = {}
+    for i, t in enumerate(vocab):
+        first.setdefault(bytes(t), i + 1)
+    toks = [first[text[i:i + 1]] for i in range(len(text))]     # (a byte without a token: the reference indexes vocab_len(-1))
+    while True:
+        best_score, best_i, best_tok = -1e10, -1, -1
+        for i in range(len(toks) - 1):
+            cand = first.get(bytes(vocab[toks[i] - 1]) + bytes(vocab[toks[i + 1] - 1]))
+            if cand is not None and float(scores[cand - 1]) > best_score:
+                best_score, best_i, best_tok = float(scores[cand - 1]), i, cand
+        if best_i < 0:
+            return toks
+        toks[best_i:best_i + 2] = [best_tok]

@@ -15,7 +15,7 @@ GOLDEN_CASES = ["tiny-gqa", "tiny-gqa-prompt", "tiny-mha", "tiny-hs64", "tiny-hs
                 # long contexts from the real reference: KV lengths cross the attention kernels' timestep tiles
                 "tk-small-long", "tk-small-long-prompt", "tiny-hs128-long"]
 # full-size TinyLlama-1.1B from the real reference, reduced to ids + top-8 + 64 probe columns + checksums per position
-GOLDEN_COMPACT = ["tinyllama"]
+GOLDEN_COMPACT = ["tinyllama", "tinyllama-f16dec"]
 
 # Parity bar (BASELINE.json north_star): logits within 1e-4 relative of the reference CPU path,
 # bit-exact argmax at temperature 0.  "Relative" is measured against the logit scale

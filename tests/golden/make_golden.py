@@ -50,14 +50,25 @@ CASES = [
     # f32 only -- as a 27 GB GGUF, 24 positions through llm_ref_llama2-7b (dims patched, oracle/Makefile).
     # Needs ~35 GB of RAM and ~30 GB of scratch disk; run it by name: make_golden.py llama2-7b
     ("llama2-7b", 40, "Q4COMPACT:Llama-2 7B, q4_0: full depth!"),     # 30 prompt tokens (all different characters would be dull: repeats included), then 10 greedy ones
+    # bpe_encode's merge loop (llama2.f90:658-724) on a vocabulary WITH merges (tools/gguf.py merge_vocab: several levels,
+    # an equal-score pair for the tie rule, a duplicated entry for lookup's first-index rule): round-4 verdict, "missing" 1
+    ("tiny-gqa", 56, "MERGE:the thing in the inn and another thing sang her other"),
+    # BASELINE.json configs[2] at FULL size from the real reference (round-4 verdict, "missing" 4): TinyLlama's matrices
+    # rounded to f16 and decoded back to f32 -- the values the f16 kernels multiply with -- through the unmodified-dims binary
+    ("tinyllama", 96, "F16DEC"),
 ]
 LONG_PROMPT = "".join(chr(33 + (7 * i + i // 13) % 90) for i in range(256))   # 256 printable non-blank characters
 PROBE_SEED = 12345
 
 
-def prompt_ids(prompt: str):
-    """1-based ids bpe_encode (llama2.f90:658-724) yields on the synthetic vocab: one token per
-    character (printable ASCII c -> 0-based id 3 + ord(c) - 32); no merged token exists."""
+def prompt_ids(prompt: str, vocab=None, scores=None):
+    """1-based ids bpe_encode (llama2.f90:658-724) yields.  On the plain synthetic vocab: one token per character
+    (printable ASCII c -> 0-based id 3 + ord(c) - 32; no merged token exists).  On a vocabulary with merges: the restated
+    merge loop (oracle/oracle.py bpe_encode_ref) -- checked below against what the reference printed and, through the
+    oracle's teacher-forced logits (tests/test_oracle.py), against what it computed."""
+    if vocab is not None:
+        from oracle.oracle import bpe_encode_ref
+        return bpe_encode_ref(prompt.encode(), vocab, scores)
     return [3 + ord(c) - 32 + 1 for c in prompt]
 
 
@@ -67,15 +78,27 @@ def main():
     with tempfile.TemporaryDirectory(dir=os.environ.get("LLMK_GOLDEN_TMP")) as td:
         only = set(sys.argv[1:])
         for name, n, prompt in CASES:
-            if only and name not in only:
+            tag0 = name + ("-f16dec" if prompt == "F16DEC" else "-merge" if prompt.startswith("MERGE:") else "")
+            if only and name not in only and tag0 not in only:
                 continue
+            if only and tag0 in only and name not in only and tag0 == name:
+                continue
+            if only and name in only and tag0 != name and tag0 not in only and (name + "-all") not in only:
+                continue                      # `make_golden.py tinyllama` keeps meaning the plain case; ask for tinyllama-f16dec by tag
             s = gguf.SHAPES[name]
             verbose = prompt.startswith("VERBOSE")
             ak = prompt in ("ak", "VERBOSE-ak")
             if verbose:
                 prompt = "ak" if ak else ""
             q4dec = prompt.startswith("Q4COMPACT")
-            compact = prompt == "COMPACT" or q4dec
+            merge = prompt.startswith("MERGE:")
+            f16dec = prompt == "F16DEC"
+            compact = prompt == "COMPACT" or q4dec or f16dec
+            mvocab, mscores = gguf.merge_vocab(s.vocab_size) if merge else (None, None)
+            if merge:
+                prompt = prompt.partition(":")[2]
+            if f16dec:
+                prompt = ""
             if q4dec and name not in only:
                 continue                      # the 27 GB case only when asked for by name
             if compact:
@@ -91,6 +114,12 @@ def main():
             elif q4dec:
                 path = os.path.join(td, name + ".gguf")
                 gguf.write_synth_q4_decoded_f32_gguf(path, s, SEED, scale_jitter=True)
+            elif f16dec:
+                path = os.path.join(td, name + "-f16dec.gguf")
+                gguf.write_gguf(path, gguf.synth_fused(s, SEED, gguf.GGML_F16).as_f32())
+            elif merge:
+                path = os.path.join(td, name + "-merge.gguf")
+                gguf.write_synth_gguf(path, s, SEED, vocab=mvocab, scores=mscores)
             else:
                 path = os.path.join(td, name + ".gguf")
                 gguf.write_synth_gguf(path, s, SEED)
@@ -107,9 +136,10 @@ def main():
                 continue
             r = subprocess.run(cmd, cwd=td, capture_output=True, check=True)
             logits = np.fromfile(os.path.join(td, "logits.bin"), dtype="<f4").reshape(n, s.vocab_size)
-            pids = prompt_ids(prompt)
+            pids = prompt_ids(prompt, mvocab, mscores)
+            assert len(pids) < n
             toks = [pids[i] if i < len(pids) else int(np.argmax(logits[i])) + 1 for i in range(n)]
-            vocab = gguf.vocab_strings(s.vocab_size)
+            vocab = mvocab if merge else gguf.vocab_strings(s.vocab_size)
             text = b"".join(vocab[t - 1] for t in toks)
             lines = r.stdout.split(b"\n")
             if ak:
@@ -118,7 +148,7 @@ def main():
                 assert lines[0].strip().startswith(b"data offset"), lines[0]
                 assert lines[1].rstrip(b" ") == text, (lines[1], text)   # reference printed the same tokens
             srt = np.sort(logits, axis=1)
-            tag = name + ("-ak" if ak else "-prompt" if prompt else "")
+            tag = name + ("-ak" if ak else "-f16dec" if f16dec else "-merge" if merge else "-prompt" if prompt else "")
             if compact:
                 # full-size case: per position the greedy id, the 8 largest logits, 64 fixed probe columns and three
                 # checksums (sum, l2 norm, max |logit|) in f64 -- enough to pin 1e-4 parity without 41 MB of floats
@@ -126,7 +156,8 @@ def main():
                 probe = np.sort(np.random.default_rng(PROBE_SEED).choice(s.vocab_size, 64, replace=False)).astype(np.int32)
                 l64 = logits.astype(np.float64)
                 np.savez_compressed(os.path.join(outdir, tag + ".npz"), shape=name, seed=SEED, n=n, prompt=prompt, ak=ak,
-                                    weights="synth_fused_q4_direct(scale_jitter) decoded to f32" if q4dec else "synth_fused f32",
+                                    weights="synth_fused_q4_direct(scale_jitter) decoded to f32" if q4dec else
+                                    "synth_fused f16 decoded to f32" if f16dec else "synth_fused f32",
                                     prompt_ids=np.asarray(pids, np.int32), tokens=np.asarray(toks, np.int32),
                                     stdout=np.frombuffer(r.stdout, np.uint8), top1_margin=(srt[:, -1] - srt[:, -2]),
                                     top8_idx=top8, top8_val=np.take_along_axis(logits, top8, axis=1),

@@ -35,3 +35,15 @@ def test_driver_invocation_prints_one_contract_line():
     if cb["kind"] == "reference":
         same, n = d["ids_match"].split("/")                    # the timed loop's ids against the real reference's transcript
         assert same == n and int(n) >= 20, d["ids_match"]
+    # the drop-in itself (round-4 verdict, item 3): the Fortran `llm` CLI on the same GGUF, -n 256 -t 0, its own tokens/second line
+    fh = d["fortran_host"]
+    assert "error" not in fh, fh
+    same, n = fh["ids_match"].split("/")
+    assert same == n and int(n) >= 25, fh
+    same, n = fh["ids_match_device_argmax"].split("/")
+    assert same == n, fh
+    # The CLI's rate covers positions 2..256 (mean KV length ~129), the 20-step line positions 6..25: the kernel is ~3 % slower at
+    # the longer context (663 -> 683 us from KV length 1 to 256), so the bar against THIS line is 6 %; against a
+    # 248-step line (bench.py's default, same positions) it is the verdict's 3 %: tests/test_host_gpu.py.
+    assert fh["tok_s"] > 0.94 * d["value"], (fh, d["value"])
+    assert fh["tok_s_device_argmax"] >= 0.97 * fh["tok_s"], fh

@@ -232,3 +232,38 @@ def test_verbose_loader_lines_are_the_reference_s(tools, gguf, ak):
     ref = bytes(g["stdout"]).split(b"\n")
     k = ref.index(b" Loaded weights") + 1
     assert r.stdout.split(b"\n")[:k] == ref[:k]
+
+
+def test_fortran_bpe_encode_matches_the_reference_on_a_vocabulary_with_merges(tools, gguf):
+    """`llm --encode` prints what the host's bpe_encode returns (no device needed).  tests/golden/tiny-gqa-merge.npz holds the
+    ids the REAL reference used on the same vocabulary (pinned through its logits, tests/test_oracle.py): greedy best-score
+    merging over several levels, the first pair on equal scores (llama2.f90:694), and the first index of a duplicated entry
+    (llama2.f90:648-651) -- which the host's hashed lookup has to reproduce.  Also through `-s tokenizer.bin` (llama2.f90:321-356)."""
+    g = load_golden("tiny-gqa-merge")
+    s = gguf.SHAPES["tiny-gqa"]
+    vocab, scores = gguf.merge_vocab(s.vocab_size)
+    path = str(tools["dir"] / "merge.gguf")
+    gguf.write_synth_gguf(path, s, int(g["seed"]), vocab=vocab, scores=scores)
+
+    def ids(prompt, extra=()):
+        r = subprocess.run([tools["llm"], "-m", path, "-p", prompt, "--encode", *extra], capture_output=True)
+        lines = r.stdout.split(b"\n")
+        assert lines[0].startswith(b" data offset"), r.stdout + r.stderr
+        return [int(x) for x in lines[1].split()]
+    assert ids(str(g["prompt"])) == g["prompt_ids"].tolist()
+    words = lambda p: [vocab[i - 1] for i in ids(p)]
+    assert words("ing") == [b"in", b"g"]
+    assert words("her") == [b"he", b"r"]
+    assert words("other") == [b"o", b"the", b"r"]
+    assert words(" the") == [b" the"] and words("and") == [b"and"]
+    assert ids("") == []
+    # a plain vocabulary through the same loop: one token per character
+    plain = str(tools["dir"] / "plain.gguf")
+    gguf.write_synth_gguf(plain, s, int(g["seed"]))
+    r = subprocess.run([tools["llm"], "-m", plain, "-p", "hi there", "--encode"], capture_output=True)
+    assert [int(x) for x in r.stdout.split(b"\n")[1].split()] == load_golden("tiny-gqa-prompt")["prompt_ids"].tolist()
+    # the same merges with the tokenizer read from tokenizer.bin over a plain-vocabulary file
+    tok = str(tools["dir"] / "merge.tok")
+    gguf.write_tokenizer_bin(tok, vocab, scores)
+    r = subprocess.run([tools["llm"], "-m", plain, "-s", tok, "-p", str(g["prompt"]), "--encode"], capture_output=True)
+    assert [int(x) for x in r.stdout.split(b"\n")[1].split()] == g["prompt_ids"].tolist()

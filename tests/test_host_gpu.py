@@ -39,6 +39,24 @@ def test_cli_output_matches_reference_transcript(tag, gguf, tmp_path):
     assert [l.split()[0] for l in out[k + 3:k + 8]] == [b"1", b"2", b"3", b"4", b"5"]   # same 5 timer lines
 
 
+@pytest.mark.parametrize("extra", [[], ["--prefill"], ["--device-argmax"]], ids=["loop", "prefill", "device-argmax"])
+def test_cli_on_a_vocabulary_with_merges_matches_the_reference_transcript(extra, gguf, tmp_path):
+    """The tokenizer end to end (round-4 verdict "missing" 1): a vocabulary WITH merges
+    (tools/gguf.py merge_vocab), a prompt that exercises them; the real reference's stdout (tests/golden/tiny-gqa-merge.npz)
+    byte for byte.  A different tokenization would print the same prompt text but continue with other tokens, and fewer
+    or more of them: 56 positions = 32 prompt tokens + 24 greedy ones."""
+    g = load_golden("tiny-gqa-merge")
+    s = gguf.SHAPES[str(g["shape"])]
+    vocab, scores = gguf.merge_vocab(s.vocab_size)
+    path = str(tmp_path / "m.gguf")
+    gguf.write_synth_gguf(path, s, int(g["seed"]), vocab=vocab, scores=scores)
+    out = _run(["-m", path, "-n", str(int(g["n"])), "-t", "0", "-p", str(g["prompt"])] + extra, str(tmp_path)).split(b"\n")
+    ref = bytes(g["stdout"]).split(b"\n")
+    k = next(i for i, l in enumerate(ref) if l.startswith(b" Inference time:"))
+    assert out[:k] == ref[:k]
+    assert len(g["prompt_ids"]) == 32 and b"".join(vocab[t - 1] for t in g["tokens"]) == ref[1].rstrip(b" ")   # (the golden is what the docstring says)
+
+
 @pytest.mark.parametrize("tag", ["tiny-gqa-verbose", "tiny-gqa-ak-verbose"])
 def test_cli_verbose_output_matches_reference_transcript(tag, gguf, tmp_path):
     """`-v`: the whole transcript -- the loader's lines, "Loaded weights", the generated text -- is the reference's, byte for
@@ -215,3 +233,20 @@ def test_cli_stream_load_q6k_output_weight(gguf, tmp_path):
     gguf.write_gguf(path, fw, output_q6k=True)
     args = ["-m", path, "-n", "16", "-t", "0"]
     assert _run(args, str(tmp_path)).split(b"\n")[1] == _run(args + ["--stream-load"], str(tmp_path)).split(b"\n")[1]
+
+
+def test_fortran_cli_rate_is_the_ctypes_rate_at_full_tinyllama_size():
+    """Round-4 verdict, item 3: the headline number is taken through ctypes (bench.py), the product is the Fortran program.
+    bench.py's `fortran_host` leg runs `llm -m <4.4 GB synthetic gguf> -n 256 -t 0` (and --device-argmax) on the same weights
+    and parses the tokens/second line the drop-in prints (llama2.f90:406 convention); both loops cover positions ..256: the
+    CLI's rate must be within 3 % of the ctypes rate, and its transcript identical."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--fortran-host"], capture_output=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:].decode(errors="replace")
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    fh = d["fortran_host"]
+    assert "error" not in fh, fh
+    assert fh["ids_match"] == "256/256" and fh["ids_match_device_argmax"] == "256/256", fh
+    assert fh["tok_s"] >= 0.97 * d["value"], (fh, d["value"])
+    assert fh["tok_s_device_argmax"] >= 0.97 * fh["tok_s"], fh

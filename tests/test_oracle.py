@@ -23,12 +23,40 @@ def test_oracle_matches_reference(tag, flavour, gguf):
     assert np.array_equal(toks, g["tokens"])            # bit-exact greedy ids (1-based)
 
 
-def test_oracle_matches_reference_at_full_tinyllama_size(gguf):
+def test_reference_tokenizer_restatement_on_a_vocabulary_with_merges(gguf):
+    """tests/golden/tiny-gqa-merge.npz: the real reference on a vocabulary WITH merges (tools/gguf.py merge_vocab).  Its
+    prompt ids are not observable directly -- merged or not, the prompt prints the same text -- but its LOGITS are: the oracle
+    teacher-forced with the ids of the restated merge loop (oracle.bpe_encode_ref, llama2.f90:658-724) reproduces them, and the
+    number of prompt positions fixes where the greedy tokens start.  The rules the vocabulary was built to expose hold."""
+    from oracle.oracle import bpe_encode_ref
+    g = load_golden("tiny-gqa-merge")
+    shape = gguf.SHAPES[str(g["shape"])]
+    vocab, scores = gguf.merge_vocab(shape.vocab_size)
+    pids = bpe_encode_ref(str(g["prompt"]).encode(), vocab, scores)
+    assert pids == g["prompt_ids"].tolist() and len(pids) < len(str(g["prompt"]))      # merges happened
+    toks, logits = Oracle(gguf.synth_fused(shape, int(g["seed"])), "strict").generate(int(g["n"]), prompt=pids)
+    assert rel_err(logits, g["logits"]).max() <= 1e-5
+    assert np.array_equal(toks, g["tokens"])
+    # one token per character instead (no merging) is a different computation: the golden discriminates
+    flat = [3 + c - 32 + 1 for c in str(g["prompt"]).encode()][:int(g["n"])]
+    _, l2 = Oracle(gguf.synth_fused(shape, int(g["seed"])), "strict").generate(int(g["n"]), prompt=flat)
+    assert rel_err(l2, g["logits"]).max() > 1e-2
+    words = lambda t: [vocab[i - 1] for i in bpe_encode_ref(t, vocab, scores)]
+    assert words(b"ing") == [b"in", b"g"]                    # equal scores: the FIRST pair wins (llama2.f90:694)
+    assert words(b"her") == [b"he", b"r"]                    # duplicated "er": the first entry's score counts (llama2.f90:648-651)
+    assert words(b"other") == [b"o", b"the", b"r"]           # ... with the second entry's score it would be ["other"]
+    assert words(b" the") == [b" the"] and words(b"and") == [b"and"]
+
+
+@pytest.mark.parametrize("tag", ["tinyllama", "tinyllama-f16dec"])
+def test_oracle_matches_reference_at_full_tinyllama_size(tag, gguf):
     """BASELINE.json configs[0]: the real reference at its compiled-in TinyLlama-1.1B dims, 320 positions on the synthetic
     weights bench.py uses (compact golden).  The oracle replays the first positions teacher-forced with the reference's
-    own tokens (a CPU token is ~0.3 s here; the GPU tests replay all 320)."""
-    g = load_golden("tinyllama")
-    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
+    own tokens (a CPU token is ~0.3 s here; the GPU tests replay all 320).  `-f16dec` (configs[2]): the same run on the
+    matrices rounded to f16 and decoded back -- what the oracle is handed when it checks the f16 kernels."""
+    g = load_golden(tag)
+    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]), 1).as_f32() if tag.endswith("f16dec") else \
+        gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
     n = 12
     toks, logits = Oracle(fw, "omp").generate(n, prompt=g["tokens"][:n].tolist())
     err = compact_err(logits, g, n)

