@@ -31,6 +31,7 @@
 using namespace llmk;
 
 extern "C" int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** out);
+static int q16_build(llmk_ctx* c);        // (defined behind the upload helpers it uses)
 
 #define HIPCHK(expr)                                          \
     do {                                                      \
@@ -131,6 +132,12 @@ struct llmk_ctx {
     void* up_stage_dev[2] = {nullptr, nullptr};      // the same buffers as the device addresses them
     void* up_tmp[2] = {nullptr, nullptr};            // device scratch of the q4_0 re-packing (written and read by kernels only)
     hipEvent_t up_done[2] = {nullptr, nullptr};
+    unsigned long long* up_acc = nullptr;            // device word of the upload verification's 16-bit word sums
+    bool up_ready = false;                           // all of the above exist (set only after every allocation succeeded)
+    // q4_0 matrices in the persistent kernel's UNIT layout (q4_units.h: 16 rows x 32 blocks as matrix-core operands), built from
+    // the row layout -- which the multi-kernel path, the prefill and the fallback keep reading -- at the first token after an upload
+    void* q16[LLMK_N_TENSORS] = {};
+    bool q16_dirty = true;
     bool pf_hm = false;                    // GEMMs on v_mfma_f32_16x16x32_f16, activations (and f32 / q4_0 weights) as two f16 pieces (prefill.h)
     unsigned* pf_flag = nullptr;           // device word: an activation did not fit f16 (the call is redone on the f32 instruction)
 };
@@ -340,11 +347,12 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
     a.gflags = g.gflags | ((TK_DEBUG && getenv("LLMK_TK_NOSYNC")) ? TKG_NOSYNC : 0);   // NOSYNC: libllmk_debug.so only
     a.emb = (const float*)c->t[LLMK_TOKEN_EMBEDDING_TABLE].data;
     a.rms = (const float*)c->t[LLMK_RMS_ATT_WEIGHT].data;      // att | ffn | final in one allocation (llmk_create_tp)
-    a.wqkv = c->t[LLMK_WQKV].data;
-    a.wo = c->t[LLMK_WO].data;
-    a.w13 = c->t[LLMK_W13].data;
-    a.w2 = c->t[LLMK_W2].data;
-    a.wcls = c->t[LLMK_WCLS].data;
+    // q4_0: the unit layout (check_ready built it)
+    a.wqkv = TK::Q4 ? c->q16[LLMK_WQKV] : c->t[LLMK_WQKV].data;
+    a.wo = TK::Q4 ? c->q16[LLMK_WO] : c->t[LLMK_WO].data;
+    a.w13 = TK::Q4 ? c->q16[LLMK_W13] : c->t[LLMK_W13].data;
+    a.w2 = TK::Q4 ? c->q16[LLMK_W2] : c->t[LLMK_W2].data;
+    a.wcls = TK::Q4 ? c->q16[LLMK_WCLS] : c->t[LLMK_WCLS].data;
     a.kc = c->d_kc;
     a.vc = c->d_vc;
     a.rope = c->d_rope;
@@ -568,6 +576,7 @@ int check_ready(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     for (int i = 0; i < LLMK_N_TENSORS; ++i)
         if (!c->t[i].uploaded) return LLMK_E_STATE;
+    if (c->use_tk && c->tk_shape == 5 && c->q16_dirty) return q16_build(c);
     return LLMK_OK;
 }
 
@@ -584,8 +593,12 @@ int tk_retire(llmk_ctx* c, unsigned code, int pos) {
     c->tk_retired = true;
     if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }
     if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
-    fprintf(stderr, "llmk: the persistent token kernel timed out waiting for its peer workgroups (code 0x%x, position %d); "
-                    "this context continues on the multi-kernel path\n", code, pos);
+    // what the sticky word says (token_kernel.h): 0x2000 no finite candidate among the classifier maxima (pipelined greedy decode),
+    // 0x4000 an activation beyond the f16 range of the q4_0 kernels' x image, anything else a bounded spin that ran out
+    const char* what = (code & 0x2000u) ? "found no finite logit among its candidates"
+                     : (code & 0x4000u) ? "met an activation beyond the f16 range of its matrix-core operands"
+                                        : "timed out waiting for its peer workgroups";
+    fprintf(stderr, "llmk: the persistent token kernel %s (code 0x%x, position %d); this context continues on the multi-kernel path\n", what, code, pos);
     return LLMK_OK;
 }
 
@@ -1143,6 +1156,49 @@ static hipError_t device_sum16(const void* dev, size_t nbytes, unsigned long lon
     return e;
 }
 
+// q4_0 + persistent kernel: (re)build the unit layout of the five matrices from their rows; with the upload verification on,
+// the 16-bit word sum of every unit image must equal that of the rows it was built from (the padding blocks are zeros)
+static int q16_build(llmk_ctx* c) {
+    static const int mats[5] = {LLMK_WQKV, LLMK_WO, LLMK_W13, LLMK_W2, LLMK_WCLS};
+    for (int i = 0; i < 5; ++i) {
+        const int tid = mats[i];
+        const TensorDesc& d = c->desc[tid];
+        const DevTensor& t = c->t[tid];
+        if (t.type != LLMK_TYPE_Q4_0 || d.rows % Q16_ROWS) return LLMK_E_SHAPE;
+        const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1), bytes = q16_bytes(rows, d.K);
+        if (!c->q16[tid]) {
+            HIPCHK(dev_alloc(&c->q16[tid], bytes + TENSOR_SLACK));
+            HIPCHK(hipMemset((char*)c->q16[tid] + bytes, 0, TENSOR_SLACK));
+        }
+        hipLaunchKernelGGL(q16_units_kernel, dim3((unsigned)(bytes / Q16_UNIT_BYTES)), dim3(64), 0, c->stream, (const char*)t.data, t.row_bytes, d.K,
+                           q16_ncs(d.K), (char*)c->q16[tid]);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (verify_uploads()) {
+        unsigned long long* d_acc = nullptr;
+        HIPCHK(dev_alloc(&d_acc, sizeof(*d_acc)));
+        int rc = LLMK_OK;
+        for (int i = 0; i < 5 && rc == LLMK_OK; ++i) {
+            const int tid = mats[i];
+            const TensorDesc& d = c->desc[tid];
+            const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1);
+            unsigned long long a = 0, b = 0;
+            hipError_t e = device_sum16(c->t[tid].data, rows * c->t[tid].row_bytes, d_acc, &a);
+            if (e == hipSuccess) e = device_sum16(c->q16[tid], q16_bytes(rows, d.K), d_acc, &b);
+            if (e != hipSuccess) rc = LLMK_E_HIP + (int)e;
+            else if (a != b) {
+                fprintf(stderr, "llmk: the unit layout of tensor %d differs from its rows (16-bit word sums 0x%llx / 0x%llx)\n", tid, b, a);
+                rc = LLMK_E_VERIFY;
+            }
+        }
+        hipFree(d_acc);
+        if (rc) return rc;
+    }
+    c->q16_dirty = false;
+    return LLMK_OK;
+}
+
 // Copy `nrows` rows of a HOST tensor (row pitch `spitch` bytes in `type` encoding; for each row only the
 // bytes [col_off, col_off + col_bytes) -- a contraction slice for the row-parallel wo / w2) into local rows
 // dst_row0.. of layer `layer` of tensor `tid`.  q4_0 is re-packed (nibble plane + scale plane) on the way.
@@ -1152,19 +1208,24 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
     DevTensor& t = c->t[tid];
     const size_t first_row = (size_t)layer * d.rows + dst_row0;
     const bool verify = verify_uploads();
-    unsigned long long* d_acc = nullptr;
-    if (verify) HIPCHK(dev_alloc(&d_acc, sizeof(*d_acc)));
     int rc = LLMK_OK;
-    if (!c->up_stage[0]) {
+    if (!c->up_ready) {
+        // the staging objects live as long as the ctx (llmk_destroy frees whatever exists); `up_ready` only after ALL of them do, so a
+        // failure half-way is retried from where it stopped instead of dereferencing what is missing (advisor, round 4)
         for (int b = 0; b < 2; ++b) {
-            HIPCHK(hipHostMalloc(&c->up_stage[b], UP_STAGE_BYTES, hipHostMallocMapped));
-            HIPCHK(hipHostGetDevicePointer(&c->up_stage_dev[b], c->up_stage[b], 0));
-            HIPCHK(hipEventCreateWithFlags(&c->up_done[b], hipEventDisableTiming));
-            HIPCHK(dev_alloc(&c->up_tmp[b], UP_STAGE_BYTES));
+            if (!c->up_stage[b]) HIPCHK(hipHostMalloc(&c->up_stage[b], UP_STAGE_BYTES, hipHostMallocMapped));
+            if (!c->up_stage_dev[b]) HIPCHK(hipHostGetDevicePointer(&c->up_stage_dev[b], c->up_stage[b], 0));
+            if (!c->up_done[b]) HIPCHK(hipEventCreateWithFlags(&c->up_done[b], hipEventDisableTiming));
+            if (!c->up_tmp[b]) HIPCHK(dev_alloc(&c->up_tmp[b], UP_STAGE_BYTES));
         }
+        if (!c->up_acc) HIPCHK(dev_alloc(&c->up_acc, sizeof(*c->up_acc)));
+        c->up_ready = true;
     }
-    if (col_bytes > UP_STAGE_BYTES || col_bytes % 2) { if (d_acc) hipFree(d_acc); return LLMK_E_ARG; }
+    unsigned long long* const d_acc = c->up_acc;
     const bool q4 = t.type == LLMK_TYPE_Q4_0;
+    // whole 16-bit words on the host side; the non-q4_0 path moves 32-bit words into rows row_bytes apart (advisor, round 4)
+    if (col_bytes > UP_STAGE_BYTES || col_bytes % 2 || (!q4 && (col_bytes % 4 || t.row_bytes % 4))) return LLMK_E_ARG;
+    c->q16_dirty = true;
     const size_t blocks_per_row = col_bytes / 18;                       // (q4_0)
     const size_t rows_per_chunk = UP_STAGE_BYTES / col_bytes;
     char* dst0 = (char*)t.data + first_row * t.row_bytes;              // the block's rows in the tensor (contiguous: row_bytes apart)
@@ -1212,7 +1273,6 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
         if (attempt == 3) rc = LLMK_E_VERIFY;
     }
     if (rc == LLMK_OK) { const hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) rc = LLMK_E_HIP + (int)e; }
-    if (d_acc) hipFree(d_acc);
     if (rc) return rc;
     t.rows_uploaded += (size_t)nrows;
     if (t.rows_uploaded >= (size_t)d.rows * (d.layered ? c->L : 1)) t.uploaded = true;
@@ -1977,6 +2037,9 @@ int llmk_destroy(llmk_ctx* c) {
         if (c->up_tmp[b]) hipFree(c->up_tmp[b]);
         if (c->up_done[b]) hipEventDestroy(c->up_done[b]);
     }
+    if (c->up_acc) hipFree(c->up_acc);
+    for (int i = 0; i < LLMK_N_TENSORS; ++i)
+        if (c->q16[i]) hipFree(c->q16[i]);
     if (c->h_tokpos) hipHostFree(c->h_tokpos);
     if (c->h_logits) hipHostFree(c->h_logits);
     if (c->h_next) hipHostFree(c->h_next);

@@ -37,6 +37,7 @@
 // Per unit and wave: 37 matrix instructions and ~230 VALU operations for 512 (row, block) pairs (round 4: ~455 + 0).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -142,8 +143,10 @@ __device__ __forceinline__ q16_v8h q16_sel(int lane) {
 // acc8 += the scale plane times the sums of x.  The B operands of the next HALF group (4 reads, 16 registers) are requested
 // before the current half group is multiplied; left to itself hipcc reads each operand one instruction ahead and the LDS latency
 // shows (probe: 2,634 against 2,095 clocks per unit).
-__device__ __forceinline__ void q16_unit_dot(const float4 (&w)[8], const float4& sc4, const Q16Lane& ln, const q16_v8h& sel, int g,
-                                             q16_v4f& acc, q16_v4f& acc8) {
+// mid(integral_constant<P>), P = 0, 1, 2: called behind half groups 1, 3 and 5 (the caller's request of its next unit, in three pieces)
+template <class F>
+__device__ __forceinline__ void q16_unit_dot(const float4 (&w)[9], const Q16Lane& ln, const q16_v8h& sel, int g, q16_v4f& acc, q16_v4f& acc8, F mid) {
+    const float4& sc4 = w[8];
     const q16_v4f z = {0.f, 0.f, 0.f, 0.f};
     const q16_v4u zu = {0u, 0u, 0u, 0u};
     const q16_v4u sc = {__float_as_uint(sc4.x), __float_as_uint(sc4.y), __float_as_uint(sc4.z), __float_as_uint(sc4.w)};
@@ -172,6 +175,11 @@ __device__ __forceinline__ void q16_unit_dot(const float4 (&w)[8], const float4&
             acc.x = fmaf(d.x, s.x, acc.x); acc.y = fmaf(d.y, s.y, acc.y); acc.z = fmaf(d.z, s.z, acc.z); acc.w = fmaf(d.w, s.w, acc.w);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (true) {
+            if (h == 1) mid(std::integral_constant<int, 0>());
+            if (h == 3) mid(std::integral_constant<int, 1>());
+            if (h == 5) mid(std::integral_constant<int, 2>());
+        }
     }
 }
 // the sixteen columns of a row added up: every lane of the 16-lane row gets the sum

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "q4_units.h"
 
 // ---- measurement knobs (defaults = the product; -D... builds a variant library for an A/B) ---------------------------
 // loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it).  H = 5632 is
@@ -167,6 +168,8 @@ struct TokenArgs {
     // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
     int q0, qn, o0, on;
     int c0, cn;              // this CU's rows of the classifier
+    int h0, hn;              // q4_0: this CU's hidden units (w1|w3 gate / up row pairs; f32 / f16: c * H / 256, compile-time count)
+    int nw;                  // q4_0: waves of this CU that take units (8; 7 on an attention CU)
     // Pipelined greedy decode (llmk_decode_greedy): `token = maxloc(logits,DIM=1)` (llama2.f90:388) without a host round
     // trip.  Every CU leaves the first maximum of ITS classifier rows in cand_out[c] = {logit, 0-based row}; the NEXT launch
     // (ordered behind this one by the stream) starts by folding the 256 candidates of cand_in -- 2 KB, first maximum wins --
@@ -196,6 +199,8 @@ __device__ __forceinline__ void tk_wave_argmax(float& v, int& i) {
     }
 }
 
+constexpr int tk_cdiv(int a, int b) { return (a + b - 1) / b; }
+constexpr int tk_cmax(int a, int b) { return a > b ? a : b; }
 template <int E_, int H_, int NH_, int NKV_, int V_, int WT_ = WT_F32>
 struct TkShape {
     static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_, WT = WT_;
@@ -203,25 +208,24 @@ struct TkShape {
     // ---- weight tiles.  A tile is TK_TCOLS (8) lane loads of 16 bytes = 8 "segments" of 1 KB.  f32: one row x 8
     // segments (2048 columns).  f16: a row of 2048 columns is 4 segments, so a tile is RPT = 2 consecutive rows x LPT = 4
     // segments -- the x fragment a lane needs (LPT segments x VPL columns) is 32 floats either way.
-    // q4_0 (nibble plane, 16 bytes = one 32-weight block): a row of 4096 columns is 2 segments, a tile is RPT = 4 rows x
-    // LPT = 2 segments; lane l owns blocks l and l + 64 of every row (64 floats of x, fixed for the whole phase) and
-    // fetches each block's f16 scale (stored right behind the row's nibbles) with its own 2-byte load (8 more loads per
-    // tile, 1/8 of the bytes).  Rows need not be whole segments: see tk_issue.
+    // q4_0 (round 5): the ring entry is a UNIT of 16 rows x 32 blocks in its own device layout (q4_units.h: 8 KB of nibbles as
+    // matrix-core operands + 1 KB of scales, 9,216 contiguous bytes), dotted on v_mfma_f32_16x16x32_f16 against an f16 hi | lo
+    // image of x in LDS.  A K = E row group is NCS_E units wide, a K = H one NCS_H (the last one ragged: zero blocks).
     static constexpr bool Q4 = WT == WT_Q4_0;
+    static constexpr int NCS_E = q16_ncs(E), NCS_H = q16_ncs(H);
+    static constexpr int NBI = (NCS_H > NCS_E ? NCS_H : NCS_E) * Q16_BLOCKS;   // blocks of the x image in LDS
     static constexpr int VPL = Q4 ? 32 : (WT == WT_F16 ? 8 : 4);         // weights per 16-byte lane load
     static constexpr int SEGW = WAVE * VPL;                              // weights per 1 KB segment
     // bytes between rows, K = E / K = H (q4_0 device row: K/2 nibble bytes, then the row's K/32 f16 scales, 16-byte aligned)
     // (the scale area is zero-padded to whole groups of 64 scales: llmk.hip q4_row_stride)
     static constexpr int RB_E = Q4 ? E / 2 + (E / 32 + 63) / 64 * 128 : E / VPL * 16, RB_H = Q4 ? H / 2 + (H / 32 + 63) / 64 * 128 : H / VPL * 16;
     static constexpr int LPR_E = (E + SEGW - 1) / SEGW, LPR_H = (H + SEGW - 1) / SEGW;   // 1 KB segments per row (q4_0: last may be ragged)
-    static constexpr int NBLK_E = E / 32, NBLK_H = H / 32;               // q4_0 blocks per row
-    static constexpr int NBP_E = NBLK_E + 1, NBP_H = NBLK_H + 1;         // q4_0: pitch (in float4) of the transposed x image in LDS
     // ring depth = tiles per streaming wave requested ahead of the dots.  Deeper is not better: what is queued at the memory
     // controllers when a phase ends is what the next exchange's polls wait behind.  f32 (streaming-bound): 5 (4: -2.6 %);
     // f16 (exchange-bound, half the bytes per tile-time): 4 (5: 1,710 tok/s, 4: 1,855, 3: 1,808, 6 spills);
-    // q4_0: 3 (4 would spill, 237 VGPRs at 3).
+    // q4_0: 4 (a unit is 36 registers; the x fragment of round 4's tiles -- 64 registers -- is gone: x lives in LDS).
 #ifndef LLMK_NB_Q4
-#define LLMK_NB_Q4 3
+#define LLMK_NB_Q4 4
 #endif
 #ifndef LLMK_NB_F16
 #define LLMK_NB_F16 4
@@ -246,50 +250,52 @@ struct TkShape {
     // memory pipeline with loads).  Round 4, interleaved on two boxes (profiles/r04_ab.jsonl): f16 +0.5 % four times out of four
     // (kernel 475.3 vs 477.7 us), f32 -1 % twice and equal once (1,452 vs 1,466 tok/s)
     static constexpr bool GF_PUB = LLMK_TK_GF_PUB >= 0 ? LLMK_TK_GF_PUB != 0 : WT == WT_F16;
-    static constexpr int RPT = Q4 ? TK_TCOLS / LPR_E : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile
-    static constexpr int LPT = TK_TCOLS / RPT;                           // segments of ONE row in a tile
+    static constexpr int RPT = Q4 ? Q16_ROWS : ((WT == WT_F16 && 2 * LPR_E <= TK_TCOLS) ? 2 : 1);   // rows per tile (q4_0: per unit)
+    static constexpr int LPT = Q4 ? 1 : TK_TCOLS / RPT;                  // segments of ONE row in a tile (f32 / f16)
     // rows per CU and tiles per CU for each phase
     // The NH attention CUs own NO rows of the QKV and wo matrices (the two phases either side of attention): their q poll,
     // K/V rows and attention never queue behind their own weight prefetch, and nobody waits for them to catch up on
     // streaming after attention.  The other NCU_W CUs split those rows as evenly as whole RoPE pairs / tile rows allow.
     static constexpr int NCU_W = TK_NCU - NH;
-    static constexpr int QB = (QKV / 2) / NCU_W, QX = (QKV / 2) % NCU_W;      // pairs per CU, CUs with one pair more
+    static constexpr int QG = Q4 ? Q16_ROWS : 2;                              // granularity of the QKV split: RoPE pairs, or whole units
+    static constexpr int QB = (QKV / QG) / NCU_W, QX = (QKV / QG) % NCU_W;    // pairs (row groups) per CU, CUs with one more
     static constexpr int OB = (E / RPT) / NCU_W, OX = (E / RPT) % NCU_W;      // tile-row groups per CU, CUs with one more
     static constexpr int CB = (V / RPT) / TK_NCU, CX = (V / RPT) % TK_NCU;    // classifier: the same over all CUs
-    static constexpr int R_Q = 2 * (QB + (QX > 0 ? 1 : 0)), R_O = RPT * (OB + (OX > 0 ? 1 : 0));   // MAX rows per CU
+    static constexpr int R_Q = QG * (QB + (QX > 0 ? 1 : 0)), R_O = RPT * (OB + (OX > 0 ? 1 : 0));   // MAX rows per CU
     static constexpr int R_C = RPT * (CB + (CX > 0 ? 1 : 0));
-    static constexpr int R_A = 2 * (H / TK_NCU), R_D = E / TK_NCU;
+    // hidden units (w1|w3 gate / up row pairs) per CU.  f32 / f16: H / 256 everywhere.  q4_0: whole 16-row groups -- an attention
+    // CU, whose service wave never streams (7 waves share its units), takes AG_ATT groups, the others split the rest
+    static constexpr int AG_ATT = (H / Q16_ROWS) / TK_NCU, AG_W = H / Q16_ROWS - NH * AG_ATT, AB = AG_W / NCU_W, AX = AG_W % NCU_W;
+    static constexpr int R_A = Q4 ? 2 * Q16_ROWS * (AB + (AX > 0 ? 1 : 0)) : 2 * (H / TK_NCU), R_D = E / TK_NCU;
     static constexpr int TPR_H = (LPR_H + LPT - 1) / LPT;                // column parts of a w2 row
-    // how the staging code is told which image of the input vector to write: 0 natural order, > 0 the transposed float4 image
-    // at that pitch (q4_0)
-    static constexpr int TR_E = Q4 ? NBP_E : 0, TR_H = Q4 ? NBP_H : 0;
+    // how the staging code is told which image of the input vector to write: 0 natural order (f32), > 0 the f16 hi | lo image
+    // of that many blocks (q4_0: q4_units.h Q16Img)
+    static constexpr int TR_E = Q4 ? NBI : 0, TR_H = TR_E;
     // a CU's row count need not be a multiple of RPT: the last tile then also covers rows of the NEXT CU (recomputed,
     // their partial sums land in slots nobody reads).  The weight allocations carry RPT rows of slack at their end.
     static constexpr int NG_A = (R_A / 2 + RPT - 1) / RPT;               // gate (= up) tiles per CU
     static constexpr int NT_Q = (R_Q + RPT - 1) / RPT, NT_O = R_O / RPT, NT_A = 2 * NG_A, NT_D = (R_D / RPT) * TPR_H, NT_C = R_C / RPT;
-    // q4_0, round 4: a slot costs ~2 us of VALU work whether one wave holds a tile in it or all seven (520 VALU instructions
-    // per tile, two waves per SIMD: the q4_0 phases are ALU-bound at the same ~18 us per layer HBM needs -- an attention CU, whose
-    // QKV tiles are the zero block, spends the same 4.5 us in its two QKV slots).  Llama-2-7B's w1|w3 range is 22 tiles per CU:
-    // three full slots and ONE tile in a fourth.  The service wave idles between the phase's two barriers: it takes that tile
-    // (LLMK_TK_SVC_A), and the phase is three slots.
-#ifndef LLMK_TK_SVC_A
-#define LLMK_TK_SVC_A 1
-#endif
-    static constexpr bool SVC_A = Q4 && LLMK_TK_SVC_A && (NT_A % TK_NS == 1);
-    static constexpr int NT_A_S = NT_A - (SVC_A ? 1 : 0);                // w1|w3 tiles of the streaming waves
-    static constexpr int SL_Q = (NT_Q + TK_NS - 1) / TK_NS, SL_O = (NT_O + TK_NS - 1) / TK_NS,
-                         SL_A = (NT_A_S + TK_NS - 1) / TK_NS, SL_C = (NT_C + TK_NS - 1) / TK_NS;
+    // q4_0: units per CU at most, per phase; ALL EIGHT waves take units (wave w: units w, w + 8, ...) except on the attention
+    // CUs, whose service wave stays out of the weight stream (its q poll and publish are the layer's critical path): 7 waves
+    static constexpr int UQ = R_Q / RPT * NCS_E, UO = R_O / RPT * NCS_E, UA = R_A / RPT * NCS_E, UA_ATT = 2 * AG_ATT * NCS_E,
+                         UD = R_D / RPT * NCS_H, UC = R_C / RPT * NCS_E;
+    static constexpr int SL_Q = Q4 ? tk_cdiv(UQ, TK_WAVES) : (NT_Q + TK_NS - 1) / TK_NS, SL_O = Q4 ? tk_cdiv(UO, TK_WAVES) : (NT_O + TK_NS - 1) / TK_NS,
+                         SL_A = Q4 ? tk_cmax(tk_cdiv(UA, TK_WAVES), tk_cdiv(UA_ATT, TK_NS)) : (NT_A + TK_NS - 1) / TK_NS,
+                         SL_C = Q4 ? tk_cdiv(UC, TK_WAVES) : (NT_C + TK_NS - 1) / TK_NS;
     // w2 rows are TPR_H parts wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
     // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
-    static constexpr int NW_D = TK_NS / TPR_H, SL_D = (R_D / RPT + NW_D - 1) / NW_D;
+    static constexpr int NW_D = tk_cmax(TK_NS / TPR_H, 1), SL_D = Q4 ? tk_cdiv(UD, TK_NS) : (R_D / RPT + NW_D - 1) / NW_D;
     static constexpr int SL_LAYER = SL_Q + SL_O + SL_A + SL_D;
     static constexpr int RA_P = 2 * RPT * NG_A, RQ_P = RPT * NT_Q;       // partial slots incl. the recomputed neighbour rows
     static constexpr int MAXP00 = RA_P > R_C ? RA_P : R_C, MAXP0 = MAXP00 > RQ_P ? MAXP00 : RQ_P, MAXP1 = R_D * TPR_H,
-                         MAXP = MAXP0 > MAXP1 ? MAXP0 : MAXP1;           // partial sums per phase
-    static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && H % TK_NCU == 0 && V % RPT == 0, "rows must split over CUs");
+                         MAXPT = MAXP0 > MAXP1 ? MAXP0 : MAXP1,          // partial sums per phase (f32 / f16: one per tile row)
+                         MAXP = Q4 ? Q16_ROWS * tk_cmax(tk_cmax(UQ, UA), tk_cmax(UD, UC)) : MAXPT;   // q4_0: 16 per unit
+    static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && (Q4 || H % TK_NCU == 0) && V % RPT == 0, "rows must split over CUs");
     static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
-    static_assert(LPR_E <= LPT && (Q4 || (R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
-                  "a K = E row is one tile row; row ranges are whole tiles (q4_0: QKV / w1|w3 may end in a shared tile)");
+    static_assert((Q4 || (LPR_E <= LPT && R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
+                  "a K = E row is one tile row; row ranges are whole tiles");
+    static_assert(!Q4 || (E % 1024 == 0 && QKV % Q16_ROWS == 0 && KV % Q16_ROWS == 0 && H % Q16_ROWS == 0 && AG_ATT >= 1 && E / Q16_ROWS % TK_NCU == 0),
+                  "q4_0: K = E rows are whole units, every matrix whole 16-row groups, one w2 group (or more) per CU");
     static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
     static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
     static_assert(HS == 64 || HS == 128, "in-kernel attention is written for head sizes 64 and 128");
@@ -315,9 +321,9 @@ __device__ __forceinline__ unsigned long long* tk_trace(const TokenArgs& a) {
 template <class SH>
 struct TkLds {
     static constexpr int XS = 0;
-    // q4_0: the streaming input is staged TRANSPOSED, xs4[m * NBP + b] = x[32 b + 4 m .. + 3], so the eight float4 a lane
-    // needs for block b are lane-contiguous (conflict-free ds_read_b128); pitch NBP = blocks + 1
-    static constexpr int XS_BYTES = SH::Q4 ? 8 * (SH::NBP_H > SH::NBP_E ? SH::NBP_H : SH::NBP_E) * 16 : SH::H * 4;
+    // q4_0: the streaming input is staged as the matrix core's B operand: an f16 hi | lo image, the blocks' sums, a line of zeros
+    // (q4_units.h Q16Img)
+    static constexpr int XS_BYTES = SH::Q4 ? Q16Img<SH::NBI>::BYTES : SH::H * 4;
     static constexpr int XRAW = XS + XS_BYTES;
     static constexpr int PART = XRAW + SH::E * 4;
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
@@ -381,13 +387,8 @@ __device__ __forceinline__ float4 tk_ldkv(__amdgpu_buffer_rsrc_t rs, int voff) {
 // (Measured and dropped, round 2: two passes in flight half a round trip apart, so that a pass that just missed the last
 // producer is not followed by a whole further round trip -- f16 1,850 -> 1,480 tok/s, f32 1,380 -> 1,290: twice the poll
 // traffic in the service wave's queue costs more than the shorter wait saves.)
-// NBP > 0: the values are written in the transposed q4_0 image (see TkLds), element e -> float4 (e>>2): block (e>>5),
-// group (e>>2)&7
 template <int NBP>
-__device__ __forceinline__ int tk_xoff(int e) {
-    if constexpr (NBP > 0) return ((((e >> 2) & 7) * NBP + (e >> 5)) << 2) + (e & 3);
-    else return e;
-}
+__device__ __forceinline__ int tk_xoff(int e) { static_assert(NBP == 0, "natural order"); return e; }
 template <int NL, int NBP>
 __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* dst,
                                                unsigned* err, int lane, bool nowait, unsigned long long* dbg,
@@ -468,9 +469,17 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0x118, 0xf, true>(0.f, v);
     return v;
 }
+// the power of two next below 1 / x (x > 0 finite): the image of a residual-stream vector is written as x * gains * 2^-e, with e
+// from the rmsnorm of the vector gathered BEFORE it on this CU -- the stream grows slowly, and the f16 pieces of the image hold
+// 2^15 either way of the magnitude they are scaled to; the row sums are divided by the same power of two (exactly) afterwards
+__device__ __forceinline__ float tk_pow2_inv(float x) {
+    const int e = (int)((__float_as_uint(x) >> 23) & 0xffu);            // biased exponent of x
+    return __uint_as_float((unsigned)min(max(254 - e, 1), 254) << 23);
+}
+constexpr int TK_XSC = 12;      // red8[TK_XSC]: that power of two (q4_0), next to the eight partial sums and the gather-first words
 template <int NLW, int NBP, bool NORM>
 __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
-                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait) {
+                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait, float psc = 1.f) {
     if constexpr (NLW == 0) { return true; }
     else {
         float2 gn[NORM ? NLW : 1];
@@ -479,7 +488,12 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
             for (int k = 0; k < NLW; ++k) gn[k] = *reinterpret_cast<const float2*>(gains + 2 * (first_pair + lane + k * WAVE));
         }
         const int e0 = 2 * (first_pair + lane);
-        const int d0 = tk_xoff<NBP>(e0);
+        // NBP > 0: the f16 hi | lo image of NBP blocks (q4_units.h): where this lane's pair goes, its factor (1, or 1/16 under a high
+        // nibble), and the slot of its block's sum; load k lies 128 elements = 4 blocks further
+        char* ip = reinterpret_cast<char*>(xs) + (NBP > 0 ? q16_pair_off(e0) : 0);
+        const float isc = NBP > 0 ? q16_pair_scale(e0) : 1.f;
+        float amax = 0.f;               // NBP > 0: the largest |value| written as an f16 hi piece (65504 is the end of that format)
+        char* sp = reinterpret_cast<char*>(xs) + (NBP > 0 ? Q16Img<(NBP > 0 ? NBP : 32)>::SUM + (e0 >> 5) * 2 : 0);
         for (unsigned spin = 0;; ++spin) {
             tk_v4u r[NLW];
 #pragma unroll
@@ -499,9 +513,25 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                         acc = fmaf(x1, x1, acc);
                         y0 = x0 * gn[k].x; y1 = x1 * gn[k].y;
                     }
-                    *reinterpret_cast<float2*>(xs + d0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(y0, y1);
+                    if constexpr (NBP > 0) {
+                        y0 *= psc; y1 *= psc;
+                        amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1)));
+                        q16_put2(ip + k * (4 * Q16_IMG_BLK), isc, y0, y1);
+                        const float bs = row16_sum(y0 + y1);             // a load's 64 lanes hold 4 whole blocks, one per DPP row
+                        if ((lane & 15) == 15) q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs);
+                    } else {
+                        *reinterpret_cast<float2*>(xs + e0 + k * 2 * WAVE) = make_float2(y0, y1);
+                    }
                 }
                 if constexpr (NORM) *ss += acc;
+                if constexpr (NBP > 0) {
+                    // an activation beyond the f16 range (or not finite): the image is useless -- raise the sticky word, the host retires
+                    // the kernel for this context and redoes the position on the multi-kernel path (f32 throughout)
+                    if (!nowait && __any(!(amax < 60000.f))) {
+                        if (lane == 0) __hip_atomic_store(err, 0x4000u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return false;
+                    }
+                }
                 return true;
             }
             if ((spin & 63) == 63) {
@@ -524,8 +554,9 @@ __device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsi
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     float ss = 0.f;
     bool ok;
-    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
-    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait);
+    const float psc = (NORM && NBP > 0) ? red8[TK_XSC] : 1.f;       // q4_0, residual stream: see tk_pow2_inv
+    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc);
+    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc);
     if constexpr (NORM) {
         ss = wave_sum(ss);
         if (lane == 0) red8[w] = ss;
@@ -553,10 +584,9 @@ struct TkNorm {
     // Stages xs = x*w and returns xn = sqrt(mean(x^2)+1e-5).  The division by xn is linear in the dot
     // product, so it is applied ONCE to each finished row sum (W.(x*w))/xn by the epilogue instead
     // of 2048 times here -- the service wave is the serial section of every phase.
-    template <int NBP = 0>   // NBP > 0: xs is the transposed q4_0 image
+    template <int NBP = 0>   // NBP > 0: xs is the f16 hi | lo image of NBP blocks (q4_0: q4_units.h)
     __device__ __forceinline__ float apply(const float* xraw, float* xs, int lane, float eps) const {
         float ss = 0.f;
-        const int xs0 = tk_xoff<NBP>(4 * lane);     // float4 lane + 64 k: 8 blocks further per k in the transposed image
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const float4 x = reinterpret_cast<const float4*>(xraw)[lane + k * WAVE];
@@ -566,7 +596,17 @@ struct TkNorm {
             o.y = x.y * w[k].y;
             o.z = x.z * w[k].z;
             o.w = x.w * w[k].w;
-            *reinterpret_cast<float4*>(xs + xs0 + k * (NBP > 0 ? 32 : 4 * WAVE)) = o;
+            if constexpr (NBP > 0) {
+                const int e = 4 * (lane + k * WAVE);                    // eight lanes hold one block
+                q16_put4(reinterpret_cast<char*>(xs), e, o);
+                float bs = (o.x + o.y) + (o.z + o.w);
+                bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
+                bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
+                bs += dpp_mov<0x114, 0xf, true>(0.f, bs);               // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
+                if ((lane & 7) == 7) q16_put_sum<(NBP > 0 ? NBP : 32)>(reinterpret_cast<char*>(xs) + Q16Img<(NBP > 0 ? NBP : 32)>::SUM + (e >> 5) * 2, bs);
+            } else {
+                *reinterpret_cast<float4*>(xs + (lane + k * WAVE) * 4) = o;
+            }
         }
         ss = wave_sum(ss);
         return sqrtf(ss / (float)E + eps);
@@ -578,24 +618,35 @@ struct TkNorm {
 // flow around the loads hipcc can count them, so consuming the oldest of the NB tiles waits with
 // vmcnt(24) and leaves the three younger tiles in flight; a skipped load would force vmcnt(0).
 struct TkTile {
-    const float4* p;  // first segment of the tile's first row (the zero block when the slot is empty)
+    const float4* p;  // first segment of the tile's first row (the zero block when the slot is empty); q4_0: the unit's 9,216 bytes
     int rstride;      // float4 units between the tile's rows (RPT > 1)
-    int ncol;         // real segments per tile row (0..LPT); segments >= ncol read zeros
+    int ncol;         // real segments per tile row (0..LPT); segments >= ncol read zeros; q4_0: 1 = a unit, 0 = none
     int pidx;         // partial index of the tile's first row (MAXP = junk slot); row s of the tile: pidx + s * pstep
-    int pstep;
-    int soff;         // q4_0 only: bytes from p to the f16 scale of the tile's first block (same row)
+    int pstep;        // q4_0: the unit's column slot (which 32 blocks of the x image it is dotted with)
 };
 
 typedef _Float16 tk_h2 __attribute__((ext_vector_type(2)));
 // one ring entry: the 8 weight vectors of a tile (+ for q4_0 the 8 block scales that go with them)
 template <class SH>
 struct TkSlot {
-    float4 b[TK_TCOLS];
-    unsigned short sc[SH::Q4 ? TK_TCOLS : 1];
+    float4 b[TK_TCOLS + (SH::Q4 ? 1 : 0)];      // q4_0: b[8] = the lane's 16 bytes of the unit's scale plane
+};
+// a wave's ring: the tiles (q4_0: units) it has requested ahead, and their descriptors
+template <class SH>
+struct TkRing {
+    TkSlot<SH> b[SH::NB];
+    TkTile t[SH::NB];
 };
 
 template <class SH>
 __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
+    if constexpr (SH::Q4) {
+        // a unit: 8 x 1 KB of operand dwords + 1 KB of scales, contiguous (q4_units.h); no unit = nine reads of one line of zeros
+        const bool real = t.ncol != 0;
+#pragma unroll
+        for (int j = 0; j <= TK_TCOLS; ++j) e.b[j] = ldg_nt(real ? t.p + j * WAVE + lane : zp);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
@@ -605,29 +656,14 @@ __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const f
         // sweep of the zero block: it still counts in vmcnt, but costs the CU's memory pipeline one line instead of eight
         e.b[j] = ldg_nt(pj + (real ? lane : 0));
     }
-    if constexpr (SH::Q4) {
-        // the blocks' f16 scales.  A ragged last segment (K = H) needs no per-lane predicate: lanes past the row end read
-        // the row's zero padding as scales (the scale area is padded to whole groups of 64) and whatever follows the
-        // row's nibbles as nibbles (its own scales: finite integers after conversion), and their x fragment is zero
-        // (TkX::load_q4), so they contribute 0 * (0 - 0) = 0.
-#pragma unroll
-        for (int j = 0; j < TK_TCOLS; ++j) {
-            const int s = j / SH::LPT, jj = j % SH::LPT;
-            const bool real = jj < t.ncol;
-            const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(t.p + s * t.rstride) + t.soff) + jj * WAVE
-                                            : reinterpret_cast<const unsigned short*>(zp);
-            e.sc[j] = __builtin_nontemporal_load(pj + (real ? lane : 0));
-        }
-    }
 }
 // Every tile of a phase is dotted against the same x fragment (the LPT segments of a row, or of one column part of a
 // w2 row): it is read from LDS once per phase into registers, not once per tile -- 7 waves x 8 KB of ds_read per
 // slot was ~0.2 us of LDS time in the middle of every slot of the critical path.  32 floats per lane for f32 and f16.
 template <class SH>
 struct TkX {
-    static constexpr int F4 = SH::VPL / 4;          // float4 of x per segment and lane: 1 (f32), 2 (f16), 8 (q4_0: one block)
+    static constexpr int F4 = SH::Q4 ? 1 : SH::VPL / 4;   // float4 of x per segment and lane: 1 (f32), 2 (f16); q4_0 keeps x in LDS
     float4 v[SH::LPT * F4];
-    float xs8[SH::Q4 ? SH::LPT : 1];                // q4_0: 8 * (sum of the block's 32 activations), the "-8" of (nibble - 8)
     // segments seg0 .. seg0+LPT-1 of a vector with nseg segments; segments past the end read as zero
     __device__ __forceinline__ void load(const float4* xs, int seg0, int nseg, int lane) {
 #pragma unroll
@@ -640,24 +676,6 @@ struct TkX {
             }
         }
     }
-    // q4_0: blocks (seg0 + j) * 64 + lane of a vector of nblk blocks staged transposed at pitch NBP (TkLds); blocks past
-    // the end read as zero
-    template <int NBP>
-    __device__ __forceinline__ void load_q4(const float4* xs, int seg0, int nblk, int lane) {
-#pragma unroll
-        for (int j = 0; j < SH::LPT; ++j) {
-            const int b = (seg0 + j) * WAVE + lane;
-            const bool in = b < nblk;
-            float t = 0.f;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const float4 x = xs[m * NBP + (in ? b : 0)];
-                v[j * 8 + m] = in ? x : make_float4(0.f, 0.f, 0.f, 0.f);
-                t += (v[j * 8 + m].x + v[j * 8 + m].y) + (v[j * 8 + m].z + v[j * 8 + m].w);
-            }
-            xs8[j] = 8.0f * t;
-        }
-    }
 };
 __device__ __forceinline__ float4 tk_h2f_lo(const float4& w) {   // halves 0..3 of a 16-byte vector of 8
     const __half2 a = *reinterpret_cast<const __half2*>(&w.x), b = *reinterpret_cast<const __half2*>(&w.y);
@@ -668,116 +686,10 @@ __device__ __forceinline__ float4 tk_h2f_hi(const float4& w) {   // halves 4..7
     return make_float4(__low2float(a), __high2float(a), __low2float(b), __high2float(b));
 }
 // per-lane partial dots of one tile (one per tile row): four independent FMA chains (x,y,z,w) instead of one long chain
-// One dword of a q4_0 block (bytes 4i..4i+3: low nibbles = elements 4i.., high nibbles = elements 16+4i..) against its 8
-// activations, as ONE asm statement: lo += sum n_lo x, hi16 += sum (16 n_hi) x.  Same arithmetic as q4_dword_dot
-// (kernels.h); written out so that exactly four temporaries are live -- left to itself the scheduler hoists the 64
-// conversions of a tile ahead of their FMAs and the kernel spills (the ring and the x fragment already hold 190 VGPRs).
-// The low and high chains alternate, so dependent FMAs are four issue slots apart.
-// Measured (probes/q4_alu_probe.hip, 2 waves per SIMD): 50 cycles per dword per SIMD -- v_cvt_f32_ubyteN issues at half
-// rate (3.6 cycles), and so does v_cvt_pk_f32_fp8 (a byte 0x0n read as OCP e4m3 is exactly n * 2^-9: two nibbles per
-// instruction, but 4.4 cycles each plus a use stall: 57 cycles per dword, slower in the kernel too).
-// Round 3: NO conversion at all.  A 16-bit half whose only set bits are a nibble at bits 0-3 IS the f16 subnormal
-// n * 2^-24 (at bits 4-7: 16 n * 2^-24), and v_fma_mix_f32 multiplies an f16 source -- the low or the high half of a
-// register, by op_sel -- with an f32 multiplicand into an f32 accumulator, exactly: q & 0x000F000F holds elements 4i and
-// 4i+2, q & 0x00F000F0 elements 16+4i and 16+4i+2 (x16), the same masks on q >> 8 the odd ones (the chains still run in
-// element order: a different order is a different, equally good, sum -- and would not be bit-identical any more).  1 shift + 4 ands +
-// 8 fma_mix = 13 full-rate operations per dword against 2 ands + 8 half-rate conversions + 8 fmas; every product and
-// every partial sum is the old recipe's times 2^-24 (a power of two commutes with rounding), so after the exact rescale
-// in tk_q4_block the results are BIT-IDENTICAL (probes/q4_mix_probe.hip: 65,536 random dword chains, zero differences;
-// cycles per dword there).  lo += 2^-24 sum n_lo x, hi16 += 2^-24 sum (16 n_hi) x.
-constexpr float TK_Q4_RESCALE = 16777216.0f;
-__device__ __forceinline__ void tk_q4_dword(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
-    unsigned l0, h0, l1, h1, s;
-    asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
-        "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
-        "v_lshrrev_b32 %[s], 8, %[q]\n\t"
-        "v_and_b32 %[l1], 0x000f000f, %[s]\n\t"
-        "v_fma_mix_f32 %[lo], %[l0], %[a0], %[lo] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h0], %[b0], %[hi] op_sel_hi:[1,0,0]\n\t"
-        "v_and_b32 %[h1], 0x00f000f0, %[s]\n\t"
-        "v_fma_mix_f32 %[lo], %[l1], %[a1], %[lo] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h1], %[b1], %[hi] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[lo], %[l0], %[a2], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h0], %[b2], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[lo], %[l1], %[a3], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h1], %[b3], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : [lo] "+v"(lo), [hi] "+v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
-        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
-          [b2] "v"(xh.z), [b3] "v"(xh.w));
-}
-// The FIRST dword of a block: the same operations with the constant 0 as the first addend of both chains instead of zeroed
-// registers (fma(a, b, 0) is the same number): two v_mov fewer per block, 16 per tile of the ~520 VALU operations that bound a
-// q4_0 phase.
-__device__ __forceinline__ void tk_q4_dword_first(unsigned q, const float4& xl, const float4& xh, float& lo, float& hi16) {
-    unsigned l0, h0, l1, h1, s;
-    asm("v_and_b32 %[l0], 0x000f000f, %[q]\n\t"
-        "v_and_b32 %[h0], 0x00f000f0, %[q]\n\t"
-        "v_lshrrev_b32 %[s], 8, %[q]\n\t"
-        "v_and_b32 %[l1], 0x000f000f, %[s]\n\t"
-        "v_fma_mix_f32 %[lo], %[l0], %[a0], 0 op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h0], %[b0], 0 op_sel_hi:[1,0,0]\n\t"
-        "v_and_b32 %[h1], 0x00f000f0, %[s]\n\t"
-        "v_fma_mix_f32 %[lo], %[l1], %[a1], %[lo] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h1], %[b1], %[hi] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[lo], %[l0], %[a2], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h0], %[b2], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[lo], %[l1], %[a3], %[lo] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
-        "v_fma_mix_f32 %[hi], %[h1], %[b3], %[hi] op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi16), [l0] "=&v"(l0), [h0] "=&v"(h0), [l1] "=&v"(l1), [h1] "=&v"(h1), [s] "=&v"(s)
-        : [q] "v"(q), [a0] "v"(xl.x), [a1] "v"(xl.y), [a2] "v"(xl.z), [a3] "v"(xl.w), [b0] "v"(xh.x), [b1] "v"(xh.y),
-          [b2] "v"(xh.z), [b3] "v"(xh.w));
-}
-// one block's contribution d * (sum n x - 8 sum x) from the two chains of tk_q4_dword (tl, th) and xs8 = 8 sum x
-__device__ __forceinline__ float tk_q4_block(float tl, float th, float d, float xs8, float acc) {
-    const float t = fmaf(th, 0.0625f, tl);
-    return fmaf(d, fmaf(t, TK_Q4_RESCALE, -xs8), acc);   // t * 2^24 is exact: == d * (t_conv - xs8) + acc
-}
-
-// a value per lane that belongs to tile row (lane & 3): the sum over the sixteen lanes that share lane & 3, written by lanes 12..15
-__device__ __forceinline__ void tk_rows4_finish(float acc, const TkTile& t, float* part, int lane) {
-    acc += dpp_mov<0x114, 0xf, true>(0.f, acc);       // row_shr:4
-    acc += dpp_mov<0x118, 0xf, true>(0.f, acc);       // row_shr:8: lanes 12..15 of every DPP row hold the row's four sums
-    acc += __shfl_xor(acc, 16, WAVE);
-    acc += __shfl_xor(acc, 32, WAVE);
-    if ((lane & ~3) == 12) part[t.pidx + (lane & 3) * t.pstep] = acc;
-}
-// FOUR per-lane partial sums (one per tile row) -> the four wave sums, in 5 selects + 5 DPP additions + the tail above instead
-// of four 64-lane reductions (24 DPP additions, 4 readlanes, 4 stores by lane 0): after two exchange steps inside each quad,
-// lane l holds the quad's sum of row l & 3 -- a transposition by halves, every addend still counted exactly once.
-// (round 4, end: the q4_0 phases are VALU-bound, ~520 operations per tile; this and tk_q4_dword_first remove ~36 of them.)
-__device__ __forceinline__ void tk_rows4_reduce(const float (&v)[4], const TkTile& t, float* part, int lane) {
-    const bool p = (lane & 1) != 0, q = (lane & 2) != 0;
-    const float s01 = (p ? v[1] : v[0]) + dpp_mov<0xB1, 0xf, true>(0.f, p ? v[0] : v[1]);      // quad_perm:[1,0,3,2]
-    const float s23 = (p ? v[3] : v[2]) + dpp_mov<0xB1, 0xf, true>(0.f, p ? v[2] : v[3]);
-    const float r = (q ? s23 : s01) + dpp_mov<0x4E, 0xf, true>(0.f, q ? s01 : s23);            // quad_perm:[2,3,0,1]
-    tk_rows4_finish(r, t, part, lane);
-}
-
 template <class SH>
 __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, float (&out)[SH::RPT]) {
+    static_assert(!SH::Q4, "q4_0 units are dotted on the matrix core (tk_unit)");
     const float4 (&b)[TK_TCOLS] = e.b;
-    if constexpr (SH::Q4) {
-        // sum_i (n_i - 8) d x_i = d (sum_i n_i x_i - 8 sum_i x_i): low nibbles are elements 0..15 of the block, high nibbles
-        // elements 16..31 (ggml block_q4_0); same arithmetic as gemv_q4_kernel (kernels.h)
-#pragma unroll
-        for (int s = 0; s < SH::RPT; ++s) {
-            float acc = 0.f;
-#pragma unroll
-            for (int jj = 0; jj < SH::LPT; ++jj) {
-                const float4& w = b[s * SH::LPT + jj];
-                const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-                float tl, th;
-                tk_q4_dword_first(q[0], x.v[jj * 8], x.v[jj * 8 + 4], tl, th);
-#pragma unroll
-                for (int i = 1; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
-                const unsigned short hs = e.sc[s * SH::LPT + jj];
-                const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
-                acc = tk_q4_block(tl, th, d, x.xs8[jj], acc);
-            }
-            out[s] = acc;
-        }
-        return;
-    }
 #pragma unroll
     for (int s = 0; s < SH::RPT; ++s) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -813,43 +725,6 @@ __device__ __forceinline__ void tk_consume(const TkSlot<SH>& b, const TkTile& t,
     }
 }
 
-// The service wave's copy of tk_consume for ONE q4_0 tile of a K = E phase (TkShape::SVC_A): the x fragment one segment at a
-// time (32 registers instead of 64 -- this wave carries the layer loop's exchange state), each row's blocks in the same order
-// with the same operations as tk_dot: bit-identical partial sums.
-template <class SH>
-__device__ __forceinline__ void tk_consume_q4_lean(const TkSlot<SH>& e, const TkTile& t, const float4* xs4, float* part, int lane) {
-    static_assert(SH::Q4, "q4_0 tiles");
-    float acc[SH::RPT];
-#pragma unroll
-    for (int s = 0; s < SH::RPT; ++s) acc[s] = 0.f;
-#pragma unroll
-    for (int jj = 0; jj < SH::LPT; ++jj) {
-        const int b = jj * WAVE + lane;                      // block of every row of the tile (K = E: all of them exist)
-        float4 xv[8];
-        float t8 = 0.f;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            xv[m] = xs4[m * SH::NBP_E + b];
-            t8 += (xv[m].x + xv[m].y) + (xv[m].z + xv[m].w);
-        }
-        const float xs8 = 8.0f * t8;
-#pragma unroll
-        for (int s = 0; s < SH::RPT; ++s) {
-            const float4& w = e.b[s * SH::LPT + jj];
-            const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-            float tl, th;
-            tk_q4_dword_first(q[0], xv[0], xv[4], tl, th);
-#pragma unroll
-            for (int i = 1; i < 4; ++i) tk_q4_dword(q[i], xv[i], xv[4 + i], tl, th);
-            const unsigned short hs = e.sc[s * SH::LPT + jj];
-            acc[s] = tk_q4_block(tl, th, __half2float(*reinterpret_cast<const __half*>(&hs)), xs8, acc[s]);
-        }
-        __builtin_amdgcn_sched_barrier(0);                   // (the second segment's x is read after the first's dots: 32 registers)
-    }
-    static_assert(SH::RPT == 4, "four rows per q4_0 tile");
-    tk_rows4_reduce(acc, t, part, lane);
-}
-
 // Static per-wave schedule: SLP slots per layer (padded to an even count so the 2-deep ring has the
 // same parity at every layer start), then the classifier slots.  Slot K (compile-time) belongs to
 // one phase; the s-th slot of a phase is tile s*15 + sw of the CU's tile range of that phase
@@ -864,7 +739,6 @@ template <class SH>
 __device__ __forceinline__ TkTile tk_null(const float4* zp) {
     TkTile t;
     t.p = zp; t.rstride = 0; t.ncol = 0; t.pidx = SH::MAXP; t.pstep = 0;
-    t.soff = 0;
     return t;
 }
 // row r of a [rows][K] matrix of SH's weight type
@@ -883,13 +757,26 @@ __device__ __forceinline__ TkTile tk_row_tile(const void* mat, long long row0, i
     t.rstride = SH::RB_E / 16;
     t.pidx = live ? ti * SH::RPT : SH::MAXP;
     t.pstep = live ? 1 : 0;
-    t.soff = SH::E / 2;
+    return t;
+}
+// q4_0: unit u of the U units a CU owns in a phase (units unit0 .. of the matrix, q4_units.h), for wave sw of the nw that take
+// units there (8; 7 on an attention CU, whose service wave stays out of the weight stream).  16 partial sums at u * 16.
+template <class SH>
+__device__ __forceinline__ TkTile tk_unit(const void* mat, int unit0, int u, int U, int ncs, int sw, int nw, const float4* zp) {
+    TkTile t;
+    const bool live = sw < nw && u < U;
+    t.ncol = live ? 1 : 0;
+    t.p = live ? reinterpret_cast<const float4*>(static_cast<const char*>(mat) + (size_t)(unsigned)(unit0 + u) * Q16_UNIT_BYTES) : zp;
+    t.rstride = 0;
+    t.pidx = live ? u * Q16_ROWS : 0;
+    t.pstep = u % ncs;
     return t;
 }
 
 template <class SH, int K>
 __device__ __forceinline__ TkTile tk_cls_at(const TokenArgs& a, int c, int sw) {
     if constexpr (K >= SH::SL_C) return tk_null<SH>(a.zeros);
+    else if constexpr (SH::Q4) return tk_unit<SH>(a.wcls, a.c0 / Q16_ROWS * SH::NCS_E, K * TK_WAVES + sw, a.cn / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, TK_WAVES, a.zeros);
     else if constexpr (SH::CX == 0) return tk_row_tile<SH>(a.wcls, (long long)c * SH::R_C, K * TK_NS + sw, SH::R_C, a.zeros);   // even split: compile-time count
     else return tk_row_tile<SH>(a.wcls, a.c0, K * TK_NS + sw, a.cn, a.zeros);
 }
@@ -905,7 +792,6 @@ __device__ __forceinline__ TkTile tk_w13_tile(const TokenArgs& a, int l, int c, 
     t.rstride = SH::RB_E / 16;
     t.pidx = live ? 2 * m * SH::RPT + gu : SH::MAXP;
     t.pstep = live ? 2 : 0;
-    t.soff = SH::E / 2;
     return t;
 }
 // w2 tile of streaming wave sw in slot k of the phase: RPT rows x column part `part` (LPT segments; the last part is ragged)
@@ -922,7 +808,6 @@ __device__ __forceinline__ TkTile tk_w2_tile(const TokenArgs& a, int l, int c, i
     t.rstride = SH::RB_H / 16;
     t.pidx = live ? rg * SH::RPT * P + part : SH::MAXP;
     t.pstep = live ? P : 0;
-    t.soff = SH::H / 2 - part * SH::LPT * WAVE * 14;   // p is part * LPT segments (1 KB each) into the row; its scales 128 B each
     return t;
 }
 // descriptor of slot K (compile-time) of layer l; K >= SLP looks into layer l+1; past the last
@@ -935,6 +820,26 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
         return tk_at<SH, K - SC::SLP>(a, l + 1, c, sw);
     } else {
         if (l >= a.L) return tk_cls_at<SH, K>(a, c, sw);
+        if constexpr (SH::Q4) {
+            // q4_0: the CU's units of the phase, wave sw takes units sw, sw + nw, ...  (w1|w3: the gate groups' units, then the up groups')
+            if constexpr (K < SC::KO) {
+                return tk_unit<SH>(a.wqkv, (l * SH::QKV + a.q0) / Q16_ROWS * SH::NCS_E, (K - SC::KQ) * a.nw + sw,
+                                   a.qn / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, a.nw, a.zeros);
+            } else if constexpr (K < SC::KA) {
+                return tk_unit<SH>(a.wo, (l * SH::E + a.o0) / Q16_ROWS * SH::NCS_E, (K - SC::KO) * a.nw + sw,
+                                   a.on / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, a.nw, a.zeros);
+            } else if constexpr (K < SC::KD) {
+                const int u = (K - SC::KA) * a.nw + sw, ug = a.hn / Q16_ROWS * SH::NCS_E, up = u >= ug ? 1 : 0;
+                TkTile t = tk_unit<SH>(a.w13, (l * 2 * SH::H + up * SH::H + a.h0) / Q16_ROWS * SH::NCS_E - up * ug, u, 2 * ug,
+                                       SH::NCS_E, sw, a.nw, a.zeros);
+                return t;
+            } else if constexpr (K < SC::KP) {
+                return tk_unit<SH>(a.w2, (l * SH::E + c * SH::R_D) / Q16_ROWS * SH::NCS_H, (K - SC::KD) * a.nw + sw,
+                                   SH::UD, SH::NCS_H, sw, a.nw, a.zeros);
+            } else {
+                return tk_null<SH>(a.zeros);
+            }
+        } else
         if constexpr (K < SC::KO) {
             return tk_row_tile<SH>(a.wqkv, (long long)l * SH::QKV + a.q0, (K - SC::KQ) * TK_NS + sw, a.qn, a.zeros);
         } else if constexpr (K < SC::KA) {
@@ -943,7 +848,7 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
             // w1|w3: tile 2m is RPT gate rows, tile 2m+1 the RPT up rows of the same hidden units (SwiGLU pairs stay in the CU);
             // partials are laid out (gate, up) per hidden unit
             const int ti = (K - SC::KA) * TK_NS + sw;
-            return tk_w13_tile<SH>(a, l, c, ti, ti < SH::NT_A_S);
+            return tk_w13_tile<SH>(a, l, c, ti, ti < SH::NT_A);
         } else if constexpr (K < SC::KP) {
             return tk_w2_tile<SH>(a, l, c, sw, K - SC::KD);
         } else {
@@ -951,6 +856,86 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
         }
     }
 }
+
+// COOP (q4_0): "lagged refill".  Slot K consumes ring entry K % NB and, INSIDE its dots, requests unit K + NB - 1 into the
+// entry slot K - 1 has just freed.  Issuing a load blocks while the CU's memory pipeline is full; spread through the dots it
+// never does, there is no refill burst anywhere (the f32 / f16 kernels place theirs behind the exchange instead, section 3b),
+// and a wave that polls after its phase has few requests of its own queued ahead of the poll.  Prefetch distance NB - 1 units.
+// the request slot K of a phase would issue from inside its dots (unit K + NB - 1 into the entry slot K - 1 has freed), as a
+// statement of its own: LLMK_TK_ADV_HOP issues it in the window BEFORE the phase, and the slot issues none
+template <class SH, int K, bool CLS>
+__device__ __forceinline__ void tk_request(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, int lane) {
+    constexpr int RN = (K + SH::NB - 1) % SH::NB;
+    if constexpr (CLS) r.t[RN] = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
+    else r.t[RN] = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
+    tk_issue<SH>(r.b[RN], r.t[RN], a.zeros, lane);
+}
+// One slot of a q4_0 phase: the unit in ring entry K % NB against the x image (q4_units.h), 16 partial sums to LDS; a wave
+// whose slot holds no unit (a CU with fewer row groups, the last round of a phase, the service wave of an attention CU, padding)
+// skips the dots -- its SIMD is then the partner wave's alone -- but issues the same nine loads: both arms of the branch leave
+// the same loads outstanding, so hipcc's counters stay exact (a load inside ONE arm would make every later wait a vmcnt(0)).
+template <class SH, int K, bool CLS, bool REQ = true>
+__device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const char* img, float* part, int lane) {
+    static_assert(SH::Q4, "q4_0 units");
+    constexpr int R = K % SH::NB, RN = (K + SH::NB - 1) % SH::NB;
+    const TkSlot<SH>& e = r.b[R];
+    TkTile tn;
+    if constexpr (!REQ) tn = r.t[RN];              // already requested (tk_request): the entry and its descriptor stay as they are
+    else if constexpr (CLS) tn = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
+    else tn = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
+    TkSlot<SH>& n = r.b[RN];
+    const bool nreal = tn.ncol != 0;
+    // the request in three pieces (4 + 4 + 1 loads), placed between the half groups of the dots
+    auto req = [&](auto piece) {
+        if constexpr (REQ) {
+            constexpr int P = decltype(piece)::value;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = (P == 0 ? 0 : P == 1 ? 4 : 8); j < (P == 0 ? 4 : P == 1 ? 8 : 9); ++j) n.b[j] = ldg_nt(nreal ? tn.p + j * WAVE + lane : a.zeros);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // a padding slot (the layer's slots rounded up to the ring depth) holds no unit on any wave of any CU
+    constexpr bool PAD = !CLS && (K % TkSched<SH>::SLP) >= TkSched<SH>::KP;
+    const TkTile tc = r.t[R];
+    if (!PAD && tc.ncol != 0) {                    // wave-uniform
+        Q16Lane ln;
+        q16_lane<SH::NBI>(ln, img, tc.pstep, lane);
+        const q16_v8h sel = q16_sel(lane);
+        q16_v4f acc = {0.f, 0.f, 0.f, 0.f}, acc8 = {0.f, 0.f, 0.f, 0.f};
+        q16_unit_dot(e.b, ln, sel, lane >> 4, acc, acc8, req);
+        q16_unit_store(acc, acc8, part + tc.pidx, lane);
+    } else {
+        req(std::integral_constant<int, 0>());
+        req(std::integral_constant<int, 1>());
+        req(std::integral_constant<int, 2>());
+    }
+    r.t[RN] = tn;
+}
+template <class SH, int K, int N, bool CLS, bool REQ0 = true>
+__device__ __forceinline__ void tk_steps(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const char* img, float* part, int lane) {
+    if constexpr (N > 0) {
+        tk_step<SH, K, CLS, REQ0>(r, a, l, c, sw, img, part, lane);
+        tk_steps<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, img, part, lane);
+    }
+}
+// REQ0 = false: the first slot's request was issued in the window before the phase (tk_request)
+template <class SH, int K0, int S, bool CLS, bool REQ0 = true>
+__device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const char* img, float* part, int lane) {
+    tk_barrier();
+    tk_steps<SH, K0, S, CLS, REQ0>(r, a, l, c, sw, img, part, lane);
+    tk_barrier();
+}
+// the ring starts with tiles 0 .. NB-2 requested; slot 0 requests tile NB-1
+template <class SH, int K>
+__device__ __forceinline__ void tk_prime_coop(TkRing<SH>& r, const TokenArgs& a, int c, int sw, int lane) {
+    if constexpr (K < SH::NB - 1) {
+        r.t[K] = tk_at<SH, K>(a, 0, c, sw);
+        tk_issue<SH>(r.b[K], r.t[K], a.zeros, lane);
+        tk_prime_coop<SH, K + 1>(r, a, c, sw, lane);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // In-kernel attention for one head on one CU, all 16 waves (llama2.f90:572-598).  q_h, k_pos, v_pos
@@ -1160,18 +1145,76 @@ __device__ __forceinline__ int tk_token(const TokenArgs& a, int c, int lane) {
     }
     return a.tokpos ? a.tokpos[0] : a.tok_imm;
 }
+// q4_0: row r of the CU's rows in a phase whose row groups are NCS units wide: the sum of its units' partials, ascending column
+// slot (a fixed order: run-to-run identical); ug0 = the first unit GROUP of the range (w1|w3: the up groups follow the gate groups)
+template <int NCS>
+__device__ __forceinline__ float tk_unit_row(const float* part, int ug0, int r) {
+    const float* p = part + (ug0 + (r >> 4)) * (NCS * Q16_ROWS) + (r & 15);
+    float v = p[0];
+#pragma unroll
+    for (int cs = 1; cs < NCS; ++cs) v += p[cs * Q16_ROWS];
+    return v;
+}
+// q4_0, layer 0: x = the embedding row (llama2.f90:520), xraw <- x, the image <- x * gains, returns sqrt(mean(x^2) + eps) (:450-457).
+// One wave, four 1 KB pieces at a time: this wave holds a ring of units, there is no room for TkNorm's 64 registers of gains.
+template <class SH>
+__device__ __forceinline__ float tk_stage_q16(const float* __restrict__ row, const float* __restrict__ gains, float* xraw, float* xs, int lane, float eps,
+                                              float& psc) {
+    float ss = 0.f;
+    constexpr int PER = SH::E / (4 * WAVE);
+    // first pass: the row's norm, for the power of two its image is scaled with (tk_pow2_inv); the second pass finds the row in L2
+#pragma unroll 1
+    for (int k0 = 0; k0 < PER; k0 += 4) {
+        float4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = reinterpret_cast<const float4*>(row)[lane + (k0 + i) * WAVE];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss = dot4(x[i], x[i], ss);
+    }
+    ss = wave_sum(ss);
+    const float xn = sqrtf(ss / (float)SH::E + eps);
+    psc = tk_pow2_inv(xn);
+#pragma unroll 1
+    for (int k0 = 0; k0 < PER; k0 += 4) {
+        float4 x[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = reinterpret_cast<const float4*>(row)[lane + (k0 + i) * WAVE];
+            w[i] = reinterpret_cast<const float4*>(gains)[lane + (k0 + i) * WAVE];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            reinterpret_cast<float4*>(xraw)[lane + (k0 + i) * WAVE] = x[i];
+            const float4 o = make_float4(x[i].x * w[i].x * psc, x[i].y * w[i].y * psc, x[i].z * w[i].z * psc, x[i].w * w[i].w * psc);
+            const int e = 4 * (lane + (k0 + i) * WAVE);
+            q16_put4(reinterpret_cast<char*>(xs), e, o);
+            float bs = (o.x + o.y) + (o.z + o.w);
+            bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
+            bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
+            bs += dpp_mov<0x114, 0xf, true>(0.f, bs);               // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
+            if ((lane & 7) == 7) q16_put_sum<SH::NBI>(reinterpret_cast<char*>(xs) + Q16Img<SH::NBI>::SUM + (e >> 5) * 2, bs);
+        }
+    }
+    return xn;
+}
 // GR: the pipelined-greedy variant (token from the previous launch's candidates, candidates of its own).  A separate
 // instantiation because the f32 kernel sits at the register ceiling: with the candidate code compiled in, hipcc spills 20
 // bytes per lane in the STREAMING waves' loop (one s_waitcnt vmcnt(0) + scratch store per slot: the ring drains).
 template <class SH, bool GR>
 __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c, int lane_in, int tid) {
-    const int lane = lane_in;
+    int lane = lane_in;     // (q4_0: made opaque once per layer, so that what is derived from it is recomputed there, not carried across the ring)
     typedef TkLds<SH> LD;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
     float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
-    const float* part = reinterpret_cast<const float*>(lds + LD::PART);
-    // q4_0: the streaming input is staged transposed (TkLds); 0 = natural order
+    float* part = reinterpret_cast<float*>(lds + LD::PART);
+    // q4_0: the streaming input is staged as an f16 hi | lo image (TkLds); 0 = natural order
     constexpr int TR_E = SH::TR_E, TR_H = SH::TR_H;
+    typedef TkSched<SH> SC;
+    // q4_0: this wave takes units like the seven others (not on an attention CU: a.nw = 7); the row sums of a phase are then
+    // spread over its units' partials (tk_unit_row)
+    [[maybe_unused]] TkRing<SH> r;
+    const char* img = lds + LD::XS;
+    if constexpr (SH::Q4) tk_prime_coop<SH, 0>(r, a, c, TK_NS, lane);
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);     // COOP: per-wave partial sums of squares
     volatile int* gflag = reinterpret_cast<volatile int*>(lds + LD::RED8 + 32);   // LLMK_TK_GF: gathers issued so far on this CU
     constexpr bool GF = LLMK_TK_GF && !SH::COOP;
@@ -1201,18 +1244,22 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 
     for (int l = 0; l < L; ++l) {
         const unsigned e_q = ebase + 5u * l + 1, e_att = e_q + 1, e_o = e_q + 2, e_a = e_q + 3, e_d = e_q + 4;
+        if constexpr (SH::Q4) asm volatile("" : "+v"(lane));
         TK_STAMP(0);
 
         // ---- P0: rmsnorm + QKV + RoPE                                            llama2.f90:527-565
-        TkNorm<SH::E> nrm;
+        TkNorm<SH::Q4 ? 4 * WAVE : SH::E> nrm;      // (q4_0: layer 0 is staged in pieces, tk_stage_q16: this wave holds a ring now)
         const bool coop0 = SH::COOP && l > 0;       // layer 0 starts from the embedding row: no exchange, this wave alone
-        if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane);
+        if constexpr (!SH::Q4) { if (!att_cu && !coop0) nrm.prefetch(tk_rms_att(a, l, SH::E), lane); }
         float xn_att = 1.f;
+        [[maybe_unused]] float sc_att = 1.f, sc_ffn = 1.f;      // q4_0: the power of two the gathered image was scaled with (tk_pow2_inv)
         if (GF && att_cu) { tk_flag_set(gflag, 4 * l + 1, lane); if (SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 1, lane); }   // no x and no xb gather on this CU: nothing for its bursts to wait for
         if (!att_cu) {   // an attention CU owns no QKV rows: it goes straight to the q poll
             if (coop0) {
                 if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
                 ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_q - 1, xraw, xs, tk_rms_att(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
+            } else if (SH::Q4) {
+                xn_att = tk_stage_q16<SH>(a.emb + (size_t)tok * SH::E, tk_rms_att(a, 0, SH::E), xraw, xs, lane, a.eps, sc_att);   // :520, :527
             } else if (l == 0) {
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
@@ -1221,15 +1268,26 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 ok = tk_gather<SH::E, 0, LLMK_TK_E_NL>(tk_g_x<SH>(a), e_q - 1, xraw, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 0 : nullptr, gflag, 4 * l) && ok;
             }
             TK_STAMP(1);
-            if (!coop0) xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps);
+            if constexpr (!SH::Q4) { if (!coop0) xn_att = nrm.template apply<TR_E>(xraw, xs, lane, a.eps); }
         }
         tk_barrier();
         if (coop0 && !att_cu) xn_att = tk_coop_xn<SH::E>(red8, a.eps);
+        if constexpr (SH::Q4) {
+            // every wave has written its slice with the scale it found; the next residual-stream gather on this CU uses this norm's
+            if (!att_cu) {
+                if (coop0) sc_att = red8[TK_XSC];
+                if (lane == 0) red8[TK_XSC] = tk_pow2_inv(xn_att);
+                xn_att *= sc_att;                       // (exact: the row sums are those of x * gains * 2^-e)
+            } else if (l == 0 && lane == 0) red8[TK_XSC] = 1.f;      // an attention CU's first scaled gather is layer 0's xa
+        }
         TK_STAMP(2);
+        if constexpr (SH::Q4) tk_steps<SH, SC::KQ, SH::SL_Q, false>(r, a, l, c, TK_NS, img, part, lane);
         tk_barrier();
         TK_STAMP(3);
         if (lane < a.qn) {
-            float v0 = part[lane], v1 = part[lane ^ 1];
+            float v0, v1;
+            if constexpr (SH::Q4) { v0 = tk_unit_row<SH::NCS_E>(part, 0, lane); v1 = tk_unit_row<SH::NCS_E>(part, 0, lane ^ 1); }
+            else { v0 = part[lane]; v1 = part[lane ^ 1]; }
             v0 = v0 / xn_att;
             v1 = v1 / xn_att;
             const int r = a.q0 + lane;
@@ -1368,6 +1426,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             }
         }
         // ---- P2: x += wo . xb                                                    llama2.f90:603-605
+        if constexpr (SH::Q4 && LLMK_TK_ADV_HOP != 0) tk_request<SH, SC::KO, false>(r, a, l, c, TK_NS, lane);   // (as the other seven waves: tk_stream_coop)
         if constexpr (SH::COOP) {
             // (this wave's slice is the last eighth of the vector: heads (E - E/8) / HS onwards)
             if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
@@ -1376,10 +1435,11 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         TK_STAMP(7);
         tk_barrier();
+        if constexpr (SH::Q4) tk_steps<SH, SC::KO, SH::SL_O, false, LLMK_TK_ADV_HOP == 0>(r, a, l, c, TK_NS, img, part, lane);
         tk_barrier();
         TK_STAMP(8);
         if (lane < a.on) {
-            const float v = part[lane];
+            const float v = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, lane) : part[lane];
             const int r = a.o0 + lane;
             tk_publish(tk_g_xa<SH>(a) + r, e_o, xraw[r] + v);
         }
@@ -1390,20 +1450,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
             ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             TK_STAMP(9);
-            if constexpr (SH::SVC_A) {
-                // the CU's last w1|w3 tile is this wave's (TkShape::SVC_A): requested and dotted between the phase's barriers, while
-                // the streaming waves run their three slots (its ~2.5 us of latency + 2 us of dots end inside their 6)
-                // (requested BEHIND barrier A: in front of it the barrier waited for the tile -- barA 0.18 -> 1.94 us in the first trace)
-                tk_barrier();
-                TkSlot<SH> st;
-                const TkTile tt = tk_w13_tile<SH>(a, l, c, SH::NT_A - 1, true);
-                tk_issue<SH>(st, tt, a.zeros, lane);
-                xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
-                tk_consume_q4_lean<SH>(st, tt, reinterpret_cast<const float4*>(xs), const_cast<float*>(part), lane);
-            } else {
-                tk_barrier();
-                xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
+            tk_barrier();
+            xn_ffn = tk_coop_xn<SH::E>(red8, a.eps);
+            if constexpr (SH::Q4) {
+                sc_ffn = red8[TK_XSC];
+                if (lane == 0) red8[TK_XSC] = tk_pow2_inv(xn_ffn);
+                xn_ffn *= sc_ffn;
             }
+            tk_steps<SH, SC::KA, SH::SL_A, false>(r, a, l, c, TK_NS, img, part, lane);
         } else {
             nrm.prefetch(tk_rms_ffn(a, l, SH::E), lane);
             if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
@@ -1415,12 +1469,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         TK_STAMP(10);
         tk_barrier();
         TK_STAMP(11);
-        if (lane < SH::R_A / 2) {
-            float gsum = part[2 * lane], usum = part[2 * lane + 1];
+        if (lane < (SH::Q4 ? a.hn : SH::R_A / 2)) {
+            // q4_0: the gate groups' units come first, then the up groups' (tk_at)
+            float gsum = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, lane) : part[2 * lane];
+            float usum = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, a.hn / Q16_ROWS, lane) : part[2 * lane + 1];
             gsum = gsum / xn_ffn;
             usum = usum / xn_ffn;
             const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
-            tk_publish(tk_g_hb<SH>(a) + c * (SH::R_A / 2) + lane, e_a, hb * usum);
+            tk_publish(tk_g_hb<SH>(a) + (SH::Q4 ? a.h0 : c * (SH::R_A / 2)) + lane, e_a, hb * usum);
         }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
@@ -1435,12 +1491,16 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         TK_STAMP(12);
         tk_barrier();
         TK_STAMP(13);
+        if constexpr (SH::Q4) tk_steps<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, TK_NS, img, part, lane);
         tk_barrier();
         TK_STAMP(14);
         if (lane < SH::R_D) {
             float v = 0.f;
+            if constexpr (SH::Q4) v = tk_unit_row<SH::NCS_H>(part, 0, lane);
+            else {
 #pragma unroll
             for (int p = 0; p < SH::TPR_H; ++p) v += part[lane * SH::TPR_H + p];
+            }
             const int r = c * SH::R_D + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
@@ -1455,6 +1515,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
         tk_barrier();
         xn_fin = tk_coop_xn<SH::E>(red8, a.eps);
+        if constexpr (SH::Q4) xn_fin *= red8[TK_XSC];
+        tk_steps<SH, 0, SH::SL_C, true>(r, a, L, c, TK_NS, img, part, lane);
     } else {
         TkNorm<SH::E> nrmf;
         nrmf.prefetch(tk_rms_final(a, SH::E), lane);
@@ -1465,12 +1527,13 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     }
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
-    for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = part[j] / xn_fin;
+    auto logit = [&](int j) { return (SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, j) : part[j]) / xn_fin; };
+    for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = logit(j);
     if constexpr (GR) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
         for (int j = lane; j < cn; j += WAVE) {       // the same quotient as the stored logit; ascending j per lane
-            const float v = part[j] / xn_fin;
+            const float v = logit(j);
             if (v > bv) { bv = v; bi = c0 + j; }
         }
         tk_wave_argmax(bv, bi);
@@ -1486,11 +1549,6 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
 // STREAMING wave: a static list of 8 KB row tiles, always NB requested ahead (register ring),
 // consumed between the phase's two barriers.  Nothing here depends on another CU.
 // ------------------------------------------------------------------------------------------------
-template <class SH>
-struct TkRing {
-    TkSlot<SH> b[SH::NB];
-    TkTile t[SH::NB];
-};
 
 // slots K .. K+N-1 (compile-time) of layer l: consume ring entry K % NB, refill it with slot K + NB
 template <class SH, int K, int N, bool CLS>
@@ -1570,112 +1628,6 @@ __device__ __forceinline__ void tk_phase(TkRing<SH>& r, const TokenArgs& a, int 
     }
 }
 
-// COOP: "lagged refill".  Slot K consumes ring entry K % NB and, INSIDE its ALU work, requests tile K + NB - 1 into the
-// entry slot K - 1 has just freed: one half of the loads after the first two rows' dots, the other half after the last
-// two.  Issuing a load blocks while the CU's memory pipeline is full; spread through 1.9 us of dequantise-and-dot it never
-// does, there is no refill burst anywhere (the f32 / f16 kernels place theirs behind the exchange instead, section 3b), and
-// a wave that polls after its phase has at most one tile of its own in flight.  Prefetch distance NB - 1 = 2 tiles.
-// the request slot K of a phase would issue from inside its dots (tile K + NB - 1 into the entry slot K - 1 has freed), as a
-// statement of its own: LLMK_TK_ADV_HOP issues it in the window BEFORE the phase, and the slot issues none
-template <class SH, int K, bool CLS>
-__device__ __forceinline__ void tk_request(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, int lane) {
-    constexpr int RN = (K + SH::NB - 1) % SH::NB;
-    if constexpr (CLS) r.t[RN] = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
-    else r.t[RN] = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
-    tk_issue<SH>(r.b[RN], r.t[RN], a.zeros, lane);
-}
-template <class SH, int K, bool CLS, bool REQ = true>
-__device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
-    static_assert(SH::Q4 && SH::RPT == 4 && SH::LPT == 2, "written for the q4_0 tile (4 rows x 2 segments)");
-    constexpr int R = K % SH::NB, RN = (K + SH::NB - 1) % SH::NB;
-    const TkSlot<SH>& e = r.b[R];
-    TkTile tn;
-    if constexpr (!REQ) tn = r.t[RN];              // already requested (tk_request): the entry and its descriptor stay as they are
-    else if constexpr (CLS) tn = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
-    else tn = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
-    TkSlot<SH>& n = r.b[RN];
-    // a padding slot (the layer's slots rounded up to the ring depth) holds no tile on any wave of any CU: it only keeps the
-    // ring turning -- the request, no dots
-    constexpr bool PAD = !CLS && (K % TkSched<SH>::SLP) >= TkSched<SH>::KP;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    auto row = [&](int s_) {
-        float acc = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const float4& w = e.b[s_ * 2 + jj];
-            const unsigned q[4] = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-            float tl, th;
-            tk_q4_dword_first(q[0], x.v[jj * 8], x.v[jj * 8 + 4], tl, th);
-#pragma unroll
-            for (int i = 1; i < 4; ++i) tk_q4_dword(q[i], x.v[jj * 8 + i], x.v[jj * 8 + 4 + i], tl, th);
-            const unsigned short hs = e.sc[s_ * 2 + jj];
-            const float d = __half2float(*reinterpret_cast<const __half*>(&hs));
-            acc = tk_q4_block(tl, th, d, x.xs8[jj], acc);
-        }
-        return acc;
-    };
-    if constexpr (!PAD) {
-        v[0] = row(0);
-        v[1] = row(1);
-    }
-    if constexpr (REQ) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < TK_TCOLS; ++j) {          // the tile's 8 nibble vectors
-            const int s_ = j / SH::LPT, jj = j % SH::LPT;
-            const bool real = jj < tn.ncol;
-            const float4* pj = real ? tn.p + s_ * tn.rstride + jj * WAVE : a.zeros;
-            n.b[j] = ldg_nt(pj + (real ? lane : 0));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (!PAD) {
-        v[2] = row(2);
-        v[3] = row(3);
-    }
-    if constexpr (REQ) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < TK_TCOLS; ++j) {          // ... and its 8 block scales
-            const int s_ = j / SH::LPT, jj = j % SH::LPT;
-            const bool real = jj < tn.ncol;
-            const unsigned short* pj = real ? reinterpret_cast<const unsigned short*>(reinterpret_cast<const char*>(tn.p + s_ * tn.rstride) + tn.soff) + jj * WAVE
-                                            : reinterpret_cast<const unsigned short*>(a.zeros);
-            n.sc[j] = __builtin_nontemporal_load(pj + (real ? lane : 0));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (!PAD) tk_rows4_reduce(v, r.t[R], part, lane);
-    r.t[RN] = tn;
-}
-template <class SH, int K, int N, bool CLS, bool REQ0 = true>
-__device__ __forceinline__ void tk_steps(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const TkX<SH>& x, float* part, int lane) {
-    if constexpr (N > 0) {
-        tk_step<SH, K, CLS, REQ0>(r, a, l, c, sw, x, part, lane);
-        tk_steps<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, x, part, lane);
-    }
-}
-// REQ0 = false: the first slot's request was issued in the window before the phase (tk_request)
-template <class SH, int K0, int S, bool CLS, bool WIDE = false, bool REQ0 = true>
-__device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const float4* xs4,
-                                              float* part, int lane) {
-    tk_barrier();
-    TkX<SH> x;
-    if constexpr (WIDE) x.template load_q4<SH::NBP_H>(xs4, (sw % SH::TPR_H) * SH::LPT, SH::NBLK_H, lane);
-    else x.template load_q4<SH::NBP_E>(xs4, 0, SH::NBLK_E, lane);
-    tk_steps<SH, K0, S, CLS, REQ0>(r, a, l, c, sw, x, part, lane);
-    tk_barrier();
-}
-// the ring starts with tiles 0 .. NB-2 requested; slot 0 requests tile NB-1
-template <class SH, int K>
-__device__ __forceinline__ void tk_prime_coop(TkRing<SH>& r, const TokenArgs& a, int c, int sw, int lane) {
-    if constexpr (K < SH::NB - 1) {
-        r.t[K] = tk_at<SH, K>(a, 0, c, sw);
-        tk_issue<SH>(r.b[K], r.t[K], a.zeros, lane);
-        tk_prime_coop<SH, K + 1>(r, a, c, sw, lane);
-    }
-}
-
 template <class SH, int K>
 __device__ __forceinline__ void tk_prime(TkRing<SH>& r, const TokenArgs& a, int c, int sw, int lane) {
     if constexpr (K < SH::NB) {
@@ -1749,7 +1701,7 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
     typedef TkSched<SH> SC;
     float* xs = reinterpret_cast<float*>(lds + LD::XS);
     float* xraw = reinterpret_cast<float*>(lds + LD::XRAW);
-    const float4* xs4 = reinterpret_cast<const float4*>(lds + LD::XS);
+    const char* xs4 = lds + LD::XS;                 // the x image the units are dotted with (q4_units.h)
     float* part = reinterpret_cast<float*>(lds + LD::PART);
     float* red8 = reinterpret_cast<float*>(lds + LD::RED8);
     constexpr int TR_E = SH::TR_E, TR_H = SH::TR_H;
@@ -1784,13 +1736,13 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
         // the wo slot's request, in the window of the attention hop (behind this CU's own attention, if it has any)
         if constexpr (ADVH) tk_request<SH, SC::KO, false>(r, a, l, c, sw, lane);
         if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
-        tk_phase_body<SH, SC::KO, SH::SL_O, false, false, !ADVH>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase_body<SH, SC::KO, SH::SL_O, false, !ADVH>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
-        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false, true>(r, a, l, c, sw, xs4, part, lane);
+        tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         if (l + 1 < L) {
             if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, a.err, sw, lane, nosync);
@@ -1814,12 +1766,23 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
         const int blk = c / HPC, ap = (blk / SH::KVMUL) % HPC;       // attention CU of this block of HPC CUs (see tk_service)
         const bool att_cu = (c % HPC) == ap;
         const int n = c - blk - ((c % HPC) > ap ? 1 : 0);            // rank among the CUs that own QKV / wo rows
-        a.qn = att_cu ? 0 : 2 * (SH::QB + (n < SH::QX ? 1 : 0));
-        a.q0 = 2 * (n * SH::QB + min(n, SH::QX));
+        a.qn = att_cu ? 0 : SH::QG * (SH::QB + (n < SH::QX ? 1 : 0));
+        a.q0 = SH::QG * (n * SH::QB + min(n, SH::QX));
         a.on = att_cu ? 0 : SH::RPT * (SH::OB + (n < SH::OX ? 1 : 0));
         a.o0 = SH::RPT * (n * SH::OB + min(n, SH::OX));
         a.cn = SH::RPT * (SH::CB + (c < SH::CX ? 1 : 0));
         a.c0 = SH::RPT * (c * SH::CB + min(c, SH::CX));
+        if constexpr (SH::Q4) {
+            // hidden units in whole 16-row groups: the row-owning CUs first (AB or AB + 1 groups each), then AG_ATT per attention CU
+            a.hn = Q16_ROWS * (att_cu ? SH::AG_ATT : SH::AB + (n < SH::AX ? 1 : 0));
+            a.h0 = Q16_ROWS * (att_cu ? SH::AG_W + blk * SH::AG_ATT : n * SH::AB + min(n, SH::AX));
+            a.nw = att_cu ? TK_NS : TK_WAVES;
+            // the image's blocks past the end of a K = H row (whole units are read), their sums, and the line of zeros: written once
+            char* img = lds + TkLds<SH>::XS;
+            for (int i = SH::H / 32 * Q16_IMG_BLK + tid * 16; i < SH::NBI * Q16_IMG_BLK; i += TK_THREADS * 16)
+                *reinterpret_cast<uint4*>(img + i) = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = Q16Img<SH::NBI>::SUM + tid * 4; i < Q16Img<SH::NBI>::BYTES; i += TK_THREADS * 4) *reinterpret_cast<unsigned*>(img + i) = 0u;
+        }
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
     else if constexpr (SH::COOP) tk_stream_coop<SH>(a, lds, c, wid, lane, tid);

@@ -273,7 +273,7 @@ program llm
         end do
      end if
      if (opts%temperature == 0) then
-        token = maxloc(logits, dim=1)
+        token = argmax1(logits)
      else
         probs = softmax_t(logits / opts%temperature)
         token = sample(probs)
@@ -294,7 +294,7 @@ program llm
      if (pos <= size(prompt_tokens)) then
         next_tok = prompt_tokens(pos)
      else if (opts%temperature == 0) then
-        next_tok = maxloc(logits, dim=1)
+        next_tok = argmax1(logits)
      else
         probs = softmax_t(logits / opts%temperature)
         next_tok = sample(probs)
@@ -377,6 +377,28 @@ contains
     end if
     deallocate(weights%token_embedding_table)
   end subroutine upload_weights
+
+  ! maxloc(v, dim=1) (llama2.f90:388: the first maximum, 1-based) in two vectorisable passes: eight running maxima, then the first
+  ! element equal to the largest.  flang's maxloc is a scalar compare-and-branch loop: 20-45 us for the 32,000 logits, 3-6 % of a
+  ! 0.68 ms token -- the one piece of host arithmetic on the path (measured: bench.py fortran_host, profiles/r05_*fortran_cli*).
+  function argmax1(v) result(idx)
+    real(kind=wp), intent(in) :: v(:)
+    integer :: idx, i, n8
+    real(kind=wp) :: m(8), mm
+    n8 = size(v) / 8 * 8
+    m = v(1)
+    do i = 1, n8, 8
+       m = max(m, v(i:i + 7))
+    end do
+    mm = maxval(m)
+    do i = n8 + 1, size(v)
+       mm = max(mm, v(i))
+    end do
+    do idx = 1, size(v)
+       if (v(idx) == mm) return
+    end do
+    idx = maxloc(v, dim=1)                    ! (a NaN among the logits: whatever the intrinsic answers)
+  end function argmax1
 
   ! Wall clock.  The reference converts a 4-byte millisecond count to real(4) BEFORE subtracting (llama2.f90:417-423):
   ! a count of ~1e9 has a 64-128 ms quantum as a float, which is nothing against its 60 s runs and everything against a
