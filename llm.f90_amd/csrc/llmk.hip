@@ -120,6 +120,7 @@ struct llmk_ctx {
     // layer l waits for batch k's K/V rows of layer l (event kv[l]).
     struct PfLane {
         float *X = nullptr, *Xs = nullptr, *Q = nullptr, *XB = nullptr, *HB = nullptr, *P = nullptr, *xn = nullptr;
+        unsigned* lowcnt = nullptr;        // [2][PF_TMAX]: the GEMM workgroups' votes on positions that are small as a whole (prefill.h pf_low_check)
         hipStream_t stream = nullptr;      // lane 0: the ctx stream
         std::vector<hipEvent_t> kv;        // per layer: this lane's batch has written its K/V rows
         hipEvent_t done = nullptr;         // this lane's batch has left the last layer
@@ -716,6 +717,7 @@ void pf_teardown(llmk_ctx* c) {
     for (PfLane& w : c->pf) {
         float** bufs[] = {&w.X, &w.Xs, &w.Q, &w.XB, &w.HB, &w.P, &w.xn};
         for (float** b : bufs) { if (*b) hipFree(*b); *b = nullptr; }
+        if (w.lowcnt) { hipFree(w.lowcnt); w.lowcnt = nullptr; }
         for (hipEvent_t e : w.kv) if (e) hipEventDestroy(e);
         w.kv.clear();
         if (w.done) { hipEventDestroy(w.done); w.done = nullptr; }
@@ -749,6 +751,8 @@ int pf_setup_inner(llmk_ctx* c) {
         HIPCHK(dev_alloc(&w.HB, T * c->H * sizeof(float)));
         HIPCHK(dev_alloc(&w.P, pcap * sizeof(float)));
         HIPCHK(dev_alloc(&w.xn, T * sizeof(float)));
+        HIPCHK(dev_alloc(&w.lowcnt, 2 * T * sizeof(unsigned)));
+        HIPCHK(hipMemset(w.lowcnt, 0, 2 * T * sizeof(unsigned)));
         if (i == 0) w.stream = c->stream;
         else HIPCHK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         w.kv.assign(c->L, nullptr);
@@ -825,9 +829,9 @@ hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, con
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
     if (c->pf_hm) {
         constexpr size_t smem_h = pf_gemm_h_smem<NG, NR>();
-        if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_Q4_0>), grid, block, smem_h, w.stream, a, c->pf_flag);
-        else if (c->cfg.weight_type == LLMK_TYPE_F16) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F16>), grid, block, smem_h, w.stream, a, c->pf_flag);
-        else hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F32>), grid, block, smem_h, w.stream, a, c->pf_flag);
+        if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_Q4_0>), grid, block, smem_h, w.stream, a, c->pf_flag, w.lowcnt);
+        else if (c->cfg.weight_type == LLMK_TYPE_F16) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F16>), grid, block, smem_h, w.stream, a, c->pf_flag, w.lowcnt);
+        else hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F32>), grid, block, smem_h, w.stream, a, c->pf_flag, w.lowcnt);
         return hipGetLastError();
     }
     if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_kernel<NG, WT_Q4_0, NR>), grid, block, smem, w.stream, a);
@@ -844,6 +848,7 @@ hipError_t pf_gemm(llmk_ctx* c, const PfLane& w, const void* W, int row_stride, 
     a.trace = (unsigned long long*)(X == w.HB ? w.Q : w.HB);   // debug build: stamps land in the SwiGLU buffer (llmk_peek 7); the w2 GEMM reads that one: its stamps go to the (dead) q buffer
 #endif
     e->U = p.U; e->nk = p.nk; e->sh = p.nr == 2 ? 7 : 6;
+    e->lowcnt = c->pf_hm ? w.lowcnt : nullptr; e->flag = c->pf_flag; e->gemm_blocks = p.grid;
 #define PF_CASE(NG_)                                                                         \
     case NG_: return p.nr == 2 ? pf_gemm_launch<NG_, 2>(c, w, a, p) : pf_gemm_launch<NG_, 1>(c, w, a, p)
     switch ((T + 15) / 16) {
@@ -1470,13 +1475,27 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     if (c->pf_hm) HIPCHK(hipMemcpyAsync(h_flag, c->pf_flag, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->pf_hm && *h_flag) {
-        // an activation of this prompt does not fit an f16 (|x| >= 65504): this context's GEMMs go back to the f32 matrix
-        // instruction for good, and the call is redone (the K/V rows it wrote are rewritten)
+        // bit 0: an activation of this prompt does not fit an f16 (|x| >= 65504, or not finite): this context's GEMMs go back to
+        // the f32 matrix instruction for good.  Bit 1 alone: a position whose whole row is below 2^-7 (the lo piece of the split
+        // is an f16 subnormal there): THIS call is redone on the f32 instruction, the next one tries the f16 one again (advisor,
+        // round 4: a BOS or early-layer row with genuinely small values must not cost the context the fast path).
+        // Either way the call is redone (the K/V rows it wrote are rewritten) and the first event says so once.
+        const bool for_good = (*h_flag & 1u) != 0;
+        static bool told = false;
+        if (!told) {
+            told = true;
+            fprintf(stderr, "llmk: llmk_prefill met %s; %s\n", for_good ? "an activation beyond the f16 range" : "a position whose activations are all below 2^-7",
+                    for_good ? "this context's prompt GEMMs run on the f32 matrix instruction from now on" : "this call is redone on the f32 matrix instruction");
+        }
+        HIPCHK(hipMemsetAsync(c->pf_flag, 0, sizeof(unsigned), c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
         pf_teardown(c);
         c->pf_hm = false;
         rc = pf_setup(c);
         if (rc) return rc;
-        return llmk_prefill(c, tokens, n, pos0, logits_out);
+        rc = llmk_prefill(c, tokens, n, pos0, logits_out);
+        if (!for_good) pf_teardown(c);          // (pf_ready = false: the next call sets the f16 instruction up again)
+        return rc;
     }
     memcpy(logits_out, c->h_logits, (size_t)c->V * sizeof(float));
     return LLMK_OK;

@@ -342,7 +342,7 @@ __device__ __forceinline__ void pf_ring(F& step, int s, int nsteps) {      // (N
 // (n - 8) d exactly (n - 8 as f16: byte n under 0x64 is the half 1024 + n, minus 1032; times the row's f16 block scale through
 // v_fma_mix_f32) and feeds each as two f16 pieces: see the step.
 template <int NG, int NR, int WT = WT_F16>
-__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag) {
+__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag, unsigned* __restrict__ lowcnt) {
     constexpr int NW = PF_WAVES, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
     constexpr bool Q4 = WT == WT_Q4_0, F32W = WT == WT_F32;
     // ring depth: f16 six 16-byte stages; q4_0 four (longer steps); f32 four / three (a stage is 32 bytes per chunk and row group)
@@ -610,10 +610,12 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
     // below 2^-3 the lo piece is an f16 subnormal and the pair's error is 2^-24 ABSOLUTE, not 2^-20 relative -- harmless for
     // the small elements of an O(1) row, but a position whose WHOLE row is small (attention output or SwiGLU output of a model
     // with tiny values there) would carry 2^-24 / |row| into every product.  The 16 lanes that stage one position's 64 columns
-    // fold their running maxima (DPP row): a position whose largest element over all of this block's steps is below 2^-7 --
-    // and not an all-zero row -- raises the same flag, and llmk_prefill redoes the call on the f32 instruction.
+    // fold their running maxima (DPP row).  A workgroup sees only ITS column steps of a row (advisor, round 4: a row whose large
+    // elements lie in another workgroup's steps must not count), so it only VOTES: a position whose largest element over this
+    // block's steps is below 2^-7 adds one to lowcnt[t] -- and one to lowcnt[PF_TMAX + t] unless the slice is all zero.  The
+    // epilogue kernel that follows every GEMM (pf_low_check) raises bit 1 of the flag for a position ALL workgroups voted
+    // for, not all of them with zeros, and clears the counters.  With activations of ordinary size no atomic is issued at all.
     float amax = wmax;
-    bool small = false;
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         amax = fmaxf(amax, rmax[i]);
@@ -622,9 +624,13 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a
         r = fmaxf(r, dpp_mov<0x4E, 0xf, false>(0.f, r));     // quad_perm [2,3,0,1]
         r = fmaxf(r, dpp_mov<0x141, 0xf, false>(0.f, r));    // row_half_mirror
         r = fmaxf(r, dpp_mov<0x140, 0xf, false>(0.f, r));    // row_mirror: every lane of the row holds the row's maximum
-        small = small || (r > 0.f && r < 0.0078125f);
+        const int t = (tid + i * NT) / (PF_KSTEP / 4);
+        if (r < 0.0078125f && (lane & 15) == 0 && t < a.T) {
+            atomicAdd(lowcnt + t, 1u);
+            if (r > 0.f) atomicAdd(lowcnt + PF_TMAX + t, 1u);
+        }
     }
-    if (__any(!(amax < 65504.0f) || small) && lane == 0) atomicOr(flag, 1u);     // (NaN counts)
+    if (__any(!(amax < 65504.0f)) && lane == 0) atomicOr(flag, 1u);     // (NaN counts)
 #ifdef LLMK_PF_TRACE
     if (tid == 0) { tr[17] = wall_clock64(); tr[19] = __builtin_readcyclecounter(); }
 #endif
@@ -813,7 +819,21 @@ struct PfEpiArgs {
     int rows, Tp, T, pos0;       // pos0: 1-based position of token 0
     int U, nk, sh;               // the GEMM's units per block / steps per strip (PfGemmArgs): the strip r >> sh has pf_nslots partials
     int E, KV, hs, H;
+    unsigned* lowcnt;            // [2][PF_TMAX] votes of the GEMM's workgroups (pf_gemm_h_kernel), null on the f32-instruction path
+    unsigned* flag;
+    int gemm_blocks;             // workgroups of the GEMM this epilogue follows
 };
+// the first workgroup of the epilogue that follows a GEMM on the f16 instruction: a position every workgroup found small in its
+// column steps -- and not all of them zero -- is small as a whole (bit 1 of the flag: llmk_prefill redoes this call on the f32
+// instruction); the votes are cleared for the next GEMM of this lane
+__device__ __forceinline__ void pf_low_check(const PfEpiArgs& a, bool first_block) {
+    if (!a.lowcnt || !first_block) return;
+    for (int t = threadIdx.x; t < a.T; t += blockDim.x) {
+        const unsigned n = a.lowcnt[t], nz = a.lowcnt[PF_TMAX + t];
+        if (n | nz) { a.lowcnt[t] = 0u; a.lowcnt[PF_TMAX + t] = 0u; }
+        if (n == (unsigned)a.gemm_blocks && nz > 0u) atomicOr(a.flag, 2u);
+    }
+}
 
 // partials of (t, r) added in slot order; four loads in flight at a time (the trip count is a run-time value: a plain
 // loop would wait for each load before asking for the next)
@@ -869,6 +889,7 @@ __global__ void pf_epi_qkv_kernel(PfEpiArgs a) {
     // a thread takes four rows = two pairs (16-byte loads of the partial tiles); E, KV and the head size are multiples of 4,
     // so both pairs lie in the same part (q, k or v)
     const int p4 = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    pf_low_check(a, blockIdx.x == 0 && blockIdx.y == 0);
     if (p4 >= a.rows / 4) return;
     const float4 s4 = pf_sum4(a, t, 4 * p4);
     pf_epi_qkv_pair(a, t, 4 * p4, s4.x / a.xn[t], s4.y / a.xn[t]);
@@ -880,6 +901,7 @@ __global__ __launch_bounds__(1024) void pf_epi_resid_norm_kernel(PfEpiArgs a, co
                                                                  float* __restrict__ xn, float eps) {
     __shared__ float red[16];
     const int t = blockIdx.x, tid = threadIdx.x;
+    pf_low_check(a, blockIdx.x == 0);
     float ss = 0.f;
     for (int r = 4 * tid; r < a.rows; r += 4096) {       // rows % 64 == 0 on this path (llmk_prefill)
         const float4 x = *reinterpret_cast<const float4*>(a.out + (size_t)t * a.rows + r), d = pf_sum4(a, t, r);
@@ -904,6 +926,7 @@ __global__ __launch_bounds__(1024) void pf_epi_resid_norm_kernel(PfEpiArgs a, co
 // hb = silu(gate) * up                                                                  :613-616
 __global__ void pf_epi_swiglu_kernel(PfEpiArgs a) {
     const int g = 4 * (blockIdx.x * blockDim.x + threadIdx.x), t = blockIdx.y;      // four hidden units per thread (H % 64 == 0)
+    pf_low_check(a, blockIdx.x == 0 && blockIdx.y == 0);
     if (g >= a.H) return;
     const float xn = a.xn[t];
     const float4 gs = pf_sum4(a, t, g), us = pf_sum4(a, t, g + a.H);

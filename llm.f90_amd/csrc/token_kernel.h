@@ -117,6 +117,10 @@
 #ifndef LLMK_TK_ADV_HOP
 #define LLMK_TK_ADV_HOP 1
 #endif
+// (round 5, measured and removed: the QKV slots' requests issued in the hop too -- three units per wave at its start: kernel
+// 1,111 -> 1,143 us, and worse with a pause before the first xb poll (1,154 / 1,195 us for 0.85 / 2.6 us): 216 KB per CU keep
+// HBM saturated for 8.6 us, the attention CUs' K/V rows and q polls queue in it, and xb arrives later everywhere;
+// profiles/r05_ab.jsonl "hopq".  One unit per wave is what the hop takes.)
 
 namespace llmk {
 
@@ -912,6 +916,7 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
     }
     r.t[RN] = tn;
 }
+// REQ0 = false: the first slot's request was issued in the window before the phase (tk_request)
 template <class SH, int K, int N, bool CLS, bool REQ0 = true>
 __device__ __forceinline__ void tk_steps(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const char* img, float* part, int lane) {
     if constexpr (N > 0) {
@@ -919,7 +924,6 @@ __device__ __forceinline__ void tk_steps(TkRing<SH>& r, const TokenArgs& a, int 
         tk_steps<SH, K + 1, N - 1, CLS>(r, a, l, c, sw, img, part, lane);
     }
 }
-// REQ0 = false: the first slot's request was issued in the window before the phase (tk_request)
 template <class SH, int K0, int S, bool CLS, bool REQ0 = true>
 __device__ __forceinline__ void tk_phase_body(TkRing<SH>& r, const TokenArgs& a, int l, int c, int sw, const char* img, float* part, int lane) {
     tk_barrier();

@@ -240,6 +240,17 @@ program llm
      freqs(j) = 1.0 / (rope_base ** (real(2*j - 1, kind=wp) / hs))
   end do
   call llmk_check(llmk_set_rope_freqs(ctx, freqs, int(hs / 2, c_int)), "llmk_set_rope_freqs")
+  ! which of the two implementations of the pass this shape and weight type get (include/llmk.h llmk_path): the persistent
+  ! whole-token kernel exists for the compiled-in shapes only (the reference's dims are compile-time too, llama2.f90:102-108);
+  ! every other model runs -- correctly, at roughly two thirds of the rate -- on five launches per layer.  Said under --vx.
+  if (opts%verbose_ext .and. lead) then
+     select case (llmk_path(ctx))
+     case (1); print *, "device path: persistent whole-token kernel"
+     case (2); print *, "device path: tensor-parallel, one-shot peer-memory collectives"
+     case (3); print *, "device path: tensor-parallel, RCCL collectives"
+     case default; print *, "device path: five kernels per layer (no persistent kernel is instantiated for this shape and weight type)"
+     end select
+  end if
 
   allocate(logits(conf%vocab_size), probs(conf%vocab_size))
   s%times = 0

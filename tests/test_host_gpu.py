@@ -250,3 +250,13 @@ def test_fortran_cli_rate_is_the_ctypes_rate_at_full_tinyllama_size():
     assert fh["ids_match"] == "256/256" and fh["ids_match_device_argmax"] == "256/256", fh
     assert fh["tok_s"] >= 0.97 * d["value"], (fh, d["value"])
     assert fh["tok_s_device_argmax"] >= 0.97 * fh["tok_s"], fh
+
+
+def test_cli_vx_says_which_device_path_a_shape_gets(gguf, tmp_path):
+    """Round-4 verdict, "weak" 9: a shape without a persistent-kernel instantiation silently took the five-launch path.  `--vx`
+    (this host's own verbose lines; `-v` stays the reference's transcript) now says which one runs (include/llmk.h llmk_path)."""
+    for shape, want in (("tk-small", b"device path: persistent whole-token kernel"), ("tiny-hs64", b"device path: five kernels per layer")):
+        path = str(tmp_path / (shape + ".gguf"))
+        gguf.write_synth_gguf(path, gguf.SHAPES[shape], 5)
+        out = _run(["-m", path, "-n", "4", "--vx"], str(tmp_path))
+        assert want in out, out[-600:]
