@@ -106,7 +106,7 @@ struct llmk_ctx {
     bool use_tk = false;
     bool tk_short_grid = false;   // libllmk_debug.so only (LLMK_TK_INJECT_TIMEOUT)
     bool tk_retired = false;   // the token kernel timed out once on this ctx: it stays on the multi-kernel path
-    int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape, 5 Llama-2-7B q4_0
+    int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape, 5 Llama-2-7B q4_0, 6 TinyLlama q4_0
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x | attention parts
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
@@ -383,7 +383,8 @@ hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false, const TkGreedy&
         case 2: return launch_token_kernel_t<TkSmall>(c, direct, g);
         case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct, g);
         case 4: return launch_token_kernel_t<TkSmallF16>(c, direct, g);
-        default: return launch_token_kernel_t<TkLlama7BQ4>(c, direct, g);
+        case 5: return launch_token_kernel_t<TkLlama7BQ4>(c, direct, g);
+        default: return launch_token_kernel_t<TkTinyLlamaQ4>(c, direct, g);
     }
 }
 // the last position of a pipelined greedy run has no next launch to fold its candidates: this does (1 wave)
@@ -577,7 +578,7 @@ int check_ready(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     for (int i = 0; i < LLMK_N_TENSORS; ++i)
         if (!c->t[i].uploaded) return LLMK_E_STATE;
-    if (c->use_tk && c->tk_shape == 5 && c->q16_dirty) return q16_build(c);
+    if (c->use_tk && c->tk_shape >= 5 && c->q16_dirty) return q16_build(c);
     return LLMK_OK;
 }
 
@@ -1066,6 +1067,7 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
         if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
         if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4>(c, 5);
+        if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaQ4>(c, 6);
     }
     if (rc == LLMK_OK) {   // raise the dynamic-LDS limits the token pass needs, or reject the shape here (see g_prepare)
         g_prepare = true;

@@ -174,6 +174,7 @@ struct TokenArgs {
     int c0, cn;              // this CU's rows of the classifier
     int h0, hn;              // q4_0: this CU's hidden units (w1|w3 gate / up row pairs; f32 / f16: c * H / 256, compile-time count)
     int nw;                  // q4_0: waves of this CU that take units (8; 7 on an attention CU)
+    int d0, dn;              // q4_0: this CU's rows of w2 (f32 / f16: c * E / 256, compile-time count)
     // Pipelined greedy decode (llmk_decode_greedy): `token = maxloc(logits,DIM=1)` (llama2.f90:388) without a host round
     // trip.  Every CU leaves the first maximum of ITS classifier rows in cand_out[c] = {logit, 0-based row}; the NEXT launch
     // (ordered behind this one by the stream) starts by folding the 256 candidates of cand_in -- 2 KB, first maximum wins --
@@ -270,7 +271,10 @@ struct TkShape {
     // hidden units (w1|w3 gate / up row pairs) per CU.  f32 / f16: H / 256 everywhere.  q4_0: whole 16-row groups -- an attention
     // CU, whose service wave never streams (7 waves share its units), takes AG_ATT groups, the others split the rest
     static constexpr int AG_ATT = (H / Q16_ROWS) / TK_NCU, AG_W = H / Q16_ROWS - NH * AG_ATT, AB = AG_W / NCU_W, AX = AG_W % NCU_W;
-    static constexpr int R_A = Q4 ? 2 * Q16_ROWS * (AB + (AX > 0 ? 1 : 0)) : 2 * (H / TK_NCU), R_D = E / TK_NCU;
+    // w2 rows per CU: E / 256; q4_0: whole 16-row groups, DB or DB + 1 of them (TinyLlama: 128 groups, one on every other... CU c < DX)
+    static constexpr int DB = (E / Q16_ROWS) / TK_NCU, DX = (E / Q16_ROWS) % TK_NCU;
+    static constexpr int R_A = Q4 ? 2 * Q16_ROWS * (AB + (AX > 0 ? 1 : 0)) : 2 * (H / TK_NCU),
+                         R_D = Q4 ? Q16_ROWS * (DB + (DX > 0 ? 1 : 0)) : E / TK_NCU;
     static constexpr int TPR_H = (LPR_H + LPT - 1) / LPT;                // column parts of a w2 row
     // how the staging code is told which image of the input vector to write: 0 natural order (f32), > 0 the f16 hi | lo image
     // of that many blocks (q4_0: q4_units.h Q16Img)
@@ -294,12 +298,12 @@ struct TkShape {
     static constexpr int MAXP00 = RA_P > R_C ? RA_P : R_C, MAXP0 = MAXP00 > RQ_P ? MAXP00 : RQ_P, MAXP1 = R_D * TPR_H,
                          MAXPT = MAXP0 > MAXP1 ? MAXP0 : MAXP1,          // partial sums per phase (f32 / f16: one per tile row)
                          MAXP = Q4 ? Q16_ROWS * tk_cmax(tk_cmax(UQ, UA), tk_cmax(UD, UC)) : MAXPT;   // q4_0: 16 per unit
-    static_assert(QKV % 2 == 0 && E % TK_NCU == 0 && (Q4 || H % TK_NCU == 0) && V % RPT == 0, "rows must split over CUs");
+    static_assert(QKV % 2 == 0 && (Q4 || (E % TK_NCU == 0 && H % TK_NCU == 0)) && V % RPT == 0, "rows must split over CUs");
     static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
     static_assert((Q4 || (LPR_E <= LPT && R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
                   "a K = E row is one tile row; row ranges are whole tiles");
-    static_assert(!Q4 || (E % 1024 == 0 && QKV % Q16_ROWS == 0 && KV % Q16_ROWS == 0 && H % Q16_ROWS == 0 && AG_ATT >= 1 && E / Q16_ROWS % TK_NCU == 0),
-                  "q4_0: K = E rows are whole units, every matrix whole 16-row groups, one w2 group (or more) per CU");
+    static_assert(!Q4 || (E % 1024 == 0 && QKV % Q16_ROWS == 0 && KV % Q16_ROWS == 0 && H % Q16_ROWS == 0 && AG_ATT >= 1),
+                  "q4_0: K = E rows are whole units, every matrix whole 16-row groups, a hidden group (or more) per attention CU");
     static_assert(NH <= TK_NCU && TK_NCU % NH == 0, "one CU per head");
     static_assert(R_Q <= 64 && R_A / 2 <= 64 && R_O <= 64, "one service lane per output");
     static_assert(HS == 64 || HS == 128, "in-kernel attention is written for head sizes 64 and 128");
@@ -838,8 +842,8 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
                                        SH::NCS_E, sw, a.nw, a.zeros);
                 return t;
             } else if constexpr (K < SC::KP) {
-                return tk_unit<SH>(a.w2, (l * SH::E + c * SH::R_D) / Q16_ROWS * SH::NCS_H, (K - SC::KD) * a.nw + sw,
-                                   SH::UD, SH::NCS_H, sw, a.nw, a.zeros);
+                return tk_unit<SH>(a.w2, (l * SH::E + a.d0) / Q16_ROWS * SH::NCS_H, (K - SC::KD) * a.nw + sw,
+                                   a.dn / Q16_ROWS * SH::NCS_H, SH::NCS_H, sw, a.nw, a.zeros);
             } else {
                 return tk_null<SH>(a.zeros);
             }
@@ -1498,14 +1502,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if constexpr (SH::Q4) tk_steps<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, TK_NS, img, part, lane);
         tk_barrier();
         TK_STAMP(14);
-        if (lane < SH::R_D) {
+        if (lane < (SH::Q4 ? a.dn : SH::R_D)) {
             float v = 0.f;
             if constexpr (SH::Q4) v = tk_unit_row<SH::NCS_H>(part, 0, lane);
             else {
 #pragma unroll
             for (int p = 0; p < SH::TPR_H; ++p) v += part[lane * SH::TPR_H + p];
             }
-            const int r = c * SH::R_D + lane;
+            const int r = (SH::Q4 ? a.d0 : c * SH::R_D) + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
@@ -1544,8 +1548,8 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if (lane == 0) tk_cand(a, pos & 1)[c] = make_float2(bv, __int_as_float(bi));
     }
     if (!ok && lane == 0) {
-        atomicOr(a.err, 0x1000u);
-        if (a.herr) __hip_atomic_store(a.herr, 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned cause = atomicOr(a.err, 0x1000u);      // (what the first failing wave left there: a timed-out spin's code, 0x4000 ...)
+        if (a.herr) __hip_atomic_store(a.herr, cause | 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1781,6 +1785,8 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
             a.hn = Q16_ROWS * (att_cu ? SH::AG_ATT : SH::AB + (n < SH::AX ? 1 : 0));
             a.h0 = Q16_ROWS * (att_cu ? SH::AG_W + blk * SH::AG_ATT : n * SH::AB + min(n, SH::AX));
             a.nw = att_cu ? TK_NS : TK_WAVES;
+            a.dn = Q16_ROWS * (SH::DB + (c < SH::DX ? 1 : 0));
+            a.d0 = Q16_ROWS * (c * SH::DB + min(c, SH::DX));
             // the image's blocks past the end of a K = H row (whole units are read), their sums, and the line of zeros: written once
             char* img = lds + TkLds<SH>::XS;
             for (int i = SH::H / 32 * Q16_IMG_BLK + tid * 16; i < SH::NBI * Q16_IMG_BLK; i += TK_THREADS * 16)
@@ -1798,5 +1804,6 @@ typedef TkShape<256, 768, 4, 2, 1024> TkSmall;           // tests/golden/tk-smal
 typedef TkShape<2048, 5632, 32, 4, 32000, WT_F16> TkTinyLlamaF16;   // BASELINE.json configs[2]: the same model, f16 matrices
 typedef TkShape<512, 1536, 8, 2, 1024, WT_F16> TkSmallF16;          // parity shape for the f16 tiles (tests: tk-small16)
 typedef TkShape<4096, 11008, 32, 32, 32000, WT_Q4_0> TkLlama7BQ4;   // BASELINE.json configs[3]: Llama-2-7B, q4_0 matrices, head size 128
+typedef TkShape<2048, 5632, 32, 4, 32000, WT_Q4_0> TkTinyLlamaQ4;   // TinyLlama-1.1B with q4_0 matrices (GQA, head size 64): the units kernel's second shape
 
 }  // namespace llmk

@@ -344,6 +344,29 @@ def test_token_kernel_timeout_retires_it_and_the_token_is_redone_on_the_multi_ke
     assert b"timed out" in r.stderr and b"multi-kernel path" in r.stderr
 
 
+def test_tinyllama_q4_0_token_kernel_matches_oracle(gguf):
+    """The q4_0 persistent kernel's second shape (round 5): TinyLlama-1.1B with q4_0 matrices -- GQA, head size 64, rows that are
+    two units wide, row ranges of 0 or 1 group on many CUs -- against the f32 reference path (oracle) on the host-decoded
+    weights, 280 positions (KV lengths cross the attention tile), teacher-forced; and the multi-kernel path beside it."""
+    s = gguf.SHAPES["tinyllama"]
+    fw = gguf.synth_fused(s, 20260928, 2)
+    n = 280
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    m = llmk.Llmk(fw)
+    assert m.path() == 1 and m.time_kernel(6, 1)[0] > 0
+    m.reset()
+    _, l = m.generate(n, prompt=ot.tolist())
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+    t2, _ = m.generate(24, want_logits=False, greedy_on_device=True)
+    first_unsafe = int(np.argmin(safe[:24])) if not safe[:24].all() else 24
+    assert np.array_equal(t2[:first_unsafe], ot[:first_unsafe])
+    m.close()
+
+
 def test_llama2_7b_column_geometry_q4_0_matches_oracle(gguf):
     """BASELINE.json configs[3] at its REAL column geometry -- E 4096, H 11008 (5.375 KB of nibbles per w2 row), head size
     128, MHA, V 32000 -- with 2 layers so the oracle (f32 reference path on the host-decoded q4_0 weights) finishes in
@@ -364,6 +387,42 @@ def test_llama2_7b_column_geometry_q4_0_matches_oracle(gguf):
         err = rel_err(l, ol)
         assert err.max() <= REL_TOL, (flags, err.max(), int(np.argmax(err)))
         assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+
+
+def test_llama2_7b_q4_0_activation_beyond_f16_falls_back_to_the_multi_kernel_path(gguf):
+    """The q4_0 persistent kernel dots its units against an f16 hi | lo image of x (csrc/q4_units.h).  Residual-stream images
+    are scaled by a power of two from the previous rmsnorm, so a residual that merely GROWS is fine (the full-depth golden's does,
+    past 65504); what cannot be held is a value far above the vector's norm -- here rmsnorm gains of 2^20 in layer 1.  The gather
+    that meets it raises the sticky word (0x4000), the shim retires the kernel for the context, redoes the position on the
+    multi-kernel path (f32 throughout) and says so once: the caller sees the oracle's logits."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import llm_f90_amd\n"
+        "from llm_f90_amd import llmk\n"
+        "from llm_f90_amd.tools import gguf\n"
+        "from oracle.oracle import Oracle\n"
+        "from conftest import rel_err, REL_TOL\n"
+        "s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 64)\n"
+        "fw = gguf.synth_fused(s, 7, 2)\n"
+        "fw.rms_att_weight = fw.rms_att_weight.copy(); fw.rms_att_weight[1] *= np.float32(2.0 ** 20)\n"
+        "fw.wqkv = fw.wqkv.copy()\n"
+        "n = 6\n"
+        "ot, ol = Oracle(fw.as_f32(), 'omp').generate(n)\n"
+        "assert np.all(np.isfinite(ol))\n"
+        "m = llmk.Llmk(fw)\n"
+        "assert m.path() == 1\n"
+        "_, l = m.generate(n, prompt=ot.tolist())\n"
+        "assert m.path() == 0\n"
+        "assert rel_err(l, ol).max() <= REL_TOL, rel_err(l, ol)\n"
+        "print('FALLBACK-OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"FALLBACK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert b"beyond the f16 range" in r.stderr and b"multi-kernel path" in r.stderr
 
 
 @pytest.fixture(scope="module")
