@@ -172,9 +172,6 @@ struct TokenArgs {
     // filled in per workgroup by the kernel: this CU's rows of the QKV and wo matrices (none on an attention CU)
     int q0, qn, o0, on;
     int c0, cn;              // this CU's rows of the classifier
-    int h0, hn;              // q4_0: this CU's hidden units (w1|w3 gate / up row pairs; f32 / f16: c * H / 256, compile-time count)
-    int nw;                  // q4_0: waves of this CU that take units (8; 7 on an attention CU)
-    int d0, dn;              // q4_0: this CU's rows of w2 (f32 / f16: c * E / 256, compile-time count)
     // Pipelined greedy decode (llmk_decode_greedy): `token = maxloc(logits,DIM=1)` (llama2.f90:388) without a host round
     // trip.  Every CU leaves the first maximum of ITS classifier rows in cand_out[c] = {logit, 0-based row}; the NEXT launch
     // (ordered behind this one by the stream) starts by folding the 256 candidates of cand_in -- 2 KB, first maximum wins --
@@ -185,6 +182,15 @@ struct TokenArgs {
     // The flags share the word of the debug build's "do not wait" switch, and with TKG_CAND_IN the unused tok_imm carries
     // the index of the id to store: the argument block is exactly as large as before.
 };
+// What a q4_0 kernel's workgroup adds for itself (token_kernel fills it in; never part of the launch's argument block -- the
+// f32 / f16 instantiations sit at the SGPR ceiling and their code is sensitive to that block's very layout): the kernel works on
+// a TokenArgsQ4 and hands it on as the TokenArgs it is; tk_q4() reads the rest back.
+struct TokenArgsQ4 : TokenArgs {
+    int h0, hn;              // this CU's hidden units (w1|w3 gate / up row pairs; f32 / f16: c * H / 256, compile-time count)
+    int nw;                  // waves of this CU that take units (8; 7 on an attention CU)
+    int d0, dn;              // this CU's rows of w2 (f32 / f16: c * E / 256, compile-time count)
+};
+__device__ __forceinline__ const TokenArgsQ4& tk_q4(const TokenArgs& a) { return static_cast<const TokenArgsQ4&>(a); }
 // A launch of the GR instantiation always leaves its candidates in buffer pos & 1 (pos is live through the whole kernel
 // anyway; a flag tested after the classifier would be one more register held across the layer loop).
 constexpr int TKG_GREEDY = 1;      // host side only: launch the GR instantiation
@@ -592,9 +598,10 @@ struct TkNorm {
     // Stages xs = x*w and returns xn = sqrt(mean(x^2)+1e-5).  The division by xn is linear in the dot
     // product, so it is applied ONCE to each finished row sum (W.(x*w))/xn by the epilogue instead
     // of 2048 times here -- the service wave is the serial section of every phase.
-    template <int NBP = 0>   // NBP > 0: xs is the f16 hi | lo image of NBP blocks (q4_0: q4_units.h)
+    template <int NBP = 0>   // (natural order only: the q4_0 kernels stage their image in pieces, tk_stage_q16)
     __device__ __forceinline__ float apply(const float* xraw, float* xs, int lane, float eps) const {
         float ss = 0.f;
+        const int xs0 = tk_xoff<NBP>(4 * lane);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const float4 x = reinterpret_cast<const float4*>(xraw)[lane + k * WAVE];
@@ -604,17 +611,7 @@ struct TkNorm {
             o.y = x.y * w[k].y;
             o.z = x.z * w[k].z;
             o.w = x.w * w[k].w;
-            if constexpr (NBP > 0) {
-                const int e = 4 * (lane + k * WAVE);                    // eight lanes hold one block
-                q16_put4(reinterpret_cast<char*>(xs), e, o);
-                float bs = (o.x + o.y) + (o.z + o.w);
-                bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
-                bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
-                bs += dpp_mov<0x114, 0xf, true>(0.f, bs);               // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
-                if ((lane & 7) == 7) q16_put_sum<(NBP > 0 ? NBP : 32)>(reinterpret_cast<char*>(xs) + Q16Img<(NBP > 0 ? NBP : 32)>::SUM + (e >> 5) * 2, bs);
-            } else {
-                *reinterpret_cast<float4*>(xs + (lane + k * WAVE) * 4) = o;
-            }
+            *reinterpret_cast<float4*>(xs + xs0 + k * (4 * WAVE)) = o;
         }
         ss = wave_sum(ss);
         return sqrtf(ss / (float)E + eps);
@@ -831,19 +828,19 @@ __device__ __forceinline__ TkTile tk_at(const TokenArgs& a, int l, int c, int sw
         if constexpr (SH::Q4) {
             // q4_0: the CU's units of the phase, wave sw takes units sw, sw + nw, ...  (w1|w3: the gate groups' units, then the up groups')
             if constexpr (K < SC::KO) {
-                return tk_unit<SH>(a.wqkv, (l * SH::QKV + a.q0) / Q16_ROWS * SH::NCS_E, (K - SC::KQ) * a.nw + sw,
-                                   a.qn / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, a.nw, a.zeros);
+                return tk_unit<SH>(a.wqkv, (l * SH::QKV + a.q0) / Q16_ROWS * SH::NCS_E, (K - SC::KQ) * tk_q4(a).nw + sw,
+                                   a.qn / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, tk_q4(a).nw, a.zeros);
             } else if constexpr (K < SC::KA) {
-                return tk_unit<SH>(a.wo, (l * SH::E + a.o0) / Q16_ROWS * SH::NCS_E, (K - SC::KO) * a.nw + sw,
-                                   a.on / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, a.nw, a.zeros);
+                return tk_unit<SH>(a.wo, (l * SH::E + a.o0) / Q16_ROWS * SH::NCS_E, (K - SC::KO) * tk_q4(a).nw + sw,
+                                   a.on / Q16_ROWS * SH::NCS_E, SH::NCS_E, sw, tk_q4(a).nw, a.zeros);
             } else if constexpr (K < SC::KD) {
-                const int u = (K - SC::KA) * a.nw + sw, ug = a.hn / Q16_ROWS * SH::NCS_E, up = u >= ug ? 1 : 0;
-                TkTile t = tk_unit<SH>(a.w13, (l * 2 * SH::H + up * SH::H + a.h0) / Q16_ROWS * SH::NCS_E - up * ug, u, 2 * ug,
-                                       SH::NCS_E, sw, a.nw, a.zeros);
+                const int u = (K - SC::KA) * tk_q4(a).nw + sw, ug = tk_q4(a).hn / Q16_ROWS * SH::NCS_E, up = u >= ug ? 1 : 0;
+                TkTile t = tk_unit<SH>(a.w13, (l * 2 * SH::H + up * SH::H + tk_q4(a).h0) / Q16_ROWS * SH::NCS_E - up * ug, u, 2 * ug,
+                                       SH::NCS_E, sw, tk_q4(a).nw, a.zeros);
                 return t;
             } else if constexpr (K < SC::KP) {
-                return tk_unit<SH>(a.w2, (l * SH::E + a.d0) / Q16_ROWS * SH::NCS_H, (K - SC::KD) * a.nw + sw,
-                                   a.dn / Q16_ROWS * SH::NCS_H, SH::NCS_H, sw, a.nw, a.zeros);
+                return tk_unit<SH>(a.w2, (l * SH::E + tk_q4(a).d0) / Q16_ROWS * SH::NCS_H, (K - SC::KD) * tk_q4(a).nw + sw,
+                                   tk_q4(a).dn / Q16_ROWS * SH::NCS_H, SH::NCS_H, sw, tk_q4(a).nw, a.zeros);
             } else {
                 return tk_null<SH>(a.zeros);
             }
@@ -1218,7 +1215,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     // q4_0: the streaming input is staged as an f16 hi | lo image (TkLds); 0 = natural order
     constexpr int TR_E = SH::TR_E, TR_H = SH::TR_H;
     typedef TkSched<SH> SC;
-    // q4_0: this wave takes units like the seven others (not on an attention CU: a.nw = 7); the row sums of a phase are then
+    // q4_0: this wave takes units like the seven others (not on an attention CU: nw = 7); the row sums of a phase are then
     // spread over its units' partials (tk_unit_row)
     [[maybe_unused]] TkRing<SH> r;
     const char* img = lds + LD::XS;
@@ -1477,14 +1474,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         TK_STAMP(10);
         tk_barrier();
         TK_STAMP(11);
-        if (lane < (SH::Q4 ? a.hn : SH::R_A / 2)) {
+        if (lane < (SH::Q4 ? tk_q4(a).hn : SH::R_A / 2)) {
             // q4_0: the gate groups' units come first, then the up groups' (tk_at)
             float gsum = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, lane) : part[2 * lane];
-            float usum = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, a.hn / Q16_ROWS, lane) : part[2 * lane + 1];
+            float usum = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, tk_q4(a).hn / Q16_ROWS, lane) : part[2 * lane + 1];
             gsum = gsum / xn_ffn;
             usum = usum / xn_ffn;
             const float hb = gsum * (1.0f / (1.0f + expf(-gsum)));
-            tk_publish(tk_g_hb<SH>(a) + (SH::Q4 ? a.h0 : c * (SH::R_A / 2)) + lane, e_a, hb * usum);
+            tk_publish(tk_g_hb<SH>(a) + (SH::Q4 ? tk_q4(a).h0 : c * (SH::R_A / 2)) + lane, e_a, hb * usum);
         }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 3, lane);
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
@@ -1502,14 +1499,14 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if constexpr (SH::Q4) tk_steps<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, TK_NS, img, part, lane);
         tk_barrier();
         TK_STAMP(14);
-        if (lane < (SH::Q4 ? a.dn : SH::R_D)) {
+        if (lane < (SH::Q4 ? tk_q4(a).dn : SH::R_D)) {
             float v = 0.f;
             if constexpr (SH::Q4) v = tk_unit_row<SH::NCS_H>(part, 0, lane);
             else {
 #pragma unroll
             for (int p = 0; p < SH::TPR_H; ++p) v += part[lane * SH::TPR_H + p];
             }
-            const int r = (SH::Q4 ? a.d0 : c * SH::R_D) + lane;
+            const int r = (SH::Q4 ? tk_q4(a).d0 : c * SH::R_D) + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
@@ -1762,7 +1759,9 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
 }
 
 template <class SH, bool GR = false>
-__global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a) {
+__global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a_in) {
+    std::conditional_t<SH::Q4, TokenArgsQ4, TokenArgs> a;
+    static_cast<TokenArgs&>(a) = a_in;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -15,8 +15,8 @@ def test_persistent_kernels_do_not_spill():
     instruction inside a loop, and at most 32 bytes of scratch at all (the f32 kernel currently keeps one 16-byte value
     across its straight-line classifier tail: one store, one reload per token, measured faster than the spill-free
     neighbours of the same schedule -- DESIGN.md section 3b)."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_tools", "tk_resources.py"), "--all"], capture_output=True, text=True,
-                       timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_tools", "tk_resources.py"), "--all", "--lds64"], capture_output=True, text=True,
+                       timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     # the prefill GEMMs on the f16 matrix instruction hold a ring of weight stages, two activation stages and 64 accumulators
     # per wave in (unified) registers: they must not spill at all (a first q4_0 version did: prefill.h)
@@ -27,6 +27,11 @@ def test_persistent_kernels_do_not_spill():
         assert m and int(m.group(1)) == 0, l
     rows = [l for l in r.stdout.splitlines() if "token_kernel" in l or "tk2" in l]
     assert len(rows) >= 5, r.stdout
+    # the f32 / f16 kernels' rmsnorm staging in 16-byte LDS accesses (round 5: hipcc once split them in pairs of 8: +7 % on the f16 token)
+    for l in rows:
+        if ", 0>" in l or ", 1>" in l:           # weight types f32 / f16
+            k = re.search(r"lds64 (-?\d+)/(-?\d+)", l)
+            assert k and 0 <= int(k.group(1)) <= 4 and 0 <= int(k.group(2)) <= 4, l
     for l in rows:
         m = re.search(r"VGPR\s+(\d+).*scratch\s+(\d+)", l)
         assert m, l
