@@ -217,7 +217,10 @@ int llmk_timings(llmk_ctx *ctx, float ms[5]);
  * 5 classifier (successive launches walk the layers), 6 the persistent whole-token kernel
  * (LLMK_E_ARG when the ctx runs the multi-kernel path), 7..10 the w1|w3, wqkv, wo, w2 GEMMs of llmk_prefill at 128 positions
  * (bytes = that matrix of one layer; flop = 2 * 128 * rows * K), 11 the five per-layer kernels of the multi-kernel path (a
- * tensor-parallel rank's too, without its exchanges) for all layers as one hipGraph: milliseconds and bytes per LAYER. */
+ * tensor-parallel rank's too, without its exchanges) for all layers as one hipGraph: milliseconds and bytes per LAYER.
+ * STATE: a measurement hook, not part of the generation path.  Kernels 0..6 and 11 run real kernels of the pass at the ctx's
+ * current position (position 1 if none was run yet): they overwrite x, that position's K/V rows and the exchange state, kernel 11
+ * for every layer; kernels 7..10 overwrite the prefill workspaces.  Call llmk_reset before generating on the ctx again. */
 int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double *bytes_per_launch);
 
 /* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),

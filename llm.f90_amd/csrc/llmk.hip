@@ -1648,7 +1648,10 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
         if (c->tp_size != 1 || c->E % pf_step || c->H % pf_step) return LLMK_E_ARG;
         rc = pf_setup(c);
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c->pf[0].Xs, 0, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
+        // activations of ordinary size (every float 0x3c3c3c3c = 0.0115): an all-zero workspace would make every workgroup of the f16-instruction
+        // GEMM cast its low-end votes (prefill.h pf_low_check: 32k atomics per launch, +16 us) -- a path real activations do not take
+        HIPCHK(hipMemsetAsync(c->pf[0].Xs, 0x3c, (size_t)PF_TMAX * c->E * sizeof(float), c->stream));
+        HIPCHK(hipMemsetAsync(c->pf[0].HB, 0x3c, (size_t)PF_TMAX * c->H * sizeof(float), c->stream));
     }
     // Successive launches walk the layers so the weight stream never re-hits the 256 MiB Infinity
     // Cache (the classifier has one matrix: its figure is cache-assisted beyond the first launch).
