@@ -24,6 +24,10 @@
 // columns; its wave-reduced partial dot goes to LDS and the service wave folds the parts of a row.
 // The x fragment a wave dots its tiles against is the same for every tile of a phase and lives in
 // registers (TkX).  DESIGN.md section 3b has the measurements behind each of these choices.
+//
+// q4_0 matrices (round 5) take the same kernel with another kind of tile: a UNIT of 16 rows x 32 blocks in its own device layout,
+// dotted on the matrix core against an f16 image of x in LDS (q4_units.h), all EIGHT waves taking units and gathering an eighth
+// of every input vector each (TkShape::COOP, tk_step, tk_stream_coop); DESIGN.md section 3d.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -126,8 +130,7 @@ namespace llmk {
 
 constexpr int TK_NCU = 256;               // one workgroup per CU
 constexpr int TK_WAVES = 8;               // 7 streaming + 1 service (2 waves/SIMD: 256 VGPRs each)
-// register tiles a streaming wave keeps requested ahead: TkShape::NB (5 x 8 KB for f32 / f16; 3 for q4_0, whose x fragment
-// takes 64 registers instead of 32 and whose tiles carry 8 scale registers)
+// register tiles a streaming wave keeps requested ahead: TkShape::NB (5 x 8 KB for f32, 4 for f16; q4_0: 4 units of 9 KB)
 constexpr int TK_NS = TK_WAVES - 1;
 constexpr int TK_THREADS = TK_WAVES * WAVE;
 constexpr int TK_TCOLS = 8;               // 16-byte vector columns per tile (8 x 64 lanes x 4 floats = 2048)
@@ -242,11 +245,11 @@ struct TkShape {
 #define LLMK_NB_F16 4
 #endif
     static constexpr int NB = Q4 ? LLMK_NB_Q4 : (WT == WT_F16 ? LLMK_NB_F16 : 5);
-    // COOP (q4_0): all eight waves gather the phase's input vector, one eighth each, and the tiles are requested from
-    // inside the dot products (tk_step).  The dequantise-and-dot of a q4_0 tile takes 1.9 us, so the loads' issue hides
-    // behind ALU work instead of behind the exchange, and a wave that polls right after its phase has almost nothing of
-    // its own queued ahead of the poll -- the reason the f32 / f16 kernels keep a wave that never streams (section 3b of
-    // DESIGN.md) does not apply, and an 88 KB sweep by one wave was 7.3 us per layer.
+    // COOP (q4_0): all eight waves gather the phase's input vector, one eighth each, and the units are requested from
+    // inside the dot products (tk_step): a unit's dots take ~1.3 us, the loads' issue is spread through them instead of bursting
+    // behind the exchange, and a wave that polls right after its phase has little of its own queued ahead of the poll -- the
+    // reason the f32 / f16 kernels keep a wave that never streams (section 3b of DESIGN.md) weighs less here than an 88 KB hb
+    // sweep by ONE wave did (7.3 us per layer at 7B, round 2).
     // Measured for f16 too (round 2, ring depth 4): any vector gathered by the streaming waves loses -- hb only 1,710 tok/s,
     // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills
     // that the next phase does not need until its input vector has been gathered (1,675).
@@ -421,9 +424,8 @@ __device__ __forceinline__ bool tk_gather_part(__amdgpu_buffer_rsrc_t rs, int fi
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             ok = ok & (r[k].y == epoch) & (r[k].w == epoch);
-            // element 2 * (first_pair + lane + 64 k): lane part + a compile-time stride per k (natural order: 128 floats;
-            // transposed image: 64 pairs = 32 float4 = 4 blocks further along the same group row = 16 floats), so the
-            // address is ONE per-lane register plus an immediate
+            // element 2 * (first_pair + lane + 64 k): lane part + a compile-time stride per k (128 floats), so the address is ONE
+            // per-lane register plus an immediate
             *reinterpret_cast<float2*>(dst + dst0 + k * (NBP > 0 ? 16 : 2 * WAVE)) = make_float2(__uint_as_float(r[k].x), __uint_as_float(r[k].z));
         }
         if (__all(ok) || nowait) {
