@@ -69,6 +69,7 @@ extern "C" {
 #define LLMK_E_TIMEOUT 8   /* an in-kernel exchange timed out (GPU shared with other work?)        */
 #define LLMK_E_COMM 9      /* tensor-parallel ctx used before llmk_tp_init_comm, or an RCCL error       */
 #define LLMK_E_VERIFY 10   /* an uploaded block's word sum on the device differed from the host's, three times over      */
+#define LLMK_E_NONFINITE 11 /* llmk_forward_greedy / llmk_decode_greedy: no logit of the position is finite, there is no greedy token  */
 #define LLMK_E_HIP 1000    /* 1000 + hipError_t                                                     */
 
 /* Run-time replacement of the reference's compile-time dims (llama2.f90:102-108) and of

@@ -948,6 +948,7 @@ const char* llmk_strerror(int code) {
         case LLMK_E_TIMEOUT: return "llmk: device-side exchange timed out (persistent kernel not fully resident?)";
         case LLMK_E_COMM: return "llmk: tensor-parallel communicator missing or RCCL error";
         case LLMK_E_VERIFY: return "llmk: uploaded weights did not arrive intact on the device (three attempts)";
+        case LLMK_E_NONFINITE: return "llmk: no finite logit at this position (the greedy pick has no answer)";
     }
     if (code >= LLMK_E_HIP) return hipGetErrorString((hipError_t)(code - LLMK_E_HIP));
     return "llmk: unknown error";
@@ -1507,6 +1508,9 @@ int llmk_forward_greedy(llmk_ctx* c, int token, int pos, int* next_token) {
     if (!c || !next_token) return LLMK_E_ARG;
     int rc = run_token(c, token, pos, true);
     if (rc) return rc;
+    // the device argmax answers 0 ("no token") when no logit is finite (a damaged upload, an overflow): an error, not an id --
+    // a host that indexes its vocabulary with it reads out of bounds (advisor, round 4)
+    if (*c->h_next < 1 || *c->h_next > c->V) return LLMK_E_NONFINITE;
     *next_token = *c->h_next;
     return LLMK_OK;
 }
@@ -1572,6 +1576,7 @@ int llmk_decode_greedy(llmk_ctx* c, int token, int pos0, int n, int* ids_out, ll
     for (int i = done; i < n; ++i) {
         rc = run_token(c, token, pos0 + i, true);
         if (rc) return rc;
+        if (*c->h_next < 1 || *c->h_next > c->V) return LLMK_E_NONFINITE;      // (before the callback sees it)
         token = ids_out[i] = *c->h_next;
         if (on_token) on_token(i, token, user);
     }

@@ -147,3 +147,24 @@ def test_decode_greedy_timeout_inside_the_pipeline_still_returns_the_reference_i
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, env=env, timeout=300)
     assert r.returncode == 0 and b"PIPELINE-FALLBACK-OK" in r.stdout, r.stdout + r.stderr
     assert b"timed out" in r.stderr and b"multi-kernel path" in r.stderr
+
+
+@pytest.mark.parametrize("shape", ["tiny-hs64", "tk-small"], ids=["multikernel", "token-kernel"])
+def test_greedy_without_a_finite_logit_is_an_error_not_token_zero(shape, gguf):
+    """Advisor, round 4: the device argmax answers 0 ("no token") when no logit is finite; llmk_forward_greedy returned LLMK_OK with
+    that 0 and llmk_decode_greedy handed it to the caller's callback -- the Fortran host indexes its vocabulary with it.  Now both
+    return LLMK_E_NONFINITE (11) before any id or callback; a final rmsnorm gain of NaN makes every logit NaN on both paths (the
+    persistent kernel's pipeline raises its sticky word, retires, and the multi-kernel redo reports the error)."""
+    from llm_f90_amd import llmk
+    fw = gguf.synth_fused(gguf.SHAPES[shape], 3)
+    fw.rms_final_weight = np.full_like(fw.rms_final_weight, np.nan)
+    m = llmk.Llmk(fw)
+    with pytest.raises(llmk.LlmkError) as e:
+        m.forward_greedy(2, 1)
+    assert e.value.code == 11
+    m.reset()
+    seen = []
+    with pytest.raises(llmk.LlmkError) as e:
+        m.decode_greedy(2, 1, 4, on_token=lambda i, t, u: seen.append(t))
+    assert e.value.code == 11 and seen == []
+    m.close()
