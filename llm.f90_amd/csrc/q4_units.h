@@ -4,11 +4,12 @@
 // four_bit_dev branch: not under /root/reference; ggml's public block format -- 32 weights = one f16 scale d + 16 bytes, low
 // nibbles elements 0..15, high nibbles elements 16..31, value (nibble - 8) d).
 //
-// Why: round 4 showed the q4_0 phases VALU-bound (an SQ-counter pass is in profiles/r05_llama2-7b_q4_0_pmc_sq.txt): 13 full-rate
-// operations per dword of nibbles, ~455 per 4-row tile and wave.  Here a dword costs 5 bit operations and ONE matrix
-// instruction, the block scales and the "-8 sum x" term go through the matrix core as well, and -- because x then lives in LDS,
-// not in 64 registers per lane -- all EIGHT waves of a CU stream weights (the service wave had no registers for a fragment).
-// Probed in round 4 (csrc/probes/q4_mfma16_probe.hip: 1.58x on equal work, 5.5e-6 against a double-precision dot).
+// Why: round 4 read the q4_0 phases as VALU-bound: 13 full-rate operations per dword of nibbles, ~455 per 4-row tile and wave.
+// Here a dword costs 5 bit operations and ONE matrix instruction, the block scales and the "-8 sum x" term go through the
+// matrix core as well, and -- because x then lives in LDS, not in 64 registers per lane -- all EIGHT waves of a CU stream weights
+// (the service wave had no registers for a fragment).  Probed in round 4 (csrc/probes/q4_mfma16_probe.hip: 1.58x on equal work,
+// 5.5e-6 against a double-precision dot).  What it bought in the kernel (profiles/r05_llama2-7b_q4_0_pmc_sq_{before,after}.txt, DESIGN.md
+// section 3d): plain VALU instructions -27 %, the token +2 % -- the slots wait for the memory pipeline, not for the VALU.
 //
 // UNIT = 16 rows x 32 blocks (1024 columns): 8 KB of nibbles + 1 KB of scales, 9,216 contiguous bytes, the bytes of a round-4
 // tile (4 rows x 128 blocks).  Device layout of a matrix [R][K]: units in (row group, column slot) order,
@@ -175,11 +176,9 @@ __device__ __forceinline__ void q16_unit_dot(const float4 (&w)[9], const Q16Lane
             acc.x = fmaf(d.x, s.x, acc.x); acc.y = fmaf(d.y, s.y, acc.y); acc.z = fmaf(d.z, s.z, acc.z); acc.w = fmaf(d.w, s.w, acc.w);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (true) {
-            if (h == 1) mid(std::integral_constant<int, 0>());
-            if (h == 3) mid(std::integral_constant<int, 1>());
-            if (h == 5) mid(std::integral_constant<int, 2>());
-        }
+        if (h == 1) mid(std::integral_constant<int, 0>());       // (h is a constant of the unrolled loop)
+        if (h == 3) mid(std::integral_constant<int, 1>());
+        if (h == 5) mid(std::integral_constant<int, 2>());
     }
 }
 // the sixteen columns of a row added up: every lane of the 16-lane row gets the sum
