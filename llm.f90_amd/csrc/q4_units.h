@@ -81,14 +81,22 @@ __device__ __forceinline__ int q16_pair_off(int e0) {
     return (e0 >> 5) * Q16_IMG_BLK + ((el & 15) >> 2) * 16 + (((el & 3) >> 1) + 2 * (el >> 4)) * 2;
 }
 __device__ __forceinline__ float q16_pair_scale(int e0) { return (e0 & 16) ? 0.0625f : 1.0f; }
+// (the gathers sit on the layer's critical path: both hi pieces in one v_cvt_pkrtz_f16_f32 -- toward zero, so the remainder has the
+// sign of x and at most 11 significant bits --, x - hi through v_fma_mix_f32 with the half as a source (no conversion back), both lo
+// pieces in one more: |x - hi - lo| <= 2^-21 |x|, 4 operations for the pair instead of 8)
 __device__ __forceinline__ void q16_put2(char* p, float sc, float x0, float x1) {
     const float a = x0 * sc, b = x1 * sc;                 // (a power of two: exact)
-    const _Float16 ah = (_Float16)a, bh = (_Float16)b;
-    const _Float16 al = (_Float16)(a - (float)ah), bl = (_Float16)(b - (float)bh);
-    *reinterpret_cast<unsigned short*>(p) = q16_bits(ah);
-    *reinterpret_cast<unsigned short*>(p + 8) = q16_bits(bh);
-    *reinterpret_cast<unsigned short*>(p + 64) = q16_bits(al);
-    *reinterpret_cast<unsigned short*>(p + 72) = q16_bits(bl);
+    typedef __fp16 q16_h2 __attribute__((ext_vector_type(2)));
+    union { q16_h2 h; unsigned u; } H, L;
+    H.h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(ra), "=&v"(rb) : "v"(H.u), "v"(a), "v"(b));
+    L.h = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    *reinterpret_cast<unsigned short*>(p) = (unsigned short)H.u;
+    *reinterpret_cast<unsigned short*>(p + 8) = (unsigned short)(H.u >> 16);
+    *reinterpret_cast<unsigned short*>(p + 64) = (unsigned short)L.u;
+    *reinterpret_cast<unsigned short*>(p + 72) = (unsigned short)(L.u >> 16);
 }
 // four consecutive elements e .. e + 3 (e % 4 == 0): elements 0, 2 are neighbours in the image, and so are 1, 3
 __device__ __forceinline__ void q16_put4(char* img, int e, const float4& x) {

@@ -501,7 +501,10 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
         float2 gn[NORM ? NLW : 1];
         if constexpr (NORM) {
 #pragma unroll
-            for (int k = 0; k < NLW; ++k) gn[k] = *reinterpret_cast<const float2*>(gains + 2 * (first_pair + lane + k * WAVE));
+            for (int k = 0; k < NLW; ++k) {
+                gn[k] = *reinterpret_cast<const float2*>(gains + 2 * (first_pair + lane + k * WAVE));
+                if constexpr (NBP > 0) { gn[k].x *= psc; gn[k].y *= psc; }      // (a power of two: x (g 2^-e) = (x g) 2^-e, and this is done before the poll)
+            }
         }
         const int e0 = 2 * (first_pair + lane);
         // NBP > 0: the f16 hi | lo image of NBP blocks (q4_units.h): where this lane's pair goes, its factor (1, or 1/16 under a high
@@ -530,7 +533,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                         y0 = x0 * gn[k].x; y1 = x1 * gn[k].y;
                     }
                     if constexpr (NBP > 0) {
-                        y0 *= psc; y1 *= psc;
+                        if constexpr (!NORM) { y0 *= psc; y1 *= psc; }
                         amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1)));
                         q16_put2(ip + k * (4 * Q16_IMG_BLK), isc, y0, y1);
                         const float bs = row16_sum(y0 + y1);             // a load's 64 lanes hold 4 whole blocks, one per DPP row
