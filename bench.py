@@ -300,11 +300,14 @@ def prefill_line(a):
         issued = flop * pieces / (ms * 1e-3) / 1e12
         MFMA_F16_PEAK = 2500.0                    # dense TFLOP/s of v_mfma_f32_16x16x32_f16 (MI355X_MICROARCH.md)
         f_hbm, f_mfma = gbps / 8000.0, issued / MFMA_F16_PEAK
-        traffic = pmc_traffic("pf_gemm_h_kernel<8, 2", f"prefill512_{a.shape}", a.type)
+        # (q4_0 weights: the 128-row strip on eight waves of one row group each, llmk.hip pf_gemm_launch)
+        kname = "pf_gemm_h_kernel<8, 1, 2, 8>" if a.type == "q4_0" else "pf_gemm_h_kernel<8, 2"
+        traffic = pmc_traffic(kname, f"prefill512_{a.shape}", a.type)
         both = {"hbm": {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm},
                 "mfma": {"achieved": issued, "peak": MFMA_F16_PEAK, "unit": "TFLOP/s issued", "frac": f_mfma, "instructions_per_chunk": pieces,
                          "algorithmic_tflops": flop / (ms * 1e-3) / 1e12}}
-        out["roofline"].update({"kernel": f"pf_gemm_h_kernel<8, 2, {a.type}> (w1|w3, 128 positions, v_mfma_f32_16x16x32_f16)",
+        out["roofline"].update({"kernel": (f"pf_gemm_h_kernel<8, 1, q4_0, 8 waves>" if a.type == "q4_0" else f"pf_gemm_h_kernel<8, 2, {a.type}>")
+                                          + " (w1|w3, 128 positions, v_mfma_f32_16x16x32_f16)",
                                 "traffic": traffic, "tflops": flop / (ms * 1e-3) / 1e12, "both": both,
                                 "note": "bound by neither roofline: see `both` and DESIGN.md section 3c"})
         if f_hbm >= f_mfma:

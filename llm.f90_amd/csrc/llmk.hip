@@ -688,7 +688,10 @@ PfPlan pf_plan(const llmk_ctx* c, int rows, int K, int T = PF_TMAX) {
     // in the loop against 84 % with two, eaten by the coarser units (TinyLlama w1|w3 67.9 vs 62.2 us; Llama-2-7B q4_0 +0.4 %).
     // f16 weights on the f16 instruction (pf_gemm_h_kernel): a step is 8x less matrix work
     static const double step_f32[2] = {2.45, 4.25}, step_h[2] = {LLMK_PF_H_STEP1, LLMK_PF_H_STEP2}, step_hq[2] = {LLMK_PF_HQ_STEP1, LLMK_PF_HQ_STEP2};
-    const double* step_us = !c->pf_hm ? step_f32 : c->cfg.weight_type == LLMK_TYPE_F16 ? step_h : step_hq;   // (f32 weights: three instructions per chunk, as q4_0)
+    // (f32 weights: three instructions per chunk, as q4_0; q4_0 at whole batches: the two-group strip runs on eight waves, pf_gemm_launch)
+    static const double step_q8[2] = {LLMK_PF_HQ_STEP1, LLMK_PF_HQ_STEP2 * 0.925};
+    const double* step_us = !c->pf_hm ? step_f32 : c->cfg.weight_type == LLMK_TYPE_F16 ? step_h
+                            : (c->cfg.weight_type == LLMK_TYPE_Q4_0 && (T + 15) / 16 == 8) ? step_q8 : step_hq;
     PfPlan best{};
     double best_t = 1e30;
     for (int nr = 1; nr <= 2; ++nr) {
@@ -798,6 +801,8 @@ hipError_t pf_gemm_h_prepare_one() {
 }
 template <int WT>
 hipError_t pf_gemm_h_prepare() {
+    if constexpr (WT == WT_Q4_0)      // (the eight-wave form of the 128-row strip: pf_gemm_launch)
+        HIPRET(hipFuncSetAttribute((const void*)pf_gemm_h_kernel<8, 1, WT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pf_gemm_h_smem<8, 2>()));
     HIPRET((pf_gemm_h_prepare_one<1, WT>())); HIPRET((pf_gemm_h_prepare_one<2, WT>())); HIPRET((pf_gemm_h_prepare_one<3, WT>())); HIPRET((pf_gemm_h_prepare_one<4, WT>()));
     HIPRET((pf_gemm_h_prepare_one<5, WT>())); HIPRET((pf_gemm_h_prepare_one<6, WT>())); HIPRET((pf_gemm_h_prepare_one<7, WT>()));
     return pf_gemm_h_prepare_one<8, WT>();
@@ -830,6 +835,15 @@ hipError_t pf_gemm_launch(llmk_ctx* c, const PfLane& w, const PfGemmArgs& a, con
     const dim3 grid(p.grid), block(PF_WAVES * WAVE);
     if (c->pf_hm) {
         constexpr size_t smem_h = pf_gemm_h_smem<NG, NR>();
+        if constexpr (NG == 8 && NR == 2) {
+            // q4_0, whole batches: the same 128-row strips on EIGHT waves of one row group each -- two waves per SIMD, one wave's nibble
+            // arithmetic under the other's matrix instructions (round 5, profiles/r05_prefill_eight_waves.txt: w1|w3 GEMM 33.0 -> 30.9 us on
+            // TinyLlama q4_0, 96.2 -> 88.8 at 7B; f16 and f32 weights, which have no such arithmetic, lose 4-6 % to the doubled LDS reads)
+            if (c->cfg.weight_type == LLMK_TYPE_Q4_0) {
+                hipLaunchKernelGGL((pf_gemm_h_kernel<8, 1, WT_Q4_0, 8>), grid, dim3(8 * WAVE), smem_h, w.stream, a, c->pf_flag, w.lowcnt);
+                return hipGetLastError();
+            }
+        }
         if (c->cfg.weight_type == LLMK_TYPE_Q4_0) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_Q4_0>), grid, block, smem_h, w.stream, a, c->pf_flag, w.lowcnt);
         else if (c->cfg.weight_type == LLMK_TYPE_F16) hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F16>), grid, block, smem_h, w.stream, a, c->pf_flag, w.lowcnt);
         else hipLaunchKernelGGL((pf_gemm_h_kernel<NG, NR, WT_F32>), grid, block, smem_h, w.stream, a, c->pf_flag, w.lowcnt);

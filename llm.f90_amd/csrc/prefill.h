@@ -341,9 +341,11 @@ __device__ __forceinline__ void pf_ring(F& step, int s, int nsteps) {      // (N
 // consecutive columns of slot kg (the activation side is the f16 kernel's), turns them into the reference's f32 weights
 // (n - 8) d exactly (n - 8 as f16: byte n under 0x64 is the half 1024 + n, minus 1032; times the row's f16 block scale through
 // v_fma_mix_f32) and feeds each as two f16 pieces: see the step.
-template <int NG, int NR, int WT = WT_F16>
-__global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag, unsigned* __restrict__ lowcnt) {
-    constexpr int NW = PF_WAVES, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
+// NWV = waves per workgroup: 4 (one per SIMD), or 8 with NR = 1 -- the strip of the 4-wave NR = 2 form (same units, same partial tiles)
+// on two waves per SIMD; used for q4_0 weights (llmk.hip pf_gemm_launch)
+template <int NG, int NR, int WT = WT_F16, int NWV = PF_WAVES>
+__global__ __launch_bounds__(NWV * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag, unsigned* __restrict__ lowcnt) {
+    constexpr int NW = NWV, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
     constexpr bool Q4 = WT == WT_Q4_0, F32W = WT == WT_F32;
     // ring depth: f16 six 16-byte stages; q4_0 four (longer steps); f32 four / three (a stage is 32 bytes per chunk and row group)
     constexpr int ST = Q4 ? 4 : F32W ? (NR == 1 ? 4 : 3) : PF_HST;

@@ -16,6 +16,7 @@
 #   prof TAG                 the evidence run: per single-GPU configuration of BASELINE.json a bench line, the pipelined-greedy
 #                            line, rocprofv3 --kernel-trace --stats and a FETCH_SIZE pass (separate runs); the 70B rank's
 #                            kernels; the prefill lines with their own stats + FETCH_SIZE; the KV-length curve
+#   pfprof                   the prefill lines of `prof` alone (bench lines of the four configurations, stats + FETCH_SIZE of two)
 #   profcfg TAG NAME [args]  the evidence of ONE configuration (bench line, greedy line, stats, FETCH_SIZE, its KV-length curve)
 #   pmc KIND                 SQ counter passes (q4 | prefill), own runs, no --stats
 #   trace [args]             tests/host_tools/tk_trace.py on the debug library (LLMK_TK_TRACE=1)
@@ -76,6 +77,12 @@ job_prof() {
   run_cfg tinyllama_f16 --no-cpu-baseline --type f16
   run_cfg llama2-7b_q4_0 --no-cpu-baseline --shape llama2-7b --type q4_0
   echo "=== 70B rank kernels"; job_rank
+  job_pfprof
+  echo "=== KV-length curve"
+  for a in "" "--type f16" "--shape llama2-7b"; do timeout 300 python tests/host_tools/tk_curve.py $a 1 256 512 1024 2048 2>&1 | tail -1; done | tee $OUT/kv_length_curve.txt
+}
+job_pfprof() {   # the prefill lines with their own stats + FETCH_SIZE passes
+  local cfg name
   echo "=== prefill 512"
   for cfg in "tinyllama_f32" "tinyllama_f16 --type f16" "tinyllama_q4_0 --type q4_0" "llama2-7b_q4_0 --shape llama2-7b --type q4_0"; do
     set -- $cfg; name=prefill512_$1; shift
@@ -85,8 +92,6 @@ job_prof() {
   fetch_of prefill512_tinyllama_f16 pf_gemm --prefill 512 --type f16
   stats_of prefill512_llama2-7b_q4_0 --prefill 512 --shape llama2-7b --type q4_0
   fetch_of prefill512_llama2-7b_q4_0 pf_gemm --prefill 512 --shape llama2-7b --type q4_0
-  echo "=== KV-length curve"
-  for a in "" "--type f16" "--shape llama2-7b"; do timeout 300 python tests/host_tools/tk_curve.py $a 1 256 512 1024 2048 2>&1 | tail -1; done | tee $OUT/kv_length_curve.txt
 }
 job_rank() { timeout 300 python tests/host_tools/tp_rank_time.py 4 8 2>&1 | tail -12 | tee $OUT/tp70_rank_kernels.txt; }
 job_pmc() {
@@ -166,6 +171,7 @@ while [ $# -gt 0 ]; do
     ab)     job_ab "${args[@]}" ;;
     prof)   OUT=$ROOT/gpurun_out/prof_${args[0]:-r04}; mkdir -p $OUT; job_prof ;;
     profcfg) OUT=$ROOT/gpurun_out/prof_${args[0]}; mkdir -p $OUT; run_cfg "${args[1]}" --no-cpu-baseline "${args[@]:2}"; timeout 300 python tests/host_tools/tk_curve.py $(case "${args[1]}" in *f16*) echo --type f16;; *7b*) echo --shape llama2-7b;; esac) 1 256 512 1024 2048 2>&1 | tail -1 | tee $OUT/kv_length_curve_${args[1]}.txt ;;
+    pfprof) OUT=$ROOT/gpurun_out/prof_${args[0]:-r05}; mkdir -p $OUT; job_pfprof ;;
     pmc)    job_pmc "${args[0]:-q4}" ;;
     trace)  LLMK_LIB=$DBG LLMK_TK_TRACE=1 timeout 300 python tests/host_tools/tk_trace.py "${args[@]}" 2>&1 | cut -c1-400 | tee $OUT/trace_$(echo "${args[*]}" | tr -c 'a-zA-Z0-9\n' _).txt | tail -70 ;;
     rank)   job_rank ;;
