@@ -309,7 +309,7 @@ __global__ __launch_bounds__(PF_WAVES * WAVE) void pf_gemm_kernel(PfGemmArgs a) 
 // accumulation order is the matrix core's either way.  Activations of 65504 and above do not fit hi: the staging raises
 // `flag` and llmk_prefill redoes the call on the f32 instruction (pf_gemm_kernel<.., WT_F16, ..>).
 // Same units / strips / partial tiles as pf_gemm_kernel; a step (64 columns) is 4 x NR x NG instructions = 1,024 matrix
-// clocks at 128 positions with two row groups, so the weights run PF_HST - 1 steps ahead (ring of register stages).
+// clocks at 128 positions with two row groups; the weights run ST - 1 steps ahead (ring of register stages; depth: see ST in the kernel).
 typedef _Float16 pf_v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 pf_v4h __attribute__((ext_vector_type(4)));
 // LDS image of a step's activations: [hi, lo][position][64 halfs], 128-byte rows, the 16-byte slot s of position t stored at
@@ -318,7 +318,6 @@ typedef _Float16 pf_v4h __attribute__((ext_vector_type(4)));
 // and with this swizzle its 16 addresses fall into 16 different 4-bank slots (a padded pitch of 144 bytes left 7 of the 16
 // pairs on one slot: two LDS cycles per group, and the LDS, not the matrix core, set the step time).
 constexpr int PF_HP = PF_KSTEP;
-constexpr int PF_HST = 6;                    // weight stages
 
 template <int Q, int N, class F>
 __device__ __forceinline__ void pf_prologue(F& wload) {
@@ -347,8 +346,22 @@ template <int NG, int NR, int WT = WT_F16, int NWV = PF_WAVES>
 __global__ __launch_bounds__(NWV * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag, unsigned* __restrict__ lowcnt) {
     constexpr int NW = NWV, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
     constexpr bool Q4 = WT == WT_Q4_0, F32W = WT == WT_F32;
-    // ring depth: f16 six 16-byte stages; q4_0 four (longer steps); f32 four / three (a stage is 32 bytes per chunk and row group)
-    constexpr int ST = Q4 ? 4 : F32W ? (NR == 1 ? 4 : 3) : PF_HST;
+    // ring depth of the weight stages.  Round 5: SHALLOWER is faster -- the ring is written out as 2 ST steps of straight-line code, and what six
+    // stages bought in lead they lost again (f16: six -> three stages +5.6 % prompt rate, f32 four / three -> two +1.8 %, q4_0 on eight waves
+    // four -> two +2.3 % at 7B; profiles/r05_prefill_ring_depth.txt)
+#ifndef LLMK_PF_ST_Q8
+#define LLMK_PF_ST_Q8 2
+#endif
+#ifndef LLMK_PF_ST_Q4
+#define LLMK_PF_ST_Q4 2
+#endif
+#ifndef LLMK_PF_ST_F32
+#define LLMK_PF_ST_F32 2
+#endif
+#ifndef LLMK_PF_ST_F16
+#define LLMK_PF_ST_F16 3
+#endif
+    constexpr int ST = Q4 ? (NWV == 8 ? LLMK_PF_ST_Q8 : LLMK_PF_ST_Q4) : F32W ? LLMK_PF_ST_F32 : LLMK_PF_ST_F16;
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     _Float16* xh = reinterpret_cast<_Float16*>(pf_smem);                                  // [2 buffers][hi, lo][TP][PF_HP]
     float* tb = reinterpret_cast<float*>(pf_smem + (size_t)4 * TP * PF_HP * sizeof(_Float16));   // [TP][SR + PF_TPAD]
