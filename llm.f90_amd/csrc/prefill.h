@@ -346,8 +346,9 @@ template <int NG, int NR, int WT = WT_F16, int NWV = PF_WAVES>
 __global__ __launch_bounds__(NWV * WAVE) void pf_gemm_h_kernel(PfGemmArgs a, unsigned* __restrict__ flag, unsigned* __restrict__ lowcnt) {
     constexpr int NW = NWV, TP = NG * 16, NJ = 2, SR = 16 * NR * NW, NT = NW * WAVE;
     constexpr bool Q4 = WT == WT_Q4_0, F32W = WT == WT_F32;
-    // ring depth of the weight stages.  Round 5: SHALLOWER is faster -- the ring is written out as 2 ST steps of straight-line code, and what six
-    // stages bought in lead they lost again (f16: six -> three stages +5.6 % prompt rate, f32 four / three -> two +1.8 %, q4_0 on eight waves
+    // ring depth of the weight stages.  Round 5: SHALLOWER is faster -- six f16 stages left ~100 values parked in accumulation registers and
+    // moved in and out inside the step (256 VGPRs + 170 AGPRs for 64 accumulators; three stages: 254 + 92), and what they bought in lead they lost
+    // again (f16: six -> three stages +5.6 % prompt rate, f32 four / three -> two +1.8 %, q4_0 on eight waves
     // four -> two +2.3 % at 7B; profiles/r05_prefill_ring_depth.txt)
 #ifndef LLMK_PF_ST_Q8
 #define LLMK_PF_ST_Q8 2
