@@ -40,3 +40,31 @@ def test_persistent_kernels_do_not_spill():
             assert int(m.group(2)) <= 32, l
             k = re.search(r"scratch_ops_in_loops (-?\d+) of (\d+)", l)
             assert k and int(k.group(1)) == 0 and int(k.group(2)) <= 4, l
+
+
+def _quoted_includes(path, seen):
+    """every file reachable from `path` through #include "..." lines (relative to the including file)"""
+    path = os.path.normpath(path)
+    if path in seen:
+        return
+    seen.add(path)
+    for line in open(path):
+        m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
+        if m:
+            _quoted_includes(os.path.join(os.path.dirname(path), m.group(1)), seen)
+
+
+def test_every_included_header_is_a_prerequisite_of_the_libraries():
+    """Round-5 verdict, build hygiene: csrc/q4_units.h (included by token_kernel.h) was not among libllmk.so's prerequisites, so
+    an edit of the unit layout alone left a stale library.  Walk the #include "..." graph of llmk.hip and hold the Makefile's
+    list (`make print-lib-deps`) to it; both library rules must use that list."""
+    pkg = os.path.join(ROOT, "llm.f90_amd")
+    r = subprocess.run(["make", "-s", "-C", pkg, "print-lib-deps"], capture_output=True, text=True, check=True)
+    deps = {os.path.normpath(os.path.join(pkg, d)) for d in r.stdout.split()}
+    seen = set()
+    _quoted_includes(os.path.join(pkg, "csrc", "llmk.hip"), seen)
+    assert len(seen) >= 7, seen
+    missing = sorted(s for s in seen if s not in deps)
+    assert not missing, f"not prerequisites of libllmk.so: {missing}"
+    mk = open(os.path.join(pkg, "Makefile")).read()
+    assert re.search(r"^csrc/libllmk\.so: \$\(LIB_DEPS\)$", mk, re.M) and re.search(r"^csrc/libllmk_debug\.so: \$\(LIB_DEPS\)$", mk, re.M)
