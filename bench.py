@@ -485,30 +485,32 @@ def main():
         want_fh = (world == 1 and not a.no_fortran_host and (a.fortran_host or not a.no_cpu_baseline) and fw is not None
                    and not a.multi_kernel and not a.no_graph and not a.greedy_on_device)
         td = tempfile.TemporaryDirectory(dir=os.environ.get("LLMK_TMP", "/tmp")) if (want_cb or want_fh) else None
-        gpath = None
-        if td is not None:
-            gpath = os.path.join(td.name, f"synthetic-{a.shape}-{a.type}.gguf")
-            gguf.write_gguf(gpath, fw)              # the same weights the timed loop ran on, as the file both CLIs read
-        if want_fh:
-            # the drop-in itself, on this GPU, while this process's context idles
-            out["fortran_host"] = fortran_host(gpath, shape.vocab_size, min(shape.seq_len, max(W + K, 256)), gpu_ids, local)
-            if "tok_s" in out["fortran_host"]:
-                out["fortran_host"]["vs_ctypes_value"] = round(out["fortran_host"]["tok_s"] / tok_s, 4)
-        if want_cb:
-            cb = cpu_baseline(fw, a.shape, wtype, gguf_path=gpath)
-            if cb is not None and "_ids" in cb:
-                # free parity check at the bench's own size: the REAL reference's greedy transcript (same weights, same
-                # box, positions 1..n) against the ids the GPU just produced in the timed loop
-                ref_ids = cb.pop("_ids")
-                n = min(len(ref_ids), len(gpu_ids))
-                same = [x == y for x, y in zip(ref_ids[:n], gpu_ids[:n])]
-                first = same.index(False) if False in same else None
-                cb["ids_match"] = f"{sum(same)}/{n}"
-                cb["first_mismatch_pos"] = None if first is None else first + 1
-                out["ids_match"] = cb["ids_match"]
-            out["cpu_baseline"] = cb
-        if td is not None:
-            td.cleanup()
+        try:            # (the 4.4 GB file must not outlive an exception in the CPU / Fortran legs: advisor, round 5)
+            gpath = None
+            if td is not None:
+                gpath = os.path.join(td.name, f"synthetic-{a.shape}-{a.type}.gguf")
+                gguf.write_gguf(gpath, fw)              # the same weights the timed loop ran on, as the file both CLIs read
+            if want_fh:
+                # the drop-in itself, on this GPU, while this process's context idles
+                out["fortran_host"] = fortran_host(gpath, shape.vocab_size, min(shape.seq_len, max(W + K, 256)), gpu_ids, local)
+                if "tok_s" in out["fortran_host"]:
+                    out["fortran_host"]["vs_ctypes_value"] = round(out["fortran_host"]["tok_s"] / tok_s, 4)
+            if want_cb:
+                cb = cpu_baseline(fw, a.shape, wtype, gguf_path=gpath)
+                if cb is not None and "_ids" in cb:
+                    # free parity check at the bench's own size: the REAL reference's greedy transcript (same weights, same
+                    # box, positions 1..n) against the ids the GPU just produced in the timed loop
+                    ref_ids = cb.pop("_ids")
+                    n = min(len(ref_ids), len(gpu_ids))
+                    same = [x == y for x, y in zip(ref_ids[:n], gpu_ids[:n])]
+                    first = same.index(False) if False in same else None
+                    cb["ids_match"] = f"{sum(same)}/{n}"
+                    cb["first_mismatch_pos"] = None if first is None else first + 1
+                    out["ids_match"] = cb["ids_match"]
+                out["cpu_baseline"] = cb
+        finally:
+            if td is not None:
+                td.cleanup()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     m.close()
     rep.close()

@@ -40,6 +40,7 @@ extern "C" {
 #define LLMK_TYPE_F32 0
 #define LLMK_TYPE_F16 1
 #define LLMK_TYPE_Q4_0 2
+#define LLMK_TYPE_Q6_K 14 /* ggml block_q6_K (210 bytes per 256 weights): LLMK_WCLS only, see llmk_set_tensor_type */
 
 /* tensor ids for llmk_upload: one per component of TransformerWeights (weight_module.f90:13-26) */
 #define LLMK_TOKEN_EMBEDDING_TABLE 0 /* (E,V)        C [V][E]         always f32            */
@@ -157,8 +158,11 @@ int llmk_upload_rows(llmk_ctx *ctx, int tensor_id, int layer, int row_offset, in
                      size_t nbytes, int ggml_type);
 
 /* Extensions beyond the reference's behaviour, both OPT-IN (the defaults reproduce llama2.f90):
- *  - llmk_set_tensor_type: give LLMK_WCLS its own ggml type (f32 / f16 / q4_0) before it is uploaded -- stock llama.cpp
- *    q4_0 files keep output.weight in q6_K, which the host loader dequantises (read_ggml.f90:682-684 stops on it);
+ *  - llmk_set_tensor_type: give LLMK_WCLS its own ggml type (f32 / f16 / q4_0 / q6_K) before it is uploaded -- stock llama.cpp
+ *    q4_0 files keep output.weight in q6_K (the reference stops on it, read_ggml.f90:633-635, :682-684).  Round 6: the raw q6_K
+ *    super-blocks are uploaded as they lie in the file (LLMK_TYPE_Q6_K, emb_dim a multiple of 256) and dotted on the device; a
+ *    ctx with q4_0 matrices of a shape the persistent kernel serves STAYS on it (llmk_path == 1).  A host may still hand the
+ *    classifier over dequantised (LLMK_TYPE_F32): that ctx runs the multi-kernel path, as before;
  *  - llmk_set_rms_eps: rmsnorm epsilon other than the reference's hard-coded 1e-5 (llama2.f90:454), for a host that
  *    honours llama.attention.layer_norm_rms_epsilon. */
 int llmk_set_tensor_type(llmk_ctx *ctx, int tensor_id, int ggml_type);

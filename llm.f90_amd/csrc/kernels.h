@@ -19,7 +19,7 @@ constexpr int GEMV_THREADS = 256;  // 4 waves
 constexpr int GEMV_WAVES = GEMV_THREADS / WAVE;
 constexpr int GEMV_SU = 8;         // vectors of x per thread requested at once while a block stages it (K <= 8192: all of them)
 
-enum WeightType { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2 };
+enum WeightType { WT_F32 = 0, WT_F16 = 1, WT_Q4_0 = 2, WT_Q6_K = 14 };   // (q6_K: classifier rows only, q6k.h)
 enum Epilogue {
     EPI_STORE = 0,    // y[r] = W[r]·x                           classifier, llama2.f90:634-636
     EPI_RESID = 1,    // y[r] += W[r]·x                          wo :603-605, w2 :618-620

@@ -106,6 +106,10 @@ struct llmk_ctx {
     bool use_tk = false;
     bool tk_short_grid = false;   // libllmk_debug.so only (LLMK_TK_INJECT_TIMEOUT)
     bool tk_retired = false;   // the token kernel timed out once on this ctx: it stays on the multi-kernel path
+    // q4_0 persistent kernels: positions whose activations did not fit the f16 image of x (sticky word 0x4000) are redone ONE AT A TIME
+    // on the multi-kernel path and the kernel stays in use (advisor, round 5: one such position used to cost the context a third of
+    // its rate for good); TK_RANGE_LIMIT of them in a row retire it after all (a model it cannot hold), and its unit copies are freed
+    int tk_range_events = 0, tk_range_run = 0;
     int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape, 5 Llama-2-7B q4_0, 6 TinyLlama q4_0
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x | attention parts
     float4* d_zeros = nullptr;
@@ -154,8 +158,13 @@ size_t row_bytes_for(int type, int K) {
         case LLMK_TYPE_F32: return (size_t)K * 4;
         case LLMK_TYPE_F16: return (size_t)K * 2;
         case LLMK_TYPE_Q4_0: return (size_t)K / 32 * 18;
+        case LLMK_TYPE_Q6_K: return (size_t)K / Q6K_WEIGHTS * Q6K_BLOCK_BYTES;      // (the classifier only: q6k.h)
     }
     return 0;
+}
+// bytes between a tensor's rows ON THE DEVICE (q4_0 and q6_K rows are re-packed by the upload: kernels.h, q6k.h)
+size_t dev_row_bytes(int type, int K) {
+    return type == LLMK_TYPE_Q4_0 ? q4_row_stride(K) : type == LLMK_TYPE_Q6_K ? q6k_row_stride(K) : row_bytes_for(type, K);
 }
 
 // llmk_create walks the token pass once with g_prepare set: nothing is launched, but every kernel whose dynamic LDS
@@ -324,6 +333,14 @@ hipError_t launch_cls(llmk_ctx* c) {
     // vocab-parallel: this rank's V/P rows land in its slice of the full logits vector
     GemvArgs a = base_args(c, LLMK_WCLS, 0, c->d_x, (const float*)c->t[LLMK_RMS_FINAL_WEIGHT].data,
                            c->d_logits + (size_t)c->tp_rank * c->Vl);
+    if (c->t[LLMK_WCLS].type == LLMK_TYPE_Q6_K) {      // raw q6_K rows (a stock q4_0 file's output.weight): q6k.h
+        const size_t smem = 16 + (size_t)a.K * sizeof(float);
+        const int blocks = (a.rows + GEMV_WAVES * Q6K_RPW - 1) / (GEMV_WAVES * Q6K_RPW);
+        hipError_t pe;
+        if (prepare_only(gemv_q6k_kernel<true>, smem, &pe)) return pe;
+        hipLaunchKernelGGL((gemv_q6k_kernel<true>), dim3(blocks), dim3(GEMV_THREADS), smem, c->stream, a);
+        return hipGetLastError();
+    }
     return launch_gemv_t<EPI_STORE, true>(c->t[LLMK_WCLS].type, c->stream, a, c->n_cu);   // the classifier may have its own type
 }
 hipError_t launch_embed(llmk_ctx* c) {
@@ -353,7 +370,7 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
     a.wo = TK::Q4 ? c->q16[LLMK_WO] : c->t[LLMK_WO].data;
     a.w13 = TK::Q4 ? c->q16[LLMK_W13] : c->t[LLMK_W13].data;
     a.w2 = TK::Q4 ? c->q16[LLMK_W2] : c->t[LLMK_W2].data;
-    a.wcls = TK::Q4 ? c->q16[LLMK_WCLS] : c->t[LLMK_WCLS].data;
+    a.wcls = (TK::Q4 && !TK::CLSQ6) ? c->q16[LLMK_WCLS] : c->t[LLMK_WCLS].data;      // (q6_K classifier rows stay rows: q6k.h)
     a.kc = c->d_kc;
     a.vc = c->d_vc;
     a.rope = c->d_rope;
@@ -384,7 +401,9 @@ hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false, const TkGreedy&
         case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct, g);
         case 4: return launch_token_kernel_t<TkSmallF16>(c, direct, g);
         case 5: return launch_token_kernel_t<TkLlama7BQ4>(c, direct, g);
-        default: return launch_token_kernel_t<TkTinyLlamaQ4>(c, direct, g);
+        case 6: return launch_token_kernel_t<TkTinyLlamaQ4>(c, direct, g);
+        case 7: return launch_token_kernel_t<TkLlama7BQ4Q6>(c, direct, g);
+        default: return launch_token_kernel_t<TkTinyLlamaQ4Q6>(c, direct, g);
     }
 }
 // the last position of a pipelined greedy run has no next launch to fold its candidates: this does (1 wave)
@@ -413,7 +432,7 @@ template <class TK>
 int tk_setup(llmk_ctx* c, int id) {
     const llmk_config& g = c->cfg;
     if (c->use_tk || g.emb_dim != TK::E || g.hidden_dim != TK::H || g.n_heads != TK::NH || g.n_kv_heads != TK::NKV ||
-        g.vocab_size != TK::V || g.weight_type != TK::WT)
+        g.vocab_size != TK::V || g.weight_type != TK::WT || c->t[LLMK_WCLS].type != TK::CLS)
         return LLMK_OK;
     // scores + exp(scores)
     const size_t lds = ((size_t)TkLds<TK>::ATT_S + 2 * (size_t)c->S * sizeof(float) + 15) & ~(size_t)15;
@@ -430,14 +449,29 @@ int tk_setup(llmk_ctx* c, int id) {
     if (per_cu < 1 || (long long)per_cu * c->n_cu < TK_NCU) return LLMK_OK;
     // qkv | xb | xa | hb | x | per head: the (PMAX - 1) other parts of a long context's attention (HS values + maximum + sum each)
     const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H + (size_t)TK::NH * (TkAttPlan<TK>::PMAX - 1) * (TK::HS + 2);
-    HIPCHK(dev_alloc(&c->d_gran, ngran * sizeof(unsigned long long)));
-    HIPCHK(dev_alloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
+    if (!c->d_gran) HIPCHK(dev_alloc(&c->d_gran, ngran * sizeof(unsigned long long)));      // (kept over a re-type of the classifier: same shape)
+    if (!c->d_zeros) HIPCHK(dev_alloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
     if (TK_DEBUG && getenv("LLMK_TK_TRACE")) HIPCHK(dev_alloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));   // libllmk_debug.so only
     HIPCHK(hipMemset(c->d_gran, 0, ngran * sizeof(unsigned long long)));
     HIPCHK(hipMemset(c->d_zeros, 0, (size_t)TK_NCU * TK_WAVES * 1024));
     c->use_tk = true;
     c->tk_shape = id;
     return LLMK_OK;
+}
+
+// The whole-token persistent kernel serves the shapes it is instantiated for, on a full 256-CU part.  Called at create and again
+// when the classifier gets a type of its own (llmk_set_tensor_type: the q6_K instantiations).
+int tk_setup_all(llmk_ctx* c) {
+    if ((c->cfg.flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) || c->n_cu != TK_NCU || c->tp_size != 1 || c->tk_retired) return LLMK_OK;
+    int rc = tk_setup<TkTinyLlama>(c, 1);
+    if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
+    if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
+    if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
+    if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4>(c, 5);
+    if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaQ4>(c, 6);
+    if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4Q6>(c, 7);
+    if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaQ4Q6>(c, 8);
+    return rc;
 }
 
 __global__ void bump_serial_kernel(int* tokpos) { tokpos[2] += 1; }
@@ -586,15 +620,26 @@ int check_ready(llmk_ctx* c) {
 // wedged peer).  Its error word is sticky by design (every CU drains instead of spinning on), so: clear it, retire the
 // token kernel for this context and tell the user once.  The caller re-runs the SAME position on the multi-kernel path,
 // which rewrites that position's KV rows and recomputes x from the embedding: nothing of the failed launch survives.
-int tk_retire(llmk_ctx* c, unsigned code, int pos) {
+constexpr int TK_RANGE_LIMIT = 4;
+int tk_clear_err(llmk_ctx* c) {
     HIPCHK(hipMemsetAsync(c->d_logits + c->V, 0, sizeof(float), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
     c->h_next[1] = 0;
+    return LLMK_OK;
+}
+// 0x4000 and nothing else: this position's activations did not fit the q4_0 kernels' f16 image; the kernel itself is sound
+bool tk_range_only(unsigned code) { return (code & 0x4000u) != 0 && (code & 0x2f00u) == 0; }
+int tk_retire(llmk_ctx* c, unsigned code, int pos) {
+    int rc = tk_clear_err(c);
+    if (rc) return rc;
     c->use_tk = false;
     c->tk_retired = true;
     if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }
     if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
+    for (int i = 0; i < LLMK_N_TENSORS; ++i)       // the q4_0 kernels' second copy of the matrices (3.8 GB at 7B): nobody reads it again
+        if (c->q16[i]) { hipFree(c->q16[i]); c->q16[i] = nullptr; }
+    c->q16_dirty = true;
     // what the sticky word says (token_kernel.h): 0x2000 no finite candidate among the classifier maxima (pipelined greedy decode),
     // 0x4000 an activation beyond the f16 range of the q4_0 kernels' x image, anything else a bounded spin that ran out
     const char* what = (code & 0x2000u) ? "found no finite logit among its candidates"
@@ -657,7 +702,23 @@ int run_token(llmk_ctx* c, int token, int pos, bool greedy) {
         }
         if (!c->use_tk) return LLMK_OK;
         const unsigned err = greedy ? (unsigned)c->h_next[1] : reinterpret_cast<unsigned*>(c->h_logits)[c->V];
-        if (err == 0) return LLMK_OK;
+        if (err == 0) { c->tk_range_run = 0; return LLMK_OK; }
+        if (tk_range_only(err) && c->tk_range_run + 1 < TK_RANGE_LIMIT) {
+            // THIS position on the multi-kernel path (f32 activations throughout; eager launches: the ctx's graphs hold the token
+            // kernel), the persistent kernel again from the next one
+            ++c->tk_range_run;
+            if (c->tk_range_events++ == 0)
+                fprintf(stderr, "llmk: position %d holds an activation beyond the f16 range of the persistent q4_0 kernel's operands (code 0x%x): that "
+                                "position is redone on the multi-kernel path, the kernel stays in use\n", pos, err);
+            rc = tk_clear_err(c);
+            if (rc) return rc;
+            c->use_tk = false;
+            const hipError_t e = enqueue_token(c, greedy, false);
+            c->use_tk = true;
+            HIPCHK(e);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            return LLMK_OK;
+        }
         rc = tk_retire(c, err, pos);   // then once more, on the multi-kernel path
         if (rc) return rc;
     }
@@ -767,8 +828,12 @@ int pf_setup_inner(llmk_ctx* c) {
     HIPCHK(dev_alloc(&c->pf_tok, (size_t)c->S * sizeof(int)));
     return LLMK_OK;
 }
-int pf_setup(llmk_ctx* c) {
+// choose: a setup from scratch also picks the matrix instruction (the f16 one unless LLMK_PF_F32_MFMA=1) -- llmk_prefill and the
+// timing hook both say so, so that a hook called first (or after a redo that tore the workspaces down) cannot leave the context on
+// the slow instruction (advisor, round 5); the redo in llmk_prefill sets pf_hm = false itself and does not
+int pf_setup(llmk_ctx* c, bool choose = false) {
     if (c->pf_ready) return LLMK_OK;
+    if (choose) c->pf_hm = !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
     const int rc = pf_setup_inner(c);
     if (rc) { pf_teardown(c); return rc; }
     c->pf_ready = true;
@@ -1039,7 +1104,7 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
         // beyond it (token_kernel.h, NT_Q / NG_A), which for the last rows of the last layer lie past the tensor
         // q4_0 device row: K/2 nibble bytes (16-byte vectors, one per 32-weight block), then the K/32 f16 block scales,
         // zero-padded to whole groups of 64 (a wave-wide scale load past a ragged row end must read finite zeros)
-        t.row_bytes = t.type == LLMK_TYPE_Q4_0 ? q4_row_stride(d.K) : row_bytes_for(t.type, d.K);
+        t.row_bytes = dev_row_bytes(t.type, d.K);
         // the three rmsnorm gain tensors share ONE allocation, att [L][E] | ffn [L][E] | final [E]: the persistent kernel
         // addresses them from one pointer (token_kernel.h TokenArgs::rms)
         if (i == LLMK_RMS_FFN_WEIGHT || i == LLMK_RMS_FINAL_WEIGHT) {
@@ -1076,14 +1141,7 @@ int llmk_create_tp(const llmk_config* cfg, int tp_rank, int tp_size, llmk_ctx** 
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 8; ++i) CK(hipEventCreate(&c->ev[i]));
     // The whole-token persistent kernel serves the shapes it is instantiated for, on a full 256-CU part
-    if (rc == LLMK_OK && !(cfg->flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) && c->n_cu == TK_NCU && tp_size == 1) {
-        rc = tk_setup<TkTinyLlama>(c, 1);
-        if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
-        if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
-        if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
-        if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4>(c, 5);
-        if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaQ4>(c, 6);
-    }
+    if (rc == LLMK_OK) rc = tk_setup_all(c);
     if (rc == LLMK_OK) {   // raise the dynamic-LDS limits the token pass needs, or reject the shape here (see g_prepare)
         g_prepare = true;
         hipError_t pe = launch_qkv(c, 0);
@@ -1186,6 +1244,7 @@ static int q16_build(llmk_ctx* c) {
         const int tid = mats[i];
         const TensorDesc& d = c->desc[tid];
         const DevTensor& t = c->t[tid];
+        if (tid == LLMK_WCLS && t.type == LLMK_TYPE_Q6_K) continue;      // q6_K classifier rows are dotted as rows (q6k.h)
         if (t.type != LLMK_TYPE_Q4_0 || d.rows % Q16_ROWS) return LLMK_E_SHAPE;
         const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1), bytes = q16_bytes(rows, d.K);
         if (!c->q16[tid]) {
@@ -1203,6 +1262,7 @@ static int q16_build(llmk_ctx* c) {
         int rc = LLMK_OK;
         for (int i = 0; i < 5 && rc == LLMK_OK; ++i) {
             const int tid = mats[i];
+            if (!c->q16[tid] || c->t[tid].type != LLMK_TYPE_Q4_0) continue;
             const TensorDesc& d = c->desc[tid];
             const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1);
             unsigned long long a = 0, b = 0;
@@ -1244,9 +1304,11 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
         c->up_ready = true;
     }
     unsigned long long* const d_acc = c->up_acc;
-    const bool q4 = t.type == LLMK_TYPE_Q4_0;
+    const bool q6 = t.type == LLMK_TYPE_Q6_K;
+    const bool q4 = t.type == LLMK_TYPE_Q4_0 || q6;      // re-packed on the way (q6_K: its own kernel, q6k.h)
     // whole 16-bit words on the host side; the non-q4_0 path moves 32-bit words into rows row_bytes apart (advisor, round 4)
     if (col_bytes > UP_STAGE_BYTES || col_bytes % 2 || (!q4 && (col_bytes % 4 || t.row_bytes % 4))) return LLMK_E_ARG;
+    if (q6 && (col_off != 0 || col_bytes != row_bytes_for(LLMK_TYPE_Q6_K, d.K))) return LLMK_E_ARG;      // whole rows only (never a contraction slice)
     c->q16_dirty = true;
     const size_t blocks_per_row = col_bytes / 18;                       // (q4_0)
     const size_t rows_per_chunk = UP_STAGE_BYTES / col_bytes;
@@ -1264,6 +1326,9 @@ static int upload_block(llmk_ctx* c, int tid, int layer, int dst_row0, int nrows
             if (q4) {   // (wide loads over PCIe into a device scratch first: the re-packing reads 2 bytes at a time)
                 hipLaunchKernelGGL(stage_copy_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)c->up_stage_dev[b], (unsigned*)c->up_tmp[b],
                                    (n * col_bytes + 3) / 4);
+                if (q6) hipLaunchKernelGGL(q6k_repack_kernel, dim3(1024), dim3(256), 0, 0, (const uint8_t*)c->up_tmp[b], dst0 + r * t.row_bytes,
+                                           n * (size_t)(d.K / Q6K_WEIGHTS), d.K / Q6K_WEIGHTS, t.row_bytes);
+                else
                 hipLaunchKernelGGL(q4_repack_kernel, dim3(1024), dim3(256), 0, 0, (const uint8_t*)c->up_tmp[b], dst0 + r * t.row_bytes,
                                    n * blocks_per_row, (int)blocks_per_row, t.row_bytes);
             }
@@ -1385,11 +1450,11 @@ int llmk_upload(llmk_ctx* c, int tid, const void* host, size_t nbytes, int ggml_
 // multi-kernel path (the persistent kernel is instantiated for one weight type).
 int llmk_set_tensor_type(llmk_ctx* c, int tid, int ggml_type) {
     if (!c || tid != LLMK_WCLS) return LLMK_E_ARG;
-    if (ggml_type != LLMK_TYPE_F32 && ggml_type != LLMK_TYPE_F16 && ggml_type != LLMK_TYPE_Q4_0) return LLMK_E_TYPE;
+    if (ggml_type != LLMK_TYPE_F32 && ggml_type != LLMK_TYPE_F16 && ggml_type != LLMK_TYPE_Q4_0 && ggml_type != LLMK_TYPE_Q6_K) return LLMK_E_TYPE;
     DevTensor& t = c->t[tid];
     if (t.type == ggml_type) return LLMK_OK;
     const TensorDesc& d = c->desc[tid];
-    const int kalign = ggml_type == LLMK_TYPE_Q4_0 ? 32 : ggml_type == LLMK_TYPE_F16 ? 8 : 4;
+    const int kalign = ggml_type == LLMK_TYPE_Q6_K ? Q6K_WEIGHTS : ggml_type == LLMK_TYPE_Q4_0 ? 32 : ggml_type == LLMK_TYPE_F16 ? 8 : 4;
     if (d.K % kalign) return LLMK_E_SHAPE;
     HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1399,14 +1464,19 @@ int llmk_set_tensor_type(llmk_ctx* c, int tid, int ggml_type) {
     t.uploaded = false;
     t.rows_uploaded = 0;
     const size_t rows = (size_t)d.rows * (d.layered ? c->L : 1);
-    t.row_bytes = ggml_type == LLMK_TYPE_Q4_0 ? q4_row_stride(d.K) : row_bytes_for(ggml_type, d.K);
+    t.row_bytes = dev_row_bytes(ggml_type, d.K);
     HIPCHK(dev_alloc(&t.data, rows * t.row_bytes + TENSOR_SLACK));
     HIPCHK(hipMemset(t.data, 0, rows * t.row_bytes + TENSOR_SLACK));
+    if (c->q16[tid]) { HIPCHK(hipFree(c->q16[tid])); c->q16[tid] = nullptr; }      // the classifier's unit copy, if one was built
+    c->q16_dirty = true;
     if (c->use_tk) {
         c->use_tk = false;
         if (c->graph_logits) { hipGraphExecDestroy(c->graph_logits); c->graph_logits = nullptr; }
         if (c->graph_greedy) { hipGraphExecDestroy(c->graph_greedy); c->graph_greedy = nullptr; }
     }
+    // the persistent kernel again, if one is instantiated for this shape with a classifier of this type (round 6: q6_K rows beside
+    // q4_0 matrices -- a stock llama.cpp q4_0 file keeps the fast path); otherwise the multi-kernel path
+    { const int rc = tk_setup_all(c); if (rc) return rc; }
     g_prepare = true;                      // the classifier GEMV may need a larger dynamic-LDS limit in its new type
     const hipError_t pe = launch_cls(c);
     g_prepare = false;
@@ -1463,8 +1533,7 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
         return LLMK_OK;
     }
     HIPCHK(hipSetDevice(c->cfg.device));
-    if (!c->pf_ready) c->pf_hm = !(getenv("LLMK_PF_F32_MFMA") && getenv("LLMK_PF_F32_MFMA")[0] == '1');
-    rc = pf_setup(c);
+    rc = pf_setup(c, true);
     if (rc) return rc;
     std::vector<int> tok0(tokens, tokens + n);
     for (int& t : tok0) --t;
@@ -1582,7 +1651,9 @@ int llmk_decode_greedy(llmk_ctx* c, int token, int pos0, int n, int* ids_out, ll
         if (err == 0 && done == n) return LLMK_OK;
         // a timed-out exchange: every later launch drained on the sticky word.  Retire the token kernel and redo the rest,
         // from the first position whose id never arrived, on the multi-kernel path (it rewrites those KV rows).
-        rc = tk_retire(c, err, pos0 + done);
+        // (0x4000 alone -- an activation beyond the q4_0 kernel's f16 image at ONE position: the rest of the call goes position by
+        // position through run_token, which redoes just the positions that need it and keeps the kernel: see there)
+        rc = tk_range_only(err) ? tk_clear_err(c) : tk_retire(c, err, pos0 + done);
         if (rc) return rc;
         if (done > 0) token = ids_out[done - 1];
         c->tk_short_grid = false;
@@ -1665,7 +1736,7 @@ int llmk_time_kernel(llmk_ctx* c, int kernel, int iters, float* avg_ms, double* 
     if (kernel >= 7) {   // the prefill GEMMs at PF_TMAX positions: 7 w1|w3, 8 wqkv, 9 wo, 10 w2 (whatever the workspaces hold: timing only)
         const int pf_step = PF_KSTEP;
         if (c->tp_size != 1 || c->E % pf_step || c->H % pf_step) return LLMK_E_ARG;
-        rc = pf_setup(c);
+        rc = pf_setup(c, true);
         if (rc) return rc;
         // activations of ordinary size (every float 0x3c3c3c3c = 0.0115): an all-zero workspace would make every workgroup of the f16-instruction
         // GEMM cast its low-end votes (prefill.h pf_low_check: 32k atomics per launch, +16 us) -- a path real activations do not take

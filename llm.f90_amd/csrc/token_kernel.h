@@ -35,6 +35,7 @@
 
 #include "kernels.h"
 #include "q4_units.h"
+#include "q6k.h"
 
 // ---- measurement knobs (defaults = the product; -D... builds a variant library for an A/B) ---------------------------
 // loads per lane the service wave keeps in flight in one pass of the hb gather (no gains are held across it).  H = 5632 is
@@ -215,9 +216,14 @@ __device__ __forceinline__ void tk_wave_argmax(float& v, int& i) {
 
 constexpr int tk_cdiv(int a, int b) { return (a + b - 1) / b; }
 constexpr int tk_cmax(int a, int b) { return a > b ? a : b; }
-template <int E_, int H_, int NH_, int NKV_, int V_, int WT_ = WT_F32>
+// CLS_: the classifier's own row type when it differs from the matrices' -- WT_Q6_K with q4_0 matrices, what stock llama.cpp
+// q4_0 files hold (q6k.h); -1 = the matrices' type
+template <int E_, int H_, int NH_, int NKV_, int V_, int WT_ = WT_F32, int CLS_ = -1>
 struct TkShape {
-    static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_, WT = WT_;
+    static constexpr int E = E_, H = H_, NH = NH_, NKV = NKV_, V = V_, WT = WT_, CLS = CLS_ < 0 ? WT_ : CLS_;
+    static constexpr bool CLSQ6 = CLS == WT_Q6_K;
+    static_assert(CLS == WT || (WT == WT_Q4_0 && CLSQ6 && E_ % 256 == 0 && E_ <= 4096),
+                  "a classifier of its own type: q6_K rows beside q4_0 matrices, one quad per lane");
     static constexpr int HS = E / NH, KV = NKV * HS, KVMUL = NH / NKV, QKV = E + 2 * KV;
     // ---- weight tiles.  A tile is TK_TCOLS (8) lane loads of 16 bytes = 8 "segments" of 1 KB.  f32: one row x 8
     // segments (2048 columns).  f16: a row of 2048 columns is 4 segments, so a tile is RPT = 2 consecutive rows x LPT = 4
@@ -298,7 +304,7 @@ struct TkShape {
                          UD = R_D / RPT * NCS_H, UC = R_C / RPT * NCS_E;
     static constexpr int SL_Q = Q4 ? tk_cdiv(UQ, TK_WAVES) : (NT_Q + TK_NS - 1) / TK_NS, SL_O = Q4 ? tk_cdiv(UO, TK_WAVES) : (NT_O + TK_NS - 1) / TK_NS,
                          SL_A = Q4 ? tk_cmax(tk_cdiv(UA, TK_WAVES), tk_cdiv(UA_ATT, TK_NS)) : (NT_A + TK_NS - 1) / TK_NS,
-                         SL_C = Q4 ? tk_cdiv(UC, TK_WAVES) : (NT_C + TK_NS - 1) / TK_NS;
+                         SL_C = CLSQ6 ? 0 : Q4 ? tk_cdiv(UC, TK_WAVES) : (NT_C + TK_NS - 1) / TK_NS;   // (q6_K rows: their own loop, tk_q6_phase)
     // w2 rows are TPR_H parts wide: streaming wave sw only ever takes column part sw % TPR_H (so its x fragment can
     // live in registers for the whole phase); the part with the fewest waves (TK_NS / TPR_H of them) sets the slot count
     static constexpr int NW_D = tk_cmax(TK_NS / TPR_H, 1), SL_D = Q4 ? tk_cdiv(UD, TK_NS) : (R_D / RPT + NW_D - 1) / NW_D;
@@ -306,7 +312,7 @@ struct TkShape {
     static constexpr int RA_P = 2 * RPT * NG_A, RQ_P = RPT * NT_Q;       // partial slots incl. the recomputed neighbour rows
     static constexpr int MAXP00 = RA_P > R_C ? RA_P : R_C, MAXP0 = MAXP00 > RQ_P ? MAXP00 : RQ_P, MAXP1 = R_D * TPR_H,
                          MAXPT = MAXP0 > MAXP1 ? MAXP0 : MAXP1,          // partial sums per phase (f32 / f16: one per tile row)
-                         MAXP = Q4 ? Q16_ROWS * tk_cmax(tk_cmax(UQ, UA), tk_cmax(UD, UC)) : MAXPT;   // q4_0: 16 per unit
+                         MAXP = Q4 ? tk_cmax(Q16_ROWS * tk_cmax(tk_cmax(UQ, UA), tk_cmax(UD, UC)), R_C) : MAXPT;   // q4_0: 16 per unit
     static_assert(QKV % 2 == 0 && (Q4 || (E % TK_NCU == 0 && H % TK_NCU == 0)) && V % RPT == 0, "rows must split over CUs");
     static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
     static_assert((Q4 || (LPR_E <= LPT && R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
@@ -347,7 +353,8 @@ struct TkLds {
     static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
     static constexpr int ATT_R4 = ATT_RED + TK_WAVES * (256 / SH::HS) * SH::HS * 4;   // [waves][TPW][HS/4] float4
     static constexpr int RED8 = ATT_R4;                                    // COOP: the eight waves' partial sums of x^2 (32 of the 64 bytes)
-    static constexpr int ROPE = ATT_R4 + 64;                               // cos[HS/2] | sin[HS/2] of pos*freq
+    // (q4_0: 256 bytes -- the scales and per-wave maxima of the xb / hb images sit behind the partial sums: TK_XSC_B ...)
+    static constexpr int ROPE = ATT_R4 + (SH::Q4 ? 256 : 64);              // cos[HS/2] | sin[HS/2] of pos*freq
     static constexpr int ATT_P = ROPE + SH::HS * 4;                        // [waves][32] softmax weights of the wave's own timesteps
     static constexpr int ATT_S = ATT_P + TK_WAVES * 32 * 4;                // scores [S], then exp(score - max) [S]
 };
@@ -493,10 +500,26 @@ __device__ __forceinline__ float tk_pow2_inv(float x) {
     return __uint_as_float((unsigned)min(max(254 - e, 1), 254) << 23);
 }
 constexpr int TK_XSC = 12;      // red8[TK_XSC]: that power of two (q4_0), next to the eight partial sums and the gather-first words
+// The images that are NOT residual-stream vectors -- xb (attention output) and hb (SwiGLU output) -- have no rmsnorm to take a scale
+// from, and written unscaled a real model's 1e-2 .. 1e-3 activations sit where the lo piece is an f16 subnormal: the absolute floor of
+// an element under a high nibble is 2^-20, i.e. 1e-4 .. 1e-3 of such a value (advisor, round 5).  They are written as x 2^e too, with
+// 2^e chosen so that the SAME vector of the previous layer had its largest |element| in [64, 128): 2^9 of head room to the end of the
+// f16 range, and elements down to 2^-10 of the largest keep a relative error below 2^-21; layer 0 starts from 2^6 (largest element
+// assumed in [1, 2)).  red8[TK_XSC_B / _H]: the scale in force; red8[TK_AMX_B / _H + w]: wave w's largest |scaled element| of the image
+// it has just written (every wave writes one eighth).  The service wave divides the row sums by the scale (exactly) and sets the
+// next layer's from the eight maxima behind the phase's second barrier.  A vector that still does not fit raises 0x4000 as before.
+constexpr int TK_XSC_B = 16, TK_XSC_H = 17, TK_AMX_B = 24, TK_AMX_H = 32;
+constexpr float TK_IMG_TARGET = 64.f;
+__device__ __forceinline__ float tk_next_scale(float cur, const float* amx8) {
+    float m = fmaxf(fmaxf(fmaxf(amx8[0], amx8[1]), fmaxf(amx8[2], amx8[3])), fmaxf(fmaxf(amx8[4], amx8[5]), fmaxf(amx8[6], amx8[7])));
+    m = m / cur;                                      // (a power of two: exact) the largest |element| as it is
+    return (m > 0.f && m < 3.0e38f) ? tk_pow2_inv(m * (1.f / TK_IMG_TARGET)) : cur;
+}
 template <int NLW, int NBP, bool NORM>
 __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
-                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait, float psc = 1.f) {
-    if constexpr (NLW == 0) { return true; }
+                                             const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait, float psc = 1.f,
+                                             float* amx = nullptr) {
+    if constexpr (NLW == 0) { if (amx && lane == 0) *amx = 0.f; return true; }
     else {
         float2 gn[NORM ? NLW : 1];
         if constexpr (NORM) {
@@ -512,6 +535,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
         char* ip = reinterpret_cast<char*>(xs) + (NBP > 0 ? q16_pair_off(e0) : 0);
         const float isc = NBP > 0 ? q16_pair_scale(e0) : 1.f;
         float amax = 0.f;               // NBP > 0: the largest |value| written as an f16 hi piece (65504 is the end of that format)
+        float smax = 0.f;               //          and the largest |block sum| (they go through the matrix core as f16 pieces too)
         char* sp = reinterpret_cast<char*>(xs) + (NBP > 0 ? Q16Img<(NBP > 0 ? NBP : 32)>::SUM + (e0 >> 5) * 2 : 0);
         for (unsigned spin = 0;; ++spin) {
             tk_v4u r[NLW];
@@ -537,7 +561,7 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                         amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1)));
                         q16_put2(ip + k * (4 * Q16_IMG_BLK), isc, y0, y1);
                         const float bs = row16_sum(y0 + y1);             // a load's 64 lanes hold 4 whole blocks, one per DPP row
-                        if ((lane & 15) == 15) q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs);
+                        if ((lane & 15) == 15) { q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs); smax = fmaxf(smax, fabsf(bs)); }
                     } else {
                         *reinterpret_cast<float2*>(xs + e0 + k * 2 * WAVE) = make_float2(y0, y1);
                     }
@@ -546,7 +570,8 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                 if constexpr (NBP > 0) {
                     // an activation beyond the f16 range (or not finite): the image is useless -- raise the sticky word, the host retires
                     // the kernel for this context and redoes the position on the multi-kernel path (f32 throughout)
-                    if (!nowait && __any(!(amax < 60000.f))) {
+                    if (amx) { const float wm = wave_max(amax); if (lane == 0) *amx = wm; }
+                    if (!nowait && __any(!(fmaxf(amax, smax) < 60000.f))) {
                         if (lane == 0) __hip_atomic_store(err, 0x4000u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         return false;
                     }
@@ -565,7 +590,8 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
     }
 }
 // wave w (0..7) of the workgroup; red8[w] receives the slice's sum of squares when NORM
-template <int N, int NBP, bool NORM>
+// KIND (q4_0 images that are not residual-stream vectors): 1 = xb, 2 = hb -- which scale word and which maxima (TK_XSC_B ...)
+template <int N, int NBP, bool NORM, int KIND = 0>
 __device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsigned epoch, float* xraw, float* xs, const float* gains,
                                                float* red8, unsigned* err, int w, int lane, bool nowait) {
     static_assert(N % 128 == 0, "two granules per 16-byte load, 64 lanes");
@@ -573,9 +599,11 @@ __device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsi
     const __amdgpu_buffer_rsrc_t rs = tk_rsrc(g, N * 8);
     float ss = 0.f;
     bool ok;
-    const float psc = (NORM && NBP > 0) ? red8[TK_XSC] : 1.f;       // q4_0, residual stream: see tk_pow2_inv
-    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc);
-    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc);
+    static_assert(KIND == 0 || (!NORM && NBP > 0), "scaled xb / hb images are the q4_0 kernels'");
+    const float psc = NBP > 0 ? (NORM ? red8[TK_XSC] : KIND == 1 ? red8[TK_XSC_B] : KIND == 2 ? red8[TK_XSC_H] : 1.f) : 1.f;   // q4_0: see tk_pow2_inv, TK_XSC_B
+    float* amx = KIND == 0 ? nullptr : red8 + (KIND == 1 ? TK_AMX_B : TK_AMX_H) + w;
+    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc, amx);
+    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc, amx);
     if constexpr (NORM) {
         ss = wave_sum(ss);
         if (lane == 0) red8[w] = ss;
@@ -947,6 +975,42 @@ __device__ __forceinline__ void tk_prime_coop(TkRing<SH>& r, const TokenArgs& a,
 }
 
 
+// ---- q6_K classifier rows in the persistent q4_0 kernels (TkShape::CLSQ6; q6k.h) ----------------------------------------------
+// CU c owns the rows [c0, c0 + cn) it owns with a q4_0 classifier; wave w of 8 takes rows w, w + 8, ...: a row is ONE quad per
+// lane (E <= 4096), TK_Q6_NB rows requested ahead -- the first ones before the final gather (weights do not depend on
+// activations), like the ring's classifier slots.  x * gains comes from LDS in natural order (the final gather writes it so when
+// CLSQ6), 64 floats per lane held for the whole phase; the row sums land in part[row] and the service wave divides them by the
+// norm (llama2.f90:627-636) as it does for every other row type.
+constexpr int TK_Q6_NB = 3;
+template <class SH>
+struct TkQ6 {
+    Q6Quad b[TK_Q6_NB];
+    __device__ __forceinline__ const char* row(const TokenArgs& a, int r) const {
+        return static_cast<const char*>(a.wcls) + (size_t)(a.c0 + min(r, a.cn - 1)) * q6k_row_stride(SH::E);      // (clamped: every slot is five loads)
+    }
+    __device__ __forceinline__ void prime(const TokenArgs& a, int w, int lane) {
+        constexpr int Q = SH::E / 64;
+#pragma unroll
+        for (int i = 0; i < TK_Q6_NB; ++i) q6k_load(b[i], row(a, w + i * TK_WAVES), min(lane, Q - 1), Q);
+    }
+    // xs: x * gains, f32, natural order (LDS).  Behind the barrier that follows the final gather.
+    __device__ __forceinline__ void run(const TokenArgs& a, int w, int lane, const float* xs, float* part) {
+        constexpr int Q = SH::E / 64;
+        const int qd = min(lane, Q - 1);
+        float x[64], sx32[4];
+        q6k_load_x(x, sx32, xs, qd, lane < Q);
+        for (int r = w; r < a.cn; r += TK_Q6_NB * TK_WAVES) {
+#pragma unroll
+            for (int i = 0; i < TK_Q6_NB; ++i) {
+                const int ri = r + i * TK_WAVES;
+                const float v = wave_sum(q6k_quad_dot(b[i], x, sx32, qd & 1));
+                if (lane == 0 && ri < a.cn) part[ri] = v;
+                q6k_load(b[i], row(a, ri + TK_Q6_NB * TK_WAVES), qd, Q);
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // In-kernel attention for one head on one CU, all 16 waves (llama2.f90:572-598).  q_h, k_pos, v_pos
 // arrive through the exchange (LDS); rows t < pos-1 come from the caches written by earlier launches.
@@ -1168,9 +1232,10 @@ __device__ __forceinline__ float tk_unit_row(const float* part, int ug0, int r) 
 // q4_0, layer 0: x = the embedding row (llama2.f90:520), xraw <- x, the image <- x * gains, returns sqrt(mean(x^2) + eps) (:450-457).
 // One wave, four 1 KB pieces at a time: this wave holds a ring of units, there is no room for TkNorm's 64 registers of gains.
 template <class SH>
+// fits = false: a scaled element (or block sum) is beyond the f16 range -- the caller raises 0x4000 as the gathers of the later layers do
 __device__ __forceinline__ float tk_stage_q16(const float* __restrict__ row, const float* __restrict__ gains, float* xraw, float* xs, int lane, float eps,
-                                              float& psc) {
-    float ss = 0.f;
+                                              float& psc, bool& fits) {
+    float ss = 0.f, amax = 0.f;
     constexpr int PER = SH::E / (4 * WAVE);
     // first pass: the row's norm, for the power of two its image is scaled with (tk_pow2_inv); the second pass finds the row in L2
 #pragma unroll 1
@@ -1202,10 +1267,29 @@ __device__ __forceinline__ float tk_stage_q16(const float* __restrict__ row, con
             bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
             bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
             bs += dpp_mov<0x114, 0xf, true>(0.f, bs);               // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
-            if ((lane & 7) == 7) q16_put_sum<SH::NBI>(reinterpret_cast<char*>(xs) + Q16Img<SH::NBI>::SUM + (e >> 5) * 2, bs);
+            if ((lane & 7) == 7) { q16_put_sum<SH::NBI>(reinterpret_cast<char*>(xs) + Q16Img<SH::NBI>::SUM + (e >> 5) * 2, bs); amax = fmaxf(amax, fabsf(bs)); }
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
+    fits = !__any(!(amax < 60000.f));
     return xn;
+}
+// q4_0, layer 0 on an ATTENTION CU: it stages no QKV input, but its first scaled gather (layer 0's xa) wants the same power of two
+// the row-owning CUs take from the embedding row's rmsnorm (advisor, round 5: it was 1.0 there)
+template <class SH>
+__device__ __forceinline__ float tk_row_norm(const float* __restrict__ row, int lane, float eps) {
+    float ss = 0.f;
+    constexpr int PER = SH::E / (4 * WAVE);
+#pragma unroll 1
+    for (int k0 = 0; k0 < PER; k0 += 4) {
+        float4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = reinterpret_cast<const float4*>(row)[lane + (k0 + i) * WAVE];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss = dot4(x[i], x[i], ss);
+    }
+    ss = wave_sum(ss);
+    return sqrtf(ss / (float)SH::E + eps);
 }
 // GR: the pipelined-greedy variant (token from the previous launch's candidates, candidates of its own).  A separate
 // instantiation because the f32 kernel sits at the register ceiling: with the candidate code compiled in, hipcc spills 20
@@ -1269,7 +1353,12 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
                 ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_q - 1, xraw, xs, tk_rms_att(a, l, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
             } else if (SH::Q4) {
-                xn_att = tk_stage_q16<SH>(a.emb + (size_t)tok * SH::E, tk_rms_att(a, 0, SH::E), xraw, xs, lane, a.eps, sc_att);   // :520, :527
+                bool fits;
+                xn_att = tk_stage_q16<SH>(a.emb + (size_t)tok * SH::E, tk_rms_att(a, 0, SH::E), xraw, xs, lane, a.eps, sc_att, fits);   // :520, :527
+                if (!fits && !nosync) {      // an embedding row times its gains that no f16 holds: the same sticky word as a gather's (tk_coop_part)
+                    if (lane == 0) __hip_atomic_store(a.err, 0x4000u + (e_q & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                }
             } else if (l == 0) {
 #pragma unroll 8
                 for (int k = 0; k < SH::E / WAVE; ++k) xraw[lane + k * WAVE] = a.emb[(size_t)tok * SH::E + lane + k * WAVE];  // :520
@@ -1288,7 +1377,10 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 if (coop0) sc_att = red8[TK_XSC];
                 if (lane == 0) red8[TK_XSC] = tk_pow2_inv(xn_att);
                 xn_att *= sc_att;                       // (exact: the row sums are those of x * gains * 2^-e)
-            } else if (l == 0 && lane == 0) red8[TK_XSC] = 1.f;      // an attention CU's first scaled gather is layer 0's xa
+            } else if (l == 0) {                         // an attention CU's first scaled gather is layer 0's xa: the embedding row's norm
+                const float xn0 = tk_row_norm<SH>(a.emb + (size_t)tok * SH::E, lane, a.eps);
+                if (lane == 0) red8[TK_XSC] = tk_pow2_inv(xn0);
+            }
         }
         TK_STAMP(2);
         if constexpr (SH::Q4) tk_steps<SH, SC::KQ, SH::SL_Q, false>(r, a, l, c, TK_NS, img, part, lane);
@@ -1439,7 +1531,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         if constexpr (SH::Q4 && LLMK_TK_ADV_HOP != 0) tk_request<SH, SC::KO, false>(r, a, l, c, TK_NS, lane);   // (as the other seven waves: tk_stream_coop)
         if constexpr (SH::COOP) {
             // (this wave's slice is the last eighth of the vector: heads (E - E/8) / HS onwards)
-            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+            if (!att_cu) ok = tk_coop_gather<SH::E, TR_E, false, SH::Q4 ? 1 : 0>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         } else {
             if (!att_cu) ok = tk_gather<SH::E, TR_E, LLMK_TK_XB_NL>(tk_g_xb<SH>(a), e_att, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 2 : nullptr, gflag, 4 * l + 1) && ok;
         }
@@ -1449,10 +1541,12 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         tk_barrier();
         TK_STAMP(8);
         if (lane < a.on) {
-            const float v = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, lane) : part[lane];
+            // q4_0: the row sums are those of xb 2^e (TK_XSC_B): divided by the same power of two, exactly
+            const float v = SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, lane) / red8[TK_XSC_B] : part[lane];
             const int r = a.o0 + lane;
             tk_publish(tk_g_xa<SH>(a) + r, e_o, xraw[r] + v);
         }
+        if constexpr (SH::Q4) { if (!att_cu && lane == 0) red8[TK_XSC_B] = tk_next_scale(red8[TK_XSC_B], red8 + TK_AMX_B); }   // the next layer's xb image
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 2, lane);
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
@@ -1492,7 +1586,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         // ---- P4: x += w2 . hb                                                    llama2.f90:618-620
         if constexpr (SH::COOP) {
             if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
-            ok = tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
+            ok = tk_coop_gather<SH::H, TR_H, false, SH::Q4 ? 2 : 0>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, TK_NS, lane, nosync) && ok;
         }
         else {
             if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
@@ -1506,7 +1600,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         TK_STAMP(14);
         if (lane < (SH::Q4 ? tk_q4(a).dn : SH::R_D)) {
             float v = 0.f;
-            if constexpr (SH::Q4) v = tk_unit_row<SH::NCS_H>(part, 0, lane);
+            if constexpr (SH::Q4) v = tk_unit_row<SH::NCS_H>(part, 0, lane) / red8[TK_XSC_H];      // (the hb image's power of two: TK_XSC_H)
             else {
 #pragma unroll
             for (int p = 0; p < SH::TPR_H; ++p) v += part[lane * SH::TPR_H + p];
@@ -1514,13 +1608,23 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = (SH::Q4 ? tk_q4(a).d0 : c * SH::R_D) + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
+        if constexpr (SH::Q4) { if (lane == 0) red8[TK_XSC_H] = tk_next_scale(red8[TK_XSC_H], red8 + TK_AMX_H); }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
         TK_STAMP(15);
     }
 #undef TK_STAMP
     // ---- final rmsnorm + classifier                                             llama2.f90:627-636
     float xn_fin;
-    if constexpr (SH::COOP) {
+    if constexpr (SH::CLSQ6) {
+        // q6_K classifier rows: x * gains in natural order (f32, unscaled) instead of the image; this wave's first rows go out first
+        TkQ6<SH> q6;
+        q6.prime(a, TK_NS, lane);
+        if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
+        ok = tk_coop_gather<SH::E, 0, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
+        tk_barrier();
+        xn_fin = tk_coop_xn<SH::E>(red8, a.eps);
+        q6.run(a, TK_NS, lane, xs, part);
+    } else if constexpr (SH::COOP) {
         if constexpr (GCD) __builtin_amdgcn_s_sleep(GCDN);
         ok = tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, TK_NS, lane, nosync) && ok;
         tk_barrier();
@@ -1537,7 +1641,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
     }
     tk_barrier();
     const int cn = SH::CX ? a.cn : SH::R_C, c0 = SH::CX ? a.c0 : c * SH::R_C;
-    auto logit = [&](int j) { return (SH::Q4 ? tk_unit_row<SH::NCS_E>(part, 0, j) : part[j]) / xn_fin; };
+    auto logit = [&](int j) { return ((SH::Q4 && !SH::CLSQ6) ? tk_unit_row<SH::NCS_E>(part, 0, j) : part[j]) / xn_fin; };
     for (int j = lane; j < cn; j += WAVE) a.logits[c0 + j] = logit(j);
     if constexpr (GR) {
         float bv = -INFINITY;
@@ -1745,21 +1849,29 @@ __device__ __forceinline__ void tk_stream_coop(const TokenArgs& a, char* lds, in
         }
         // the wo slot's request, in the window of the attention hop (behind this CU's own attention, if it has any)
         if constexpr (ADVH) tk_request<SH, SC::KO, false>(r, a, l, c, sw, lane);
-        if (!att_cu) tk_coop_gather<SH::E, TR_E, false>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        if (!att_cu) tk_coop_gather<SH::E, TR_E, false, SH::Q4 ? 1 : 0>(tk_g_xb<SH>(a), e_att, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KO, SH::SL_O, false, !ADVH>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         tk_coop_gather<SH::E, TR_E, true>(tk_g_xa<SH>(a), e_o, xraw, xs, tk_rms_ffn(a, l, SH::E), red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KA, SH::SL_A, false>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
-        tk_coop_gather<SH::H, TR_H, false>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
+        tk_coop_gather<SH::H, TR_H, false, SH::Q4 ? 2 : 0>(tk_g_hb<SH>(a), e_a, nullptr, xs, nullptr, red8, a.err, sw, lane, nosync);
         tk_phase_body<SH, SC::KD, SC::SLP - SC::KD, false>(r, a, l, c, sw, xs4, part, lane);
         if constexpr (LLMK_TK_COOP_DELAY > 0) __builtin_amdgcn_s_sleep(LLMK_TK_COOP_DELAY);
         if (l + 1 < L) {
             if (!att_cu) tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_att(a, l + 1, SH::E), red8, a.err, sw, lane, nosync);
-        } else {
+        } else if constexpr (!SH::CLSQ6) {
             tk_coop_gather<SH::E, TR_E, true>(tk_g_x<SH>(a), e_d, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, sw, lane, nosync);
         }
     }
+    if constexpr (SH::CLSQ6) {      // q6_K classifier rows (tk_service mirrors this)
+        TkQ6<SH> q6;
+        q6.prime(a, sw, lane);
+        tk_coop_gather<SH::E, 0, true>(tk_g_x<SH>(a), ebase + 5u * L, xraw, xs, tk_rms_final(a, SH::E), red8, a.err, sw, lane, nosync);
+        tk_barrier();
+        q6.run(a, sw, lane, xs, part);
+        tk_barrier();
+    } else
     tk_phase_body<SH, 0, SH::SL_C, true>(r, a, L, c, sw, xs4, part, lane);
 }
 
@@ -1796,6 +1908,8 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a_in) {
             for (int i = SH::H / 32 * Q16_IMG_BLK + tid * 16; i < SH::NBI * Q16_IMG_BLK; i += TK_THREADS * 16)
                 *reinterpret_cast<uint4*>(img + i) = make_uint4(0u, 0u, 0u, 0u);
             for (int i = Q16Img<SH::NBI>::SUM + tid * 4; i < Q16Img<SH::NBI>::BYTES; i += TK_THREADS * 4) *reinterpret_cast<unsigned*>(img + i) = 0u;
+            // layer 0's xb / hb images: the largest element assumed in [1, 2) (TK_XSC_B; first read behind the QKV phase's barriers)
+            if (tid < 2) reinterpret_cast<float*>(lds + TkLds<SH>::RED8)[TK_XSC_B + tid] = TK_IMG_TARGET;
         }
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
@@ -1809,5 +1923,8 @@ typedef TkShape<2048, 5632, 32, 4, 32000, WT_F16> TkTinyLlamaF16;   // BASELINE.
 typedef TkShape<512, 1536, 8, 2, 1024, WT_F16> TkSmallF16;          // parity shape for the f16 tiles (tests: tk-small16)
 typedef TkShape<4096, 11008, 32, 32, 32000, WT_Q4_0> TkLlama7BQ4;   // BASELINE.json configs[3]: Llama-2-7B, q4_0 matrices, head size 128
 typedef TkShape<2048, 5632, 32, 4, 32000, WT_Q4_0> TkTinyLlamaQ4;   // TinyLlama-1.1B with q4_0 matrices (GQA, head size 64): the units kernel's second shape
+// the same two with the classifier in q6_K rows: what `llama-quantize ... Q4_0` writes (output.weight stays q6_K) -- round 6
+typedef TkShape<4096, 11008, 32, 32, 32000, WT_Q4_0, WT_Q6_K> TkLlama7BQ4Q6;
+typedef TkShape<2048, 5632, 32, 4, 32000, WT_Q4_0, WT_Q6_K> TkTinyLlamaQ4Q6;
 
 }  // namespace llmk

@@ -80,7 +80,8 @@ contains
     integer(4) :: n_layers, emb, ctx_len, n_heads, n_kv_heads, ffn, vocab_size
     character(len=:), allocatable :: key, str
     logical :: have_kv_heads
-    integer :: E, H, KV, hs, mt
+    integer :: E, H, KV, hs, mt, cls_ft, envstat
+    character(len=8) :: envbuf
     integer(1) :: b3(3)
     character(len=NAME_LEN) :: tname
 
@@ -221,7 +222,19 @@ contains
     w%wcls_type = mt
     deferred = .false.
     if (present(defer)) deferred = defer
-    if (deferred .and. dir(find("output.weight"))%ttype /= mt) w%wcls_type = GT_F32   ! dequantised on the way (q6_K)
+    ! stock llama.cpp q4_0 files keep output.weight in q6_K (the reference stops on any type >= 2, read_ggml.f90:633-635).
+    ! Round 6: its super-blocks go to the device AS THEY LIE IN THE FILE (llmk.h LLMK_TYPE_Q6_K; rows are whole super-blocks
+    ! when emb_dim is a multiple of 256) and the q4_0 persistent kernels dot them there; any other foreign type -- or
+    ! LLM_DEQUANT_CLS=1 in the environment, the round-2 behaviour -- is dequantised here exactly as ggml does and handed over as f32.
+    cls_ft = dir(find("output.weight"))%ttype
+    if (cls_ft /= mt) then
+       call get_environment_variable("LLM_DEQUANT_CLS", envbuf, status=envstat)
+       if (cls_ft == GT_Q6_K .and. mt /= GT_F32 .and. mod(E, 256) == 0 .and. .not. (envstat == 0 .and. envbuf(1:1) == "1")) then
+          w%wcls_type = GT_Q6_K
+       else
+          w%wcls_type = GT_F32
+       end if
+    end if
 
     if (.not. deferred) then
        allocate(w%token_embedding_table(E, vocab_size))
@@ -249,7 +262,11 @@ contains
           call read_f32(layer_name(l, "ffn_up.weight"), w%w13(:, H+1:2*H, l), E, H)
           call read_f32(layer_name(l, "ffn_down.weight"), w%w2(:, :, l), H, E)
        end do
-       call read_f32("output.weight", w%wcls, E, vocab_size)
+       if (cls_ft == GT_F32) then
+          call read_f32("output.weight", w%wcls, E, vocab_size)
+       else
+          call read_matrix_as_f32("output.weight", w%wcls, E, vocab_size)
+       end if
     else
        allocate(w%wqkv_raw(rowbytes(mt, E) * (E + 2*KV) * n_layers), w%wo_raw(rowbytes(mt, E) * E * n_layers), &
                 w%w13_raw(rowbytes(mt, E) * 2*H * n_layers), w%w2_raw(rowbytes(mt, H) * E * n_layers), &
@@ -263,10 +280,12 @@ contains
           call read_raw(layer_name(l, "ffn_up.weight"), w%w13_raw, mt, E, H, int(l-1, 8) * 2*H + H)
           call read_raw(layer_name(l, "ffn_down.weight"), w%w2_raw, mt, H, E, int(l-1, 8) * E)
        end do
-       ! stock llama.cpp q4_0 files keep output.weight in q6_K (the reference stops on any type >= 2,
-       ! read_ggml.f90:633-635): it is dequantised here exactly as ggml does and handed over as f32
-       if (dir(find("output.weight"))%ttype == mt) then
+       if (w%wcls_type == mt) then
           call read_raw("output.weight", w%wcls_raw, mt, E, vocab_size, 0_8)
+       else if (w%wcls_type == GT_Q6_K) then      ! raw super-blocks (see above)
+          deallocate(w%wcls_raw)
+          allocate(w%wcls_raw(rowbytes(GT_Q6_K, E) * vocab_size))
+          call read_raw("output.weight", w%wcls_raw, GT_Q6_K, E, vocab_size, 0_8)
        else
           deallocate(w%wcls_raw)
           allocate(w%wcls(E, vocab_size))
@@ -402,8 +421,8 @@ contains
     call sink(TID_RMS_FINAL_WEIGHT, 0, 0, 1, c_loc(w%rms_final_weight), 4_c_size_t * E, GT_F32)
 
     ! classifier: this rank's vocabulary rows; dequantised in chunks when the file keeps it in another type (q6_K)
-    if (w%wcls_type == mt) then
-       call stream_rows("output.weight", TID_WCLS, 0, E, V_, tp_rank * Vl, Vl, tp_rank * Vl)
+    if (w%wcls_type == mt .or. w%wcls_type == GT_Q6_K) then
+       call stream_rows("output.weight", TID_WCLS, 0, E, V_, tp_rank * Vl, Vl, tp_rank * Vl, w%wcls_type)
     else
        r0 = tp_rank * Vl
        do while (r0 < (tp_rank + 1) * Vl)
@@ -432,25 +451,28 @@ contains
   contains
 
     ! rows [frow, frow + n) of file tensor `name` (cols x rows_total) -> rows grow.. of layer `layer0` of fused tensor `tid`
-    subroutine stream_rows(name, tid, layer0, cols, rows_total, frow, n, grow)
+    subroutine stream_rows(name, tid, layer0, cols, rows_total, frow, n, grow, ttype)
       character(len=*), intent(in) :: name
       integer, intent(in) :: tid, layer0, cols, rows_total, frow, n, grow
-      integer :: idx
+      integer, intent(in), optional :: ttype       ! the tensor's own type when it is not the matrices' (q6_K classifier rows)
+      integer :: idx, tt
       integer(8) :: nb
+      tt = mt
+      if (present(ttype)) tt = ttype
       idx = find(name)
       call check_shape(idx, cols, rows_total)
-      if (dir(idx)%ttype /= mt) then
+      if (dir(idx)%ttype /= tt) then
          print *, "Type not supported", dir(idx)%ttype, " (mixed matrix types) for ", trim(name)
          stop 1
       end if
-      nb = n * rowbytes(mt, cols)
+      nb = n * rowbytes(tt, cols)
       if (allocated(raw)) then
          if (size(raw, kind=8) < nb) deallocate(raw)
       end if
       if (.not. allocated(raw)) allocate(raw(nb))
       peak = max(peak, nb)
-      read(u, pos=data_pos + dir(idx)%offset + frow * rowbytes(mt, cols)) raw(1:nb)
-      call sink(tid, layer0, grow, n, c_loc(raw), int(nb, c_size_t), mt)
+      read(u, pos=data_pos + dir(idx)%offset + frow * rowbytes(tt, cols)) raw(1:nb)
+      call sink(tid, layer0, grow, n, c_loc(raw), int(nb, c_size_t), tt)
     end subroutine
 
   end subroutine stream_ggml_weights
@@ -546,6 +568,7 @@ contains
     select case (t)
     case (GT_F16);  nb = 2_8 * k
     case (GT_Q4_0); nb = int(k / 32, 8) * 18_8
+    case (GT_Q6_K); nb = int(k / 256, 8) * 210_8
     case default;   nb = 4_8 * k
     end select
   end function

@@ -34,7 +34,8 @@ module weight_module
      real(kind=wp), allocatable :: wcls(:,:)                    ! (emb, vocab)
      ! f16 / q4_0 path: ggml type of the five matrices and their bytes in the same fused order
      integer :: wtype = 0
-     integer :: wcls_type = 0      ! ggml type the classifier is handed over in (f32 when the loader dequantised a q6_K output.weight)
+     integer :: wcls_type = 0      ! ggml type the classifier is handed over in: the matrices', or 14 (raw q6_K super-blocks: a stock q4_0 file's
+                                   ! output.weight, dotted on the device), or f32 when the loader dequantised a foreign type
      integer(c_int8_t), allocatable :: wqkv_raw(:), wo_raw(:), w13_raw(:), w2_raw(:), wcls_raw(:)
   end type TransformerWeights
 

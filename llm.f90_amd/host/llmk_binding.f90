@@ -6,7 +6,7 @@ module llmk_binding
   use iso_c_binding
   implicit none
 
-  integer(c_int), parameter :: LLMK_TYPE_F32 = 0, LLMK_TYPE_F16 = 1, LLMK_TYPE_Q4_0 = 2
+  integer(c_int), parameter :: LLMK_TYPE_F32 = 0, LLMK_TYPE_F16 = 1, LLMK_TYPE_Q4_0 = 2, LLMK_TYPE_Q6_K = 14
   integer(c_int), parameter :: LLMK_TOKEN_EMBEDDING_TABLE = 0, LLMK_RMS_ATT_WEIGHT = 1, LLMK_RMS_FFN_WEIGHT = 2, &
        LLMK_WQKV = 3, LLMK_WO = 4, LLMK_W13 = 5, LLMK_W2 = 6, LLMK_RMS_FINAL_WEIGHT = 7, LLMK_WCLS = 8
   integer(c_int), parameter :: LLMK_FLAG_NO_GRAPH = 1, LLMK_FLAG_TIMINGS = 2

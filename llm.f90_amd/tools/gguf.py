@@ -316,7 +316,7 @@ class FusedWeights:
     w13: np.ndarray = None                    # [L][2H][E*]  rows 0..H-1 gate, H.. up (read_ggml.f90:347,376)
     w2: np.ndarray = None                     # [L][E][H*]
     wcls: np.ndarray = None                   # [V][E*]
-    wcls_type: int = None                     # the classifier's own ggml type when it differs (q6_K output.weight -> f32)
+    wcls_type: int = None                     # the classifier's own ggml type when it differs: 14 = raw q6_K super-blocks, 0 = dequantised
 
     @property
     def cls_type(self) -> int:
@@ -706,8 +706,10 @@ def read_gguf(path: str) -> GGUFFile:
     return GGUFFile(version, kv, tensors, data_start, path, alignment)
 
 
-def load_fused(path: str) -> FusedWeights:
-    """Read a Llama GGUF into the fused weight_module layout (python mirror of load_ggml)."""
+def load_fused(path: str, dequant_cls: bool = False) -> FusedWeights:
+    """Read a Llama GGUF into the fused weight_module layout (python mirror of load_ggml).  A q6_K output.weight beside f16 / q4_0
+    matrices stays RAW (wcls_type 14: the device dots the super-blocks, csrc/q6k.h) unless dequant_cls -- the round-2 behaviour
+    and what the Fortran loader does under LLM_DEQUANT_CLS=1: any foreign classifier type is handed over as f32."""
     g = read_gguf(path)
     s = g.shape()
     E, H, L, KV = s.emb_dim, s.hidden_dim, s.n_layers, s.kv_dim
@@ -717,9 +719,13 @@ def load_fused(path: str) -> FusedWeights:
     fw.token_embedding_table = decode(emb, et, E)
     fw.rms_final_weight = g.read_tensor("output_norm.weight")[0].astype(np.float32)
     fw.wcls, ct = g.read_tensor("output.weight")
-    if ct != mt:   # mixed file: the classifier is handed over dequantised, as the Fortran loader does (q6_K output.weight)
-        fw.wcls = decode(fw.wcls, ct, E)
-        fw.wcls_type = GGML_F32
+    if ct != mt:   # mixed file (a stock q4_0 file's q6_K output.weight)
+        if ct == GGML_Q6_K and mt != GGML_F32 and E % QK_K == 0 and not dequant_cls:
+            fw.wcls = np.ascontiguousarray(fw.wcls).reshape(s.vocab_size, -1)
+            fw.wcls_type = GGML_Q6_K
+        else:
+            fw.wcls = decode(fw.wcls, ct, E)
+            fw.wcls_type = GGML_F32
     cat = lambda parts: np.ascontiguousarray(np.concatenate(parts, axis=0))
     fw.rms_att_weight = np.stack([g.read_tensor(f"blk.{i}.attn_norm.weight")[0] for i in range(L)]).astype(np.float32)
     fw.rms_ffn_weight = np.stack([g.read_tensor(f"blk.{i}.ffn_norm.weight")[0] for i in range(L)]).astype(np.float32)

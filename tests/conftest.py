@@ -15,7 +15,7 @@ GOLDEN_CASES = ["tiny-gqa", "tiny-gqa-prompt", "tiny-mha", "tiny-hs64", "tiny-hs
                 # long contexts from the real reference: KV lengths cross the attention kernels' timestep tiles
                 "tk-small-long", "tk-small-long-prompt", "tiny-hs128-long"]
 # full-size TinyLlama-1.1B from the real reference, reduced to ids + top-8 + 64 probe columns + checksums per position
-GOLDEN_COMPACT = ["tinyllama", "tinyllama-f16dec"]
+GOLDEN_COMPACT = ["tinyllama", "tinyllama-f16dec", "tinyllama-long"]
 
 # Parity bar (BASELINE.json north_star): logits within 1e-4 relative of the reference CPU path,
 # bit-exact argmax at temperature 0.  "Relative" is measured against the logit scale
@@ -53,6 +53,24 @@ def compact_err(logits, g, n=None):
     e_mean = np.abs(lg.sum(axis=1) - g["lsum"][:n]) / V
     e_rms = np.abs(np.sqrt((lg * lg).sum(axis=1)) - g["l2"][:n]) / np.sqrt(V)
     return np.maximum.reduce([e_top, e_probe, e_mean, e_rms]) / scale
+
+
+def top8_elementwise(logits, ref=None, g=None, n=None):
+    """Element-wise relative error on the reference's EIGHT LARGEST logits of every position: max |got - ref| / |ref| over them
+    (round-5 verdict, weak 1c: the max-norm of rel_err / compact_err would not notice 1e-4 * max|logit| on one small logit; the
+    top-8 are what a sampler or an argmax reads, and an element-wise ratio is meaningful there -- none of them is near zero).
+    `ref`: the reference's full logits [n][V]; or `g`: a compact golden (top8_idx / top8_val)."""
+    lg = np.asarray(logits, np.float64)
+    lg = lg.reshape(-1, lg.shape[-1])
+    n = len(lg) if n is None else n
+    if g is not None:
+        idx, val = g["top8_idx"][:n].astype(np.int64), g["top8_val"][:n].astype(np.float64)
+    else:
+        rf = np.asarray(ref, np.float64).reshape(-1, lg.shape[-1])[:n]
+        idx = np.argsort(-rf, axis=1, kind="stable")[:, :8]
+        val = np.take_along_axis(rf, idx, axis=1)
+    got = np.take_along_axis(lg[:n], idx, axis=1)
+    return np.max(np.abs(got - val) / np.maximum(np.abs(val), 1e-30), axis=1)
 
 
 def safe_positions(g, n=None):

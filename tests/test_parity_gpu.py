@@ -4,7 +4,7 @@ and (b) the oracle on the same seeded inputs.  Tolerance (BASELINE.json): logits
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, REL_TOL, compact_err, load_golden, rel_err, safe_positions
+from conftest import GOLDEN_CASES, REL_TOL, compact_err, load_golden, rel_err, safe_positions, top8_elementwise
 from llm_f90_amd import llmk
 from oracle.oracle import Oracle
 
@@ -156,6 +156,8 @@ def test_tinyllama_f32_matches_the_real_reference_over_320_positions(flags, gguf
     m.close()
     err = compact_err(logits, g)
     assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    e8 = top8_elementwise(logits, g=g)               # element-wise on the reference's eight largest logits (verdict r5, weak 1c)
+    assert e8.max() <= REL_TOL, (e8.max(), int(np.argmax(e8)))
     ok = safe_positions(g)
     assert ok.sum() > n // 2
     assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][ok])
@@ -185,6 +187,8 @@ def test_tinyllama_f16_matches_the_real_reference_on_the_decoded_weights(flags, 
     _, logits = m.generate(n, prompt=g["tokens"].tolist())
     err = compact_err(logits, g)
     assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    e8 = top8_elementwise(logits, g=g)
+    assert e8.max() <= REL_TOL, (e8.max(), int(np.argmax(e8)))
     ok = safe_positions(g)
     assert ok.sum() > n // 2
     assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][ok])
@@ -231,6 +235,8 @@ def test_token_kernel_attention_in_parts_matches_oracle_up_to_2048_timesteps(sha
     _, l = m.generate(s.seq_len, prompt=ot.tolist())
     err = rel_err(l, ol)
     assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    e8 = top8_elementwise(l, ref=ol)
+    assert e8.max() <= REL_TOL, (e8.max(), int(np.argmax(e8)))
     margin = np.sort(ol, axis=1)
     safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
     assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
@@ -389,6 +395,70 @@ def test_llama2_7b_column_geometry_q4_0_matches_oracle(gguf):
         assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
 
 
+@pytest.mark.parametrize("flags", [0, llmk.FLAG_MULTI_KERNEL], ids=["token-kernel", "multikernel"])
+def test_tinyllama_f32_matches_the_real_reference_over_its_whole_2048_position_context(flags, gguf):
+    """BASELINE.json configs[1] at FULL size over the reference's WHOLE context (round-5 verdict, item 4a):
+    tests/golden/tinyllama-long.npz = the unmodified-dims llama2.f90 (seq_len = 2048, llama2.f90:108) run for all 2,048
+    positions on the synthetic weights bench.py uses.  At the real 32-head / 4-kv-head geometry (8 CUs per head group, heads of a kv
+    group on one XCD: tk_att_role's placement takes other values than on tk-small) this crosses EVERY attention part count 1..8 of
+    the persistent kernel and every 256-timestep tile of attn_kernel<64>, against the reference's O(pos) loop (llama2.f90:572-598).
+    Teacher-forced; per position the top-8 logits, 64 probe columns and checksums within 1e-4 of max |logit|, the top-8
+    element-wise within 1e-4, greedy ids equal wherever the reference's margin allows; then llmk_prefill of the first k tokens
+    (k = 513, 1,025, 2,047: 5, 9 and 16 batches of 128) lands on the golden's position k."""
+    g = load_golden("tinyllama-long")
+    n = int(g["n"])
+    assert n == 2048
+    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
+    m = llmk.Llmk(fw, flags=flags)
+    assert m.path() == (1 if flags == 0 else 0)
+    _, logits = m.generate(n, prompt=g["tokens"].tolist())
+    err = compact_err(logits, g)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    e8 = top8_elementwise(logits, g=g)
+    assert e8.max() <= REL_TOL, (e8.max(), int(np.argmax(e8)))
+    ok = safe_positions(g)
+    assert ok.sum() > n // 2
+    assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][ok])
+    del logits
+    for k in (513, 1025, 2047):
+        m.reset()
+        lg = m.prefill([2] + g["tokens"][:k - 1].tolist(), 1)
+        gk = {f: v[k - 1:k] if getattr(v, "ndim", 0) and len(v) == n else v for f, v in g.items()}
+        assert compact_err(lg[None], gk).max() <= REL_TOL, k
+        assert top8_elementwise(lg[None], g=gk).max() <= REL_TOL, k
+        # ... and the decode path continues from the prefilled cache onto the golden's next position
+        if k < n:
+            l2 = m.forward(int(g["tokens"][k - 1]), k + 1)
+            gk1 = {f: v[k:k + 1] if getattr(v, "ndim", 0) and len(v) == n else v for f, v in g.items()}
+            assert compact_err(l2[None], gk1).max() <= REL_TOL, k
+    m.close()
+
+
+def test_llama2_7b_column_geometry_q4_0_long_context_matches_oracle(gguf):
+    """BASELINE.json configs[3] at its real column geometry over a LONG context (round-5 verdict, item 4b): E 4096, H 11008, head
+    size 128, MHA (32 kv heads: one CU group per head), V 32000, 2 layers, 2,100 positions -- every attention part count 1..8 of
+    the q4_0 persistent kernel at head size 128 (merge in two rounds from 6 parts on: tk_service), against the ORACLE (f32
+    reference path, llama2.f90:572-598, on the host-decoded q4_0 weights; omp flavour, bit-identical to strict), not GPU against
+    GPU.  Teacher-forced, every logit of every position; the multi-kernel path (attn_kernel<128>, 128-timestep tiles) beside it."""
+    s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 2100)
+    fw = gguf.synth_fused(s, 7, 2)
+    n = s.seq_len
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    for flags in (0, llmk.FLAG_MULTI_KERNEL):
+        m = llmk.Llmk(fw, flags=flags)
+        assert m.path() == (1 if flags == 0 else 0)
+        _, l = m.generate(n, prompt=ot.tolist())
+        m.close()
+        err = rel_err(l, ol)
+        assert err.max() <= REL_TOL, (flags, err.max(), int(np.argmax(err)))
+        e8 = top8_elementwise(l, ref=ol)
+        assert e8.max() <= REL_TOL, (flags, e8.max(), int(np.argmax(e8)))
+        assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+        del l
+
+
 def test_llama2_7b_q4_0_activation_beyond_f16_falls_back_to_the_multi_kernel_path(gguf):
     """The q4_0 persistent kernel dots its units against an f16 hi | lo image of x (csrc/q4_units.h).  Residual-stream images
     are scaled by a power of two from the previous rmsnorm, so a residual that merely GROWS is fine (the full-depth golden's does,
@@ -448,6 +518,8 @@ def test_llama2_7b_q4_0_full_depth_matches_the_real_reference(flags, llama7b_q4_
     _, logits = m.generate(n, prompt=g["tokens"].tolist())
     err = compact_err(logits, g)
     assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    e8 = top8_elementwise(logits, g=g)
+    assert e8.max() <= REL_TOL, (e8.max(), int(np.argmax(e8)))
     ok = safe_positions(g)
     ok[:len(g["prompt_ids"])] = False                 # (`tokens` holds the PROMPT ids there, not the reference's greedy choice)
     assert ok.sum() >= (n - len(g["prompt_ids"])) // 2
