@@ -174,7 +174,7 @@ class _ShapeOnly:
         self.shape, self.ggml_type = shape, wtype
 
 
-def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, collective="p2p"):
+def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, collective="p2p", cls_q6k=False):
     """Create the ctx first, then upload layer by layer (llmk_upload_rows hands over FULL layers; a
     tensor-parallel ctx keeps only its shard).  q4_0 weights of the big shapes are generated directly in
     block format.  With tp_size > 1 the ranks meet over torch.distributed (a side channel only): the 64-byte inbox
@@ -183,6 +183,8 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
     s = shape
     E, H, L, KV, V = s.emb_dim, s.hidden_dim, s.n_layers, s.kv_dim, s.vocab_size
     m = llmk.Llmk.create_empty(s, wtype, device, flags, tp_rank, tp_size)
+    if cls_q6k:       # the classifier as raw q6_K super-blocks: what a stock llama.cpp q4_0 file holds (csrc/q6k.h)
+        m.set_tensor_type("wcls", gguf.GGML_Q6_K)
     if (tp_size > 1 or rep is not None) and collective == "p2p" and tp_size > 1:
         handles = [None] * tp_size
         rep.dist.all_gather_object(handles, m.tp_p2p_handle())
@@ -217,17 +219,38 @@ def build_streamed(shape, wtype, fw, device, flags, tp_rank, tp_size, rep, colle
     if fw is not None:
         up(T["token_embedding_table"], 0, fw.token_embedding_table, 0)
         up(T["rms_final_weight"], 0, fw.rms_final_weight, 0)
-        up(T["wcls"], 0, fw.wcls, wtype)
+        if cls_q6k and fw.cls_type != gguf.GGML_Q6_K:
+            fw = gguf.with_q6k_classifier(fw)
+        up(T["wcls"], 0, fw.wcls, fw.cls_type if cls_q6k else wtype)
         for l in range(L):
             up(T["rms_att_weight"], l, fw.rms_att_weight[l], 0)
             up(T["rms_ffn_weight"], l, fw.rms_ffn_weight[l], 0)
             for k in ("wqkv", "wo", "w13", "w2"):
                 up(T[k], l, getattr(fw, k)[l], wtype)
         return m
+    if wtype == 1:
+        # f16 matrices of a big shape (Llama-2-7B f16: 13.2 GB), tensor by tensor: synth_fused's values, never more than one on the host
+        f16 = lambda name, rows, K: gguf.synth_tensor(s, SEED, idx[name], (rows, K), "mat").astype(np.float16)
+        up(T["token_embedding_table"], 0, gguf.synth_tensor(s, SEED, idx["token_embd.weight"], (V, E), "emb"), 0)
+        up(T["rms_final_weight"], 0, gguf.synth_tensor(s, SEED, idx["output_norm.weight"], (E,), "norm"), 0)
+        up(T["wcls"], 0, f16("output.weight", V, E), 1)
+        for l in range(L):
+            pre = f"blk.{l}."
+            up(T["rms_att_weight"], l, gguf.synth_tensor(s, SEED, idx[pre + "attn_norm.weight"], (E,), "norm"), 0)
+            up(T["rms_ffn_weight"], l, gguf.synth_tensor(s, SEED, idx[pre + "ffn_norm.weight"], (E,), "norm"), 0)
+            up(T["wqkv"], l, np.concatenate([f16(pre + "attn_q.weight", E, E), f16(pre + "attn_k.weight", KV, E),
+                                             f16(pre + "attn_v.weight", KV, E)]), 1)
+            up(T["wo"], l, f16(pre + "attn_output.weight", E, E), 1)
+            up(T["w13"], l, np.concatenate([f16(pre + "ffn_gate.weight", H, E), f16(pre + "ffn_up.weight", H, E)]), 1)
+            up(T["w2"], l, f16(pre + "ffn_down.weight", E, H), 1)
+        return m
     q4 = lambda name, rows, K: gguf.synth_q4_rows(SEED, idx[name], rows, K)
     up(T["token_embedding_table"], 0, gguf.synth_tensor(s, SEED, idx["token_embd.weight"], (V, E), "emb"), 0)
     up(T["rms_final_weight"], 0, gguf.synth_tensor(s, SEED, idx["output_norm.weight"], (E,), "norm"), 0)
-    up(T["wcls"], 0, q4("output.weight", V, E), 2)
+    if cls_q6k:
+        up(T["wcls"], 0, gguf.quantize_q6_K(gguf.dequantize_q4_0(q4("output.weight", V, E), E)).reshape(V, -1), gguf.GGML_Q6_K)
+    else:
+        up(T["wcls"], 0, q4("output.weight", V, E), 2)
     for l in range(L):
         pre = f"blk.{l}."
         up(T["rms_att_weight"], l, gguf.synth_tensor(s, SEED, idx[pre + "attn_norm.weight"], (E,), "norm"), 0)
@@ -325,6 +348,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--shape", default="tinyllama", choices=sorted(gguf.SHAPES))
     ap.add_argument("--type", default="f32", choices=["f32", "f16", "q4_0"])
+    ap.add_argument("--cls-q6k", action="store_true", help="the classifier as q6_K rows beside f16 / q4_0 matrices: the layout of a stock llama.cpp q4_0 file (output.weight stays q6_K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fortran-host", action="store_true", help="skip the `fortran_host` leg (the ./llm CLI timed on the same GGUF)")
     ap.add_argument("--fortran-host", action="store_true", help="run the `fortran_host` leg even with --no-cpu-baseline")
@@ -365,13 +389,17 @@ def main():
     t0 = time.perf_counter()
     flags = (llmk.FLAG_NO_GRAPH if a.no_graph else 0) | (llmk.FLAG_MULTI_KERNEL if a.multi_kernel else 0)
     big = shape.matmul_params() > 3e9            # 7B / 70B: never materialise f32 weights on the host
-    if big and wtype != 2:
-        raise SystemExit("the 7B/70B shapes are benchmarked as q4_0 (BASELINE.json configs[3], configs[4])")
+    if big and (wtype == 0 or (wtype == 1 and (a.tp or shape.matmul_params() > 1e10))):
+        raise SystemExit("the 7B/70B shapes are benchmarked as q4_0 (BASELINE.json configs[3], configs[4]); Llama-2-7B also as f16 (13.2 GB)")
     fw = None if big else gguf.synth_fused(shape, SEED, wtype)
+    if a.cls_q6k and (wtype == 0 or shape.emb_dim % 256):
+        raise SystemExit("--cls-q6k: a q6_K classifier beside f16 / q4_0 matrices, emb_dim a multiple of 256")
+    if a.cls_q6k and fw is not None:
+        fw = gguf.with_q6k_classifier(fw)
     t_gen = time.perf_counter() - t0
     if a.tp or big:
         m = build_streamed(shape, wtype, fw, local, flags, rank if a.tp else 0, world if a.tp else 1, rep if a.tp else None,
-                           a.tp_collective)
+                           a.tp_collective, cls_q6k=a.cls_q6k)
     else:
         m = llmk.Llmk(fw, device=local, flags=flags)
     t_up = time.perf_counter() - t0 - t_gen
@@ -440,7 +468,7 @@ def main():
         "timing": (f"median of {repeats} repetitions of the whole run ({W} warm-up + {K} timed positions each, context reset between)"
                    if repeats > 1 else "one run"),
         "value_all": [round((1 if a.tp else world) * K / t, 1) for t, _ in runs],
-        "config": {"workload": f"{a.shape} {a.type} decode, greedy, positions {W + 1}..{W + K} (./llm -n {W + K} -t 0)",
+        "config": {"workload": f"{a.shape} {a.type}{' + q6_K classifier' if a.cls_q6k else ''} decode, greedy, positions {W + 1}..{W + K} (./llm -n {W + K} -t 0)",
                    "consumer": "device argmax, K positions pipelined in one call (llmk_decode_greedy): an AUXILIARY line, the headline keeps the reference's host consumer" if step else "logits to host + host argmax (llmk_forward)",
                    "parallelism": ((f"tp{world} (row-parallel GEMVs, " + ("one-shot peer-memory all-reduce" if m.path() == 2 else "RCCL all-reduce")
                                     + (f", peer-memory self-test verdicts per rank {getattr(m, 'p2p_selftest', None)}" if a.tp_collective == "p2p" else "")

@@ -240,7 +240,13 @@ int llmk_peek(llmk_ctx *ctx, int which, int layer, int pos, float *out, int n);
 #define LLMK_PATH_TOKEN_KERNEL 1     /* persistent whole-token kernel (csrc/token_kernel.h)                          */
 #define LLMK_PATH_TP_P2P 2           /* tensor-parallel rank: 6 launches per layer + one-shot peer-memory exchanges  */
 #define LLMK_PATH_TP_RCCL 3          /* tensor-parallel rank: eager launches + ncclAllReduce / ncclAllGather         */
-#define LLMK_PATH_TP_UNCONNECTED 4   /* tensor-parallel rank without collectives yet (llmk_tp_segment stepping only) */
+#define LLMK_PATH_TP_UNCONNECTED 4   /* The model shapes the persistent whole-token kernel is instantiated for in this build, as text:
+ * "E,H,NH,NKV,V,type[+q6_K];..." (type = the matrices' f32 | f16 | q4_0; +q6_K = with a q6_K classifier).  The reference's dims
+ * are compile-time parameters (llama2.f90:102-108); so are the kernel's -- `make TK_SHAPES="..."` adds shapes (llm.f90_amd/Makefile).
+ * Any other shape runs the multi-kernel path (llmk_path).  LLMK_E_SIZE when `buf` is too small. */
+int llmk_tk_shapes(char *buf, size_t n);
+
+/* tensor-parallel rank without collectives yet (llmk_tp_segment stepping only) */
 int llmk_path(llmk_ctx *ctx);
 /* How many ranks this ctx's collective actually spans: ncclCommCount of its RCCL communicator, or the number of mapped
  * peer inboxes (+ itself) on the peer-memory path, or 1.  For the benchmark line of a multi-GPU run (`ranks_seen`). */

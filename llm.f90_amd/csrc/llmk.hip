@@ -110,7 +110,7 @@ struct llmk_ctx {
     // on the multi-kernel path and the kernel stays in use (advisor, round 5: one such position used to cost the context a third of
     // its rate for good); TK_RANGE_LIMIT of them in a row retire it after all (a model it cannot hold), and its unit copies are freed
     int tk_range_events = 0, tk_range_run = 0;
-    int tk_shape = 0;      // 1 TinyLlama-1.1B f32, 2 the small f32 parity shape, 3 TinyLlama f16, 4 the small f16 parity shape, 5 Llama-2-7B q4_0, 6 TinyLlama q4_0
+    int tk_shape = 0;      // 1-based index into tk_table (the instantiated shapes: LLMK_TK_SHAPES), 0 = none
     unsigned long long* d_gran = nullptr;  // exchange granules: qkv | xb | xa | hb | x | attention parts
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
@@ -394,17 +394,34 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
     else hipLaunchKernelGGL((token_kernel<TK>), grid, dim3(TK_THREADS), c->tk_lds, c->stream, a);
     return hipGetLastError();
 }
+// ---- the shapes the persistent kernel is instantiated for -------------------------------------------------------------------
+// The reference's dims are seven `parameter` lines (llama2.f90:102-108: edit, make, run); the persistent kernel's are template
+// arguments, so a shape is one line here: the built-in list below (BASELINE.json's configurations, the parity shapes, the
+// stock-file q6_K variants, Llama-2-7B f16) plus whatever the build adds --
+//     make -C llm.f90_amd TK_SHAPES="4096,14336,32,8,32000,WT_F16 5120,13824,40,40,32000,WT_F32"
+// turns every "E,H,NH,NKV,V,WT[,CLS]" into X(TkShape<...>) (Makefile: LLMK_TK_EXTRA_SHAPES); TkShape's static_asserts say at
+// compile time whether a shape fits the kernel (token_kernel.h).  llmk_tk_shapes() lists them; `llm --vx` prints that list.
+#ifndef LLMK_TK_EXTRA_SHAPES
+#define LLMK_TK_EXTRA_SHAPES(X)
+#endif
+#define LLMK_TK_SHAPES(X)                                                                                          \
+    X(TkTinyLlama) X(TkSmall) X(TkTinyLlamaF16) X(TkSmallF16) X(TkLlama7BQ4) X(TkTinyLlamaQ4) X(TkLlama7BQ4Q6)     \
+    X(TkTinyLlamaQ4Q6) X(TkLlama7BF16) LLMK_TK_EXTRA_SHAPES(X)
+struct TkEntry {
+    int E, H, NH, NKV, V, WT, CLS;
+    bool q4;                                        // units layout (q16_build) before the first token
+    hipError_t (*launch)(llmk_ctx*, bool, const TkGreedy&);
+    int (*setup)(llmk_ctx*, int);
+};
+template <class TK> int tk_setup(llmk_ctx* c, int id);
+#define TK_ENTRY(...) {__VA_ARGS__::E, __VA_ARGS__::H, __VA_ARGS__::NH, __VA_ARGS__::NKV, __VA_ARGS__::V, __VA_ARGS__::WT, __VA_ARGS__::CLS, \
+                       __VA_ARGS__::Q4, launch_token_kernel_t<__VA_ARGS__>, tk_setup<__VA_ARGS__>},
+static const TkEntry tk_table[] = {LLMK_TK_SHAPES(TK_ENTRY)};
+#undef TK_ENTRY
+constexpr int TK_NSHAPES = (int)(sizeof(tk_table) / sizeof(tk_table[0]));
 hipError_t launch_token_kernel(llmk_ctx* c, bool direct = false, const TkGreedy& g = TkGreedy()) {
-    switch (c->tk_shape) {
-        case 1: return launch_token_kernel_t<TkTinyLlama>(c, direct, g);
-        case 2: return launch_token_kernel_t<TkSmall>(c, direct, g);
-        case 3: return launch_token_kernel_t<TkTinyLlamaF16>(c, direct, g);
-        case 4: return launch_token_kernel_t<TkSmallF16>(c, direct, g);
-        case 5: return launch_token_kernel_t<TkLlama7BQ4>(c, direct, g);
-        case 6: return launch_token_kernel_t<TkTinyLlamaQ4>(c, direct, g);
-        case 7: return launch_token_kernel_t<TkLlama7BQ4Q6>(c, direct, g);
-        default: return launch_token_kernel_t<TkTinyLlamaQ4Q6>(c, direct, g);
-    }
+    if (c->tk_shape < 1 || c->tk_shape > TK_NSHAPES) return hipErrorInvalidValue;
+    return tk_table[c->tk_shape - 1].launch(c, direct, g);
 }
 // the last position of a pipelined greedy run has no next launch to fold its candidates: this does (1 wave)
 // (no id while the sticky error word is set, and none from candidates without a finite maximum: see tk_token)
@@ -463,14 +480,8 @@ int tk_setup(llmk_ctx* c, int id) {
 // when the classifier gets a type of its own (llmk_set_tensor_type: the q6_K instantiations).
 int tk_setup_all(llmk_ctx* c) {
     if ((c->cfg.flags & (LLMK_FLAG_MULTI_KERNEL | LLMK_FLAG_TIMINGS)) || c->n_cu != TK_NCU || c->tp_size != 1 || c->tk_retired) return LLMK_OK;
-    int rc = tk_setup<TkTinyLlama>(c, 1);
-    if (rc == LLMK_OK) rc = tk_setup<TkSmall>(c, 2);
-    if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaF16>(c, 3);
-    if (rc == LLMK_OK) rc = tk_setup<TkSmallF16>(c, 4);
-    if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4>(c, 5);
-    if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaQ4>(c, 6);
-    if (rc == LLMK_OK) rc = tk_setup<TkLlama7BQ4Q6>(c, 7);
-    if (rc == LLMK_OK) rc = tk_setup<TkTinyLlamaQ4Q6>(c, 8);
+    int rc = LLMK_OK;
+    for (int i = 0; i < TK_NSHAPES && rc == LLMK_OK; ++i) rc = tk_table[i].setup(c, i + 1);      // (the first match takes the ctx)
     return rc;
 }
 
@@ -612,7 +623,7 @@ int check_ready(llmk_ctx* c) {
     if (!c) return LLMK_E_ARG;
     for (int i = 0; i < LLMK_N_TENSORS; ++i)
         if (!c->t[i].uploaded) return LLMK_E_STATE;
-    if (c->use_tk && c->tk_shape >= 5 && c->q16_dirty) return q16_build(c);
+    if (c->use_tk && tk_table[c->tk_shape - 1].q4 && c->q16_dirty) return q16_build(c);
     return LLMK_OK;
 }
 
@@ -2103,6 +2114,23 @@ int llmk_tensor_checksum(llmk_ctx* c, int tid, unsigned long long* out) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d_out);
     return e == hipSuccess ? LLMK_OK : LLMK_E_HIP + (int)e;
+}
+
+// "E,H,NH,NKV,V,type[+cls];..." of every shape the persistent kernel is instantiated for in THIS build (LLMK_TK_SHAPES)
+int llmk_tk_shapes(char* buf, size_t n) {
+    if (!buf || n == 0) return LLMK_E_ARG;
+    static const char* tn[] = {"f32", "f16", "q4_0"};
+    size_t o = 0;
+    buf[0] = 0;
+    for (int i = 0; i < TK_NSHAPES; ++i) {
+        const TkEntry& e = tk_table[i];
+        char one[96];
+        const int k = snprintf(one, sizeof(one), "%s%d,%d,%d,%d,%d,%s%s", i ? ";" : "", e.E, e.H, e.NH, e.NKV, e.V, tn[e.WT], e.CLS != e.WT ? "+q6_K" : "");
+        if (o + (size_t)k + 1 > n) return LLMK_E_SIZE;
+        memcpy(buf + o, one, (size_t)k + 1);
+        o += (size_t)k;
+    }
+    return LLMK_OK;
 }
 
 int llmk_path(llmk_ctx* c) {

@@ -127,6 +127,23 @@
 // HBM saturated for 8.6 us, the attention CUs' K/V rows and q polls queue in it, and xb arrives later everywhere;
 // profiles/r05_ab.jsonl "hopq".  One unit per wave is what the hop takes.)
 
+// ---- experiment switches: MEASUREMENT BUILDS ONLY (tests/host_tools/build_variant.sh NAME -DLLMK_EXP_...; never in libllmk.so) ----
+// Wrong results by construction, only the kernel's time is read (profiles/r05_slot_decomposition.txt, r06_f16_stream_decomposition.txt):
+//   LLMK_EXP_NOHBM  every tile / unit request reads one line of zeros (same instructions, same counts): the exchange chain and
+//                   the dots without the weight stream;
+//   LLMK_EXP_NODOT  f32 / f16: tiles are requested and waited for, not multiplied: the stream and the chain without the dots.
+// Combined with the debug library's LLMK_TK_NOSYNC=1 (nothing waits for a tag: the stream and the dots without the chain).
+#if defined(LLMK_EXP_NOHBM)
+constexpr bool TK_EXP_NOHBM = true;
+#else
+constexpr bool TK_EXP_NOHBM = false;
+#endif
+#if defined(LLMK_EXP_NODOT)
+constexpr bool TK_EXP_NODOT = true;
+#else
+constexpr bool TK_EXP_NODOT = false;
+#endif
+
 namespace llmk {
 
 constexpr int TK_NCU = 256;               // one workgroup per CU
@@ -314,7 +331,9 @@ struct TkShape {
                          MAXPT = MAXP0 > MAXP1 ? MAXP0 : MAXP1,          // partial sums per phase (f32 / f16: one per tile row)
                          MAXP = Q4 ? tk_cmax(Q16_ROWS * tk_cmax(tk_cmax(UQ, UA), tk_cmax(UD, UC)), R_C) : MAXPT;   // q4_0: 16 per unit
     static_assert(QKV % 2 == 0 && (Q4 || (E % TK_NCU == 0 && H % TK_NCU == 0)) && V % RPT == 0, "rows must split over CUs");
-    static_assert(E % SEGW == 0 && (Q4 || H % SEGW == 0) && E % 32 == 0 && H % 32 == 0, "rows are whole 1 KB segments (q4_0: K = H may be ragged)");
+    // K = H rows may end inside a segment (Llama-2-7B: H = 11008 = 21.5 segments of f16): the lanes past the row end multiply the
+    // next row's first weights (the tensor's slack behind the last row) with the ZEROS the staged vector is padded with (TkLds::XS_BYTES)
+    static_assert(E % SEGW == 0 && E % 32 == 0 && H % 128 == 0, "K = E rows are whole 1 KB segments; hb is gathered in 16-byte loads of two granules");
     static_assert((Q4 || (LPR_E <= LPT && R_Q % RPT == 0 && (R_A / 2) % RPT == 0)) && R_D % RPT == 0 && R_O % RPT == 0,
                   "a K = E row is one tile row; row ranges are whole tiles");
     static_assert(!Q4 || (E % 1024 == 0 && QKV % Q16_ROWS == 0 && KV % Q16_ROWS == 0 && H % Q16_ROWS == 0 && AG_ATT >= 1),
@@ -346,7 +365,7 @@ struct TkLds {
     static constexpr int XS = 0;
     // q4_0: the streaming input is staged as the matrix core's B operand: an f16 hi | lo image, the blocks' sums, a line of zeros
     // (q4_units.h Q16Img)
-    static constexpr int XS_BYTES = SH::Q4 ? Q16Img<SH::NBI>::BYTES : SH::H * 4;
+    static constexpr int XS_BYTES = SH::Q4 ? Q16Img<SH::NBI>::BYTES : SH::LPR_H * SH::SEGW * 4;      // (whole segments: zeros behind a ragged H)
     static constexpr int XRAW = XS + XS_BYTES;
     static constexpr int PART = XRAW + SH::E * 4;
     static constexpr int ATT_Q = PART + (((SH::MAXP + 1) * 4 + 15) / 16) * 16;   // q_h, k_cur, v_cur: 3*HS floats
@@ -511,7 +530,8 @@ constexpr int TK_XSC = 12;      // red8[TK_XSC]: that power of two (q4_0), next 
 constexpr int TK_XSC_B = 16, TK_XSC_H = 17, TK_AMX_B = 24, TK_AMX_H = 32;
 constexpr float TK_IMG_TARGET = 64.f;
 __device__ __forceinline__ float tk_next_scale(float cur, const float* amx8) {
-    float m = fmaxf(fmaxf(fmaxf(amx8[0], amx8[1]), fmaxf(amx8[2], amx8[3])), fmaxf(fmaxf(amx8[4], amx8[5]), fmaxf(amx8[6], amx8[7])));
+    const float4 a = reinterpret_cast<const float4*>(amx8)[0], b = reinterpret_cast<const float4*>(amx8)[1];      // (two 16-byte LDS reads)
+    float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
     m = m / cur;                                      // (a power of two: exact) the largest |element| as it is
     return (m > 0.f && m < 3.0e38f) ? tk_pow2_inv(m * (1.f / TK_IMG_TARGET)) : cur;
 }
@@ -561,7 +581,8 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                         amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1)));
                         q16_put2(ip + k * (4 * Q16_IMG_BLK), isc, y0, y1);
                         const float bs = row16_sum(y0 + y1);             // a load's 64 lanes hold 4 whole blocks, one per DPP row
-                        if ((lane & 15) == 15) { q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs); smax = fmaxf(smax, fabsf(bs)); }
+                        if ((lane & 15) == 15) q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs);
+                        smax = fmaxf(smax, fabsf(bs));      // (every lane: the other lanes' partial sums only make the check stricter)
                     } else {
                         *reinterpret_cast<float2*>(xs + e0 + k * 2 * WAVE) = make_float2(y0, y1);
                     }
@@ -680,7 +701,7 @@ template <class SH>
 __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const float4* zp, int lane) {
     if constexpr (SH::Q4) {
         // a unit: 8 x 1 KB of operand dwords + 1 KB of scales, contiguous (q4_units.h); no unit = nine reads of one line of zeros
-        const bool real = t.ncol != 0;
+        const bool real = t.ncol != 0 && !TK_EXP_NOHBM;
 #pragma unroll
         for (int j = 0; j <= TK_TCOLS; ++j) e.b[j] = ldg_nt(real ? t.p + j * WAVE + lane : zp);
         return;
@@ -688,7 +709,7 @@ __device__ __forceinline__ void tk_issue(TkSlot<SH>& e, const TkTile& t, const f
 #pragma unroll
     for (int j = 0; j < TK_TCOLS; ++j) {
         const int s = j / SH::LPT, jj = j % SH::LPT;                             // compile-time
-        const bool real = jj < t.ncol;                                             // wave-uniform select, no branch
+        const bool real = jj < t.ncol && !TK_EXP_NOHBM;                            // wave-uniform select, no branch
         const float4* pj = real ? t.p + s * t.rstride + jj * WAVE : zp;
         // an empty segment is ONE 16-byte access for the whole wave (every lane reads the same zero vector), not a 1 KB
         // sweep of the zero block: it still counts in vmcnt, but costs the CU's memory pipeline one line instead of eight
@@ -728,6 +749,13 @@ template <class SH>
 __device__ __forceinline__ void tk_dot(const TkSlot<SH>& e, const TkX<SH>& x, float (&out)[SH::RPT]) {
     static_assert(!SH::Q4, "q4_0 units are dotted on the matrix core (tk_unit)");
     const float4 (&b)[TK_TCOLS] = e.b;
+    if constexpr (TK_EXP_NODOT) {          // the tile is waited for (every register named), not multiplied
+#pragma unroll
+        for (int j = 0; j < TK_TCOLS; ++j) asm volatile("" :: "v"(b[j].x), "v"(b[j].y), "v"(b[j].z), "v"(b[j].w));
+#pragma unroll
+        for (int s = 0; s < SH::RPT; ++s) out[s] = x.v[0].x;
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < SH::RPT; ++s) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -922,7 +950,7 @@ __device__ __forceinline__ void tk_step(TkRing<SH>& r, const TokenArgs& a, int l
     else if constexpr (CLS) tn = tk_cls_at<SH, K + SH::NB - 1>(a, c, sw);
     else tn = tk_at<SH, K + SH::NB - 1>(a, l, c, sw);
     TkSlot<SH>& n = r.b[RN];
-    const bool nreal = tn.ncol != 0;
+    const bool nreal = tn.ncol != 0 && !TK_EXP_NOHBM;
     // the request in three pieces (4 + 4 + 1 loads), placed between the half groups of the dots
     auto req = [&](auto piece) {
         if constexpr (REQ) {
@@ -1910,6 +1938,11 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a_in) {
             for (int i = Q16Img<SH::NBI>::SUM + tid * 4; i < Q16Img<SH::NBI>::BYTES; i += TK_THREADS * 4) *reinterpret_cast<unsigned*>(img + i) = 0u;
             // layer 0's xb / hb images: the largest element assumed in [1, 2) (TK_XSC_B; first read behind the QKV phase's barriers)
             if (tid < 2) reinterpret_cast<float*>(lds + TkLds<SH>::RED8)[TK_XSC_B + tid] = TK_IMG_TARGET;
+        } else if constexpr (SH::H % SH::SEGW != 0) {
+            // f32 / f16, ragged K = H rows: the staged hb vector is whole segments wide, the part behind H stays zero for the whole
+            // launch (the gathers write H floats); first read behind the QKV phase's barriers
+            float* xs = reinterpret_cast<float*>(lds + TkLds<SH>::XS);
+            for (int i = SH::H + tid; i < SH::LPR_H * SH::SEGW; i += TK_THREADS) xs[i] = 0.f;
         }
     }
     if (wid == TK_NS) { __builtin_amdgcn_s_setprio(3); tk_service<SH, GR>(a, lds, c, lane, tid); }
@@ -1926,5 +1959,8 @@ typedef TkShape<2048, 5632, 32, 4, 32000, WT_Q4_0> TkTinyLlamaQ4;   // TinyLlama
 // the same two with the classifier in q6_K rows: what `llama-quantize ... Q4_0` writes (output.weight stays q6_K) -- round 6
 typedef TkShape<4096, 11008, 32, 32, 32000, WT_Q4_0, WT_Q6_K> TkLlama7BQ4Q6;
 typedef TkShape<2048, 5632, 32, 4, 32000, WT_Q4_0, WT_Q6_K> TkTinyLlamaQ4Q6;
+// Llama-2-7B with f16 matrices (round 6: "any shape the reference could be recompiled for" -- K = E rows of 8 segments: one row
+// per tile, a 64-register x fragment; K = H rows end inside their 22nd segment)
+typedef TkShape<4096, 11008, 32, 32, 32000, WT_F16> TkLlama7BF16;
 
 }  // namespace llmk

@@ -250,6 +250,21 @@ program llm
      case (3); print *, "device path: tensor-parallel, RCCL collectives"
      case default; print *, "device path: five kernels per layer (no persistent kernel is instantiated for this shape and weight type)"
      end select
+     ! ... and for which shapes this build of libllmk.so has one (make TK_SHAPES="E,H,NH,NKV,V,WT ..." adds more; the reference's
+     ! own dims are seven compile-time parameters, llama2.f90:102-108)
+     block
+       character(kind=c_char) :: sbuf(4096)
+       character(len=4096) :: stxt
+       integer :: k
+       if (llmk_tk_shapes(sbuf, int(size(sbuf), c_size_t)) == 0) then
+          stxt = ""
+          do k = 1, size(sbuf)
+             if (sbuf(k) == c_null_char) exit
+             stxt(k:k) = sbuf(k)
+          end do
+          print *, "persistent kernel built for (E,H,heads,kv heads,V,type): ", trim(stxt)
+       end if
+     end block
   end if
 
   allocate(logits(conf%vocab_size), probs(conf%vocab_size))

@@ -124,6 +124,11 @@ module llmk_binding
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx
      end function
+     integer(c_int) function llmk_tk_shapes(buf, n) bind(C, name="llmk_tk_shapes")
+       import :: c_int, c_char, c_size_t
+       character(kind=c_char), intent(out) :: buf(*)
+       integer(c_size_t), value :: n
+     end function
      integer(c_int) function llmk_reset(ctx) bind(C, name="llmk_reset")
        import :: c_int, c_ptr
        type(c_ptr), value :: ctx

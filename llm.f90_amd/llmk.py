@@ -25,7 +25,7 @@ SYMBOLS = ["llmk_create", "llmk_create_tp", "llmk_tp_unique_id", "llmk_tp_init_c
            "llmk_tp_p2p_connect_local", "llmk_tp_p2p_selftest", "llmk_tp_p2p_stress", "llmk_tp_p2p_disable", "llmk_tp_begin", "llmk_tp_segment",
            "llmk_tp_read_partial", "llmk_tp_write_partial", "llmk_tp_read_logits", "llmk_upload", "llmk_upload_rows",
            "llmk_set_rope_freqs", "llmk_set_tensor_type", "llmk_set_rms_eps", "llmk_forward", "llmk_prefill", "llmk_forward_greedy", "llmk_decode_greedy", "llmk_reset", "llmk_timings",
-           "llmk_time_kernel", "llmk_peek", "llmk_tensor_checksum", "llmk_path", "llmk_tp_ranks_seen", "llmk_destroy", "llmk_strerror", "llmk_version"]
+           "llmk_time_kernel", "llmk_peek", "llmk_tensor_checksum", "llmk_path", "llmk_tk_shapes", "llmk_tp_ranks_seen", "llmk_destroy", "llmk_strerror", "llmk_version"]
 PATH_NAMES = {0: "multi-kernel (5 launches per layer)", 1: "persistent whole-token kernel",
               2: "tensor-parallel rank: 6 launches per layer + one-shot peer-memory exchanges",
               3: "tensor-parallel rank: eager launches + RCCL collectives", 4: "tensor-parallel rank, collectives not connected"}
@@ -92,12 +92,14 @@ def lib():
         L.llmk_peek.argtypes = [vp, ci, ci, ci, cf, ci]
         L.llmk_destroy.argtypes = [vp]
         L.llmk_path.argtypes = [vp]
+        if hasattr(L, "llmk_tk_shapes"):          # (absent from an older build selected with LLMK_LIB for an A/B)
+            L.llmk_tk_shapes.argtypes = [C.c_char_p, C.c_size_t]
         L.llmk_tp_ranks_seen.argtypes = [vp]
         L.llmk_strerror.argtypes = [ci]
         L.llmk_strerror.restype = C.c_char_p
         L.llmk_version.argtypes = []
         for s in SYMBOLS:
-            if s != "llmk_strerror":
+            if s != "llmk_strerror" and (hasattr(L, s) or not os.environ.get("LLMK_LIB")):
                 getattr(L, s).restype = ci
         _lib = L
     return _lib
@@ -106,6 +108,17 @@ def lib():
 def _ck(rc):
     if rc != 0:
         raise LlmkError(rc, lib().llmk_strerror(rc).decode())
+
+
+def tk_shapes():
+    """[(E, H, NH, NKV, V, "f32" | "f16" | "q4_0" | "q4_0+q6_K"), ...]: the shapes the persistent kernel is built for (llmk_tk_shapes)"""
+    buf = C.create_string_buffer(8192)
+    _ck(lib().llmk_tk_shapes(buf, len(buf)))
+    out = []
+    for item in buf.value.decode().split(";"):
+        f = item.split(",")
+        out.append(tuple(int(x) for x in f[:5]) + (f[5],))
+    return out
 
 
 class Llmk:
@@ -161,6 +174,10 @@ class Llmk:
     def set_rope_freqs(self, fr):
         fr = np.ascontiguousarray(fr, np.float32)
         _ck(lib().llmk_set_rope_freqs(self._h, fr.ctypes.data_as(C.POINTER(C.c_float)), len(fr)))
+
+    def set_tensor_type(self, name: str, ggml_type: int):
+        """give a tensor (the classifier) a ggml type of its own BEFORE it is uploaded (llmk_set_tensor_type)"""
+        _ck(lib().llmk_set_tensor_type(self._h, TENSOR_IDS[name], ggml_type))
 
     def set_rms_eps(self, eps: float):
         _ck(lib().llmk_set_rms_eps(self._h, eps))

@@ -331,6 +331,16 @@ class FusedWeights:
                             decode(self.wcls, self.cls_type, s.emb_dim))
 
 
+def with_q6k_classifier(fw: FusedWeights) -> FusedWeights:
+    """The same weights with the classifier as RAW q6_K super-blocks (quantised from its decoded values): what `llama-quantize
+    ... Q4_0` leaves in a stock file's output.weight, and what load_fused() returns for such a file."""
+    import dataclasses
+    E = fw.shape.emb_dim
+    assert E % QK_K == 0
+    raw = quantize_q6_K(decode(fw.wcls, fw.cls_type, E)).reshape(fw.shape.vocab_size, -1)
+    return dataclasses.replace(fw, wcls=np.ascontiguousarray(raw), wcls_type=GGML_Q6_K)
+
+
 def synth_fused_q4_direct(shape: LlamaShape, seed: int, scale_jitter: bool = True) -> FusedWeights:
     """q4_0 FusedWeights with every matrix generated directly in block format (synth_q4_rows): seconds where
     synth_fused + quantisation takes minutes at 70B geometry.  Embedding and norm gains as in synth_fused."""

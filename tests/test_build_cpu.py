@@ -29,7 +29,7 @@ def test_persistent_kernels_do_not_spill():
     assert len(rows) >= 5, r.stdout
     # the f32 / f16 kernels' rmsnorm staging in 16-byte LDS accesses (round 5: hipcc once split them in pairs of 8: +7 % on the f16 token)
     for l in rows:
-        if ", 0>" in l or ", 1>" in l:           # weight types f32 / f16
+        if ", 0, -1>" in l or ", 1, -1>" in l:   # weight types f32 / f16 (TkShape<..., WT, CLS>)
             k = re.search(r"lds64 (-?\d+)/(-?\d+)", l)
             assert k and 0 <= int(k.group(1)) <= 4 and 0 <= int(k.group(2)) <= 4, l
     for l in rows:

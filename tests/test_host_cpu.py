@@ -47,7 +47,7 @@ def _read_dump(path, gguf):
     out["rms_att_weight"] = take("<f4", L * E).reshape(L, E)
     out["rms_ffn_weight"] = take("<f4", L * E).reshape(L, E)
     out["rms_final_weight"] = take("<f4", E)
-    rbt = lambda t, k: {0: 4 * k, 1: 2 * k, 2: k // 32 * 18}[int(t)]
+    rbt = lambda t, k: {0: 4 * k, 1: 2 * k, 2: k // 32 * 18, 14: k // 256 * 210}[int(t)]
     for name, rows, k, t in (("wqkv", L * (E + 2 * KV), E, wtype), ("wo", L * E, E, wtype), ("w13", L * 2 * H, E, wtype),
                              ("w2", L * E, H, wtype), ("wcls", V, E, wcls_type)):
         out[name] = take("u1", rows * rbt(t, k)).reshape(rows, rbt(t, k))
@@ -82,27 +82,33 @@ def test_fortran_loader_matches_python_reader(tools, gguf, shape, wtype):
     assert np.array_equal(got["scores"], -np.arange(s.vocab_size, dtype=np.float32))
 
 
-def test_fortran_loader_dequantises_a_q6k_output_weight_and_keeps_the_file_s_eps_and_rope_base(tools, gguf):
-    """A stock llama.cpp q4_0 file keeps output.weight in q6_K (the reference stops on it, read_ggml.f90:633-635): the
-    loader hands the classifier over as f32, decoded exactly as ggml's dequantize_row_q6_K does (the python mirror in
-    tools/gguf.py is checked against a scalar transcription of that loop).  It also records the file's rmsnorm epsilon
-    and RoPE base for hosts that opt in (the reference ignores both)."""
+def test_fortran_loader_hands_a_q6k_output_weight_over_raw_or_dequantised_and_keeps_the_file_s_eps_and_rope_base(tools, gguf):
+    """A stock llama.cpp q4_0 file keeps output.weight in q6_K (the reference stops on it, read_ggml.f90:633-635).  Round 6: the
+    loader hands the super-blocks over AS THEY LIE IN THE FILE (wcls_type 14: the device dots them, csrc/q6k.h); under
+    LLM_DEQUANT_CLS=1 -- the round-2 behaviour -- as f32, decoded exactly as ggml's dequantize_row_q6_K does (the python mirror in
+    tools/gguf.py is checked against a scalar transcription of that loop).  It also records the file's rmsnorm epsilon and RoPE
+    base for hosts that opt in (the reference ignores both)."""
     d = tools["dir"]
     s = gguf.LlamaShape(256, 512, 2, 4, 2, 320, 32)      # E a multiple of 256: q6_K super-blocks
     fw = gguf.synth_fused(s, 99, 2)
     path = str(d / "q6k.gguf")
     gguf.write_gguf(path, fw, rms_eps=1e-6, rope_freq_base=500000.0, output_q6k=True)
     out = str(d / "dump_q6k.bin")
-    subprocess.run([tools["dump"], path, out], capture_output=True, check=True)
-    got = _read_dump(out, gguf)
-    ref = gguf.load_fused(path)
-    assert got["wtype"] == 2 and got["wcls_type"] == 0 and ref.cls_type == 0
-    assert np.array_equal(got["wcls"].reshape(-1), np.ascontiguousarray(ref.wcls).view(np.uint8).reshape(-1))
-    assert np.array_equal(got["wqkv"].reshape(-1), ref.wqkv.view(np.uint8).reshape(-1))
-    assert got["rms_eps"] == np.float32(1e-6) and got["rope_freq_base"] == np.float32(500000.0)
-    # the decoded classifier is the q6_K rounding of the q4_0 one: close, not equal
+    for dequant in (False, True):
+        env = dict(os.environ, LLM_DEQUANT_CLS="1") if dequant else {k: v for k, v in os.environ.items() if k != "LLM_DEQUANT_CLS"}
+        subprocess.run([tools["dump"], path, out], capture_output=True, check=True, env=env)
+        got = _read_dump(out, gguf)
+        ref = gguf.load_fused(path, dequant_cls=dequant)
+        want = 0 if dequant else 14
+        assert got["wtype"] == 2 and got["wcls_type"] == want and ref.cls_type == want
+        assert np.array_equal(got["wcls"].reshape(-1), np.ascontiguousarray(ref.wcls).view(np.uint8).reshape(-1))
+        assert np.array_equal(got["wqkv"].reshape(-1), ref.wqkv.view(np.uint8).reshape(-1))
+        assert got["rms_eps"] == np.float32(1e-6) and got["rope_freq_base"] == np.float32(500000.0)
+    # the decoded classifier is the q6_K rounding of the q4_0 one: close, not equal; raw and dequantised forms decode alike
     full = gguf.decode(fw.wcls, 2, s.emb_dim)
     assert 0 < np.abs(ref.wcls - full).max() < 0.05 * np.abs(full).max()
+    raw = gguf.load_fused(path)
+    assert np.array_equal(gguf.decode(raw.wcls, 14, s.emb_dim).reshape(ref.wcls.shape), ref.wcls)
 
 
 def test_loader_accepts_every_gguf_kv_type_and_spm_space(tools, gguf):

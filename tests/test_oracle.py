@@ -65,6 +65,30 @@ def test_oracle_matches_reference_at_full_tinyllama_size(tag, gguf):
     assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][:n][ok])
 
 
+def test_the_two_full_size_tinyllama_goldens_are_one_run():
+    """tests/golden/tinyllama-long.npz (2,048 positions, round 6) and tinyllama.npz (320, round 1) come from the same reference
+    binary on the same weights: their common positions must hold the same ids, top-8 and checksums, bit for bit."""
+    a, b = load_golden("tinyllama"), load_golden("tinyllama-long")
+    n = int(a["n"])
+    assert int(b["n"]) == 2048 and np.array_equal(a["tokens"], b["tokens"][:n])
+    for k in ("top8_idx", "top8_val", "probe_idx", "lsum", "l2", "absmax"):
+        assert np.array_equal(a[k], b[k][:n] if b[k].shape[0] == 2048 else b[k]), k
+
+
+@pytest.mark.skipif(not os.environ.get("LLMK_BIG_ORACLE"), reason="~10 minutes of 8 cores: LLMK_BIG_ORACLE=1")
+def test_oracle_matches_reference_over_the_whole_tinyllama_context(gguf):
+    """The oracle's own pin at long contexts and full size: all 2,048 positions of tests/golden/tinyllama-long.npz, teacher-forced
+    (the GPU tests replay the same golden on the device: test_parity_gpu.py)."""
+    g = load_golden("tinyllama-long")
+    fw = gguf.synth_fused(gguf.SHAPES["tinyllama"], int(g["seed"]))
+    n = int(os.environ.get("LLMK_BIG_ORACLE_N", g["n"]))
+    toks, logits = Oracle(fw, "omp").generate(n, prompt=g["tokens"][:n].tolist())
+    err = compact_err(logits, g, n)
+    assert err.max() <= 1e-5, (err.max(), int(np.argmax(err)))
+    ok = safe_positions(g, n)
+    assert np.array_equal((np.argmax(logits, axis=1) + 1)[ok], g["tokens"][:n][ok])
+
+
 @pytest.mark.skipif(not os.environ.get("LLMK_BIG_ORACLE"), reason="31 GB of host memory and ~3 minutes: LLMK_BIG_ORACLE=1")
 def test_oracle_matches_reference_at_full_llama2_7b_depth(gguf):
     """BASELINE.json configs[3] at FULL depth: tests/golden/llama2-7b.npz is the real reference (dims patched to Llama-2-7B)

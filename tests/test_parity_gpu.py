@@ -600,19 +600,117 @@ def test_opt_in_rms_epsilon_matches_the_oracle_with_the_same_epsilon(gguf):
         assert rel_err(l2, l0).max() > 100 * REL_TOL      # the epsilon really took effect
 
 
-def test_classifier_with_its_own_type_q6k_output_weight(gguf, tmp_path):
-    """A q4_0 file whose output.weight is q6_K (stock llama.cpp layout): the loader dequantises the classifier, the ctx
-    re-types LLMK_WCLS to f32 (llmk_set_tensor_type) and runs; checked against the oracle on the fully decoded weights."""
+@pytest.mark.parametrize("dequant", [False, True], ids=["raw-q6k-on-device", "host-dequantised"])
+def test_classifier_with_its_own_type_q6k_output_weight(dequant, gguf, tmp_path):
+    """A q4_0 file whose output.weight is q6_K (stock llama.cpp layout; the reference stops on it, read_ggml.f90:633-635).
+    Round 6: the raw super-blocks go to the device (LLMK_TYPE_Q6_K) and gemv_q6k_kernel dots them (csrc/q6k.h; K = 256 here: one
+    super-block per row, 4 of a wave's 64 lanes hold a quad); `dequant`: the round-2 form, the loader hands the classifier over as
+    f32.  Either way against the oracle on the fully decoded weights -- ggml's d * scale * (q - 32) is exact in f32."""
     s = gguf.LlamaShape(256, 512, 2, 4, 2, 320, 48)
     path = str(tmp_path / "q6k.gguf")
     gguf.write_gguf(path, gguf.synth_fused(s, 5, 2), output_q6k=True)
-    fw = gguf.load_fused(path)
-    assert fw.ggml_type == 2 and fw.cls_type == 0
+    fw = gguf.load_fused(path, dequant_cls=dequant)
+    assert fw.ggml_type == 2 and fw.cls_type == (0 if dequant else 14)
     n = 16
     ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
     m = llmk.Llmk(fw)
     _, l = m.generate(n, prompt=ot.tolist())
     assert rel_err(l, ol).max() <= REL_TOL
+    assert top8_elementwise(l, ref=ol).max() <= REL_TOL
     lg = m.prefill([2] + ot[:n - 1].tolist(), 1)
     assert rel_err(lg[None], ol[n - 1][None]).max() <= REL_TOL
     m.close()
+
+
+@pytest.mark.parametrize("E,V", [(512, 1000), (1024, 2048), (2048, 32000)])
+def test_q6k_classifier_rows_of_other_widths_match_oracle(E, V, gguf):
+    """gemv_q6k_kernel at row widths between one super-block and a full wave of quads (K = 512: 8 quads, 1024: 16, 2048: 32 of 64
+    lanes), V not a multiple of the block's 16 rows, f16 matrices beside the q6_K classifier (any matrix type may carry one)."""
+    s = gguf.LlamaShape(E, 2 * E, 1, E // 64, E // 128, V, 24)          # head size 64, GQA
+    fw = gguf.with_q6k_classifier(gguf.synth_fused(s, 11, 1))
+    assert fw.cls_type == 14
+    n = 8
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    m = llmk.Llmk(fw)
+    _, l = m.generate(n, prompt=ot.tolist())
+    m.close()
+    assert rel_err(l, ol).max() <= REL_TOL
+    assert top8_elementwise(l, ref=ol).max() <= REL_TOL
+
+
+def test_llama2_7b_column_geometry_q4_0_with_q6k_classifier_stays_on_the_persistent_kernel(gguf):
+    """Round-5 verdict, item 3 / missing 1: a STOCK llama.cpp Llama-2-7B Q4_0 file keeps output.weight in q6_K, and such a context
+    used to leave the persistent kernel (llmk_set_tensor_type retired it).  Now TkShape<..., WT_Q4_0, WT_Q6_K> dots the raw
+    super-blocks in the kernel's classifier phase (token_kernel.h TkQ6).  Real column geometry (E 4096: 64 quads = one per lane;
+    V 32000: 112 or 128 rows per CU), 2 layers, 96 positions against the oracle on the decoded weights; path() == 1; the
+    pipelined greedy instantiation; the multi-kernel path (gemv_q6k_kernel) and llmk_prefill (its last position's classifier)."""
+    s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 128)
+    fw = gguf.with_q6k_classifier(gguf.synth_fused(s, 7, 2))
+    n = 96
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    for flags in (0, llmk.FLAG_MULTI_KERNEL):
+        m = llmk.Llmk(fw, flags=flags)
+        assert m.path() == (1 if flags == 0 else 0), m.path_name()
+        _, l = m.generate(n, prompt=ot.tolist())
+        err = rel_err(l, ol)
+        assert err.max() <= REL_TOL, (flags, err.max(), int(np.argmax(err)))
+        e8 = top8_elementwise(l, ref=ol)
+        assert e8.max() <= REL_TOL, (flags, e8.max())
+        assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+        first_unsafe = int(np.argmin(safe)) if not safe.all() else n
+        if flags == 0 and first_unsafe > 8:
+            t3, _ = m.generate(first_unsafe, want_logits=False, greedy_on_device=True)
+            assert np.array_equal(t3, ot[:first_unsafe])
+            ids = (m.reset(), m.decode_greedy(2, 1, first_unsafe))[1]       # the pipelined loop: token_kernel<SH, true>
+            assert np.array_equal(ids, ot[:first_unsafe])
+        m.reset()
+        lg = m.prefill([2] + ot[:n - 1].tolist(), 1)
+        assert rel_err(lg[None], ol[n - 1][None]).max() <= REL_TOL
+        m.close()
+
+
+def test_llama2_7b_column_geometry_f16_runs_the_persistent_kernel_and_matches_oracle(gguf):
+    """Round-5 verdict, item 5 / missing 2: the persistent kernel for a shape beyond the compiled-in TinyLlama ones -- Llama-2-7B
+    with f16 matrices (TkLlama7BF16: K = E rows of 8 one-KB segments, one row per tile and a 64-register x fragment; K = H = 11008
+    rows END INSIDE their 22nd segment -- the staged hb vector is zero-padded to whole segments, token_kernel.h).  Real column
+    geometry, 2 layers, 300 positions (attention in 1..3 parts at head size 128) against the oracle on the decoded f16 weights;
+    path() == 1; the multi-kernel path beside it; the pipelined greedy instantiation."""
+    s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 320)
+    fw = gguf.synth_fused(s, 7, 1)
+    n = 300
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)
+    for flags in (0, llmk.FLAG_MULTI_KERNEL):
+        m = llmk.Llmk(fw, flags=flags)
+        assert m.path() == (1 if flags == 0 else 0), m.path_name()
+        _, l = m.generate(n, prompt=ot.tolist())
+        err = rel_err(l, ol)
+        assert err.max() <= REL_TOL, (flags, err.max(), int(np.argmax(err)))
+        e8 = top8_elementwise(l, ref=ol)
+        assert e8.max() <= REL_TOL, (flags, e8.max())
+        assert np.array_equal((np.argmax(l, axis=1) + 1)[safe], ot[safe])
+        first_unsafe = int(np.argmin(safe)) if not safe.all() else n
+        if flags == 0 and first_unsafe > 8:
+            m.reset()
+            ids = m.decode_greedy(2, 1, first_unsafe)
+            assert np.array_equal(ids, ot[:first_unsafe])
+        m.close()
+
+
+def test_tinyllama_q4_0_with_q6k_classifier_matches_oracle(gguf):
+    """The second q6_K instantiation: TinyLlama-1.1B q4_0 + q6_K classifier (E 2048: 32 quads, half of every wave's lanes idle in
+    the classifier phase), all 22 layers, 40 positions against the oracle on the decoded weights, on the persistent kernel."""
+    s = gguf.SHAPES["tinyllama"]
+    fw = gguf.with_q6k_classifier(gguf.synth_fused(s, 20260928, 2))
+    n = 40
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    m = llmk.Llmk(fw)
+    assert m.path() == 1
+    _, l = m.generate(n, prompt=ot.tolist())
+    m.close()
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    assert top8_elementwise(l, ref=ol).max() <= REL_TOL
