@@ -2,7 +2,7 @@
 // (/root/reference/llama2.f90:480-640) in ONE launch, one 8-wave workgroup per CU.
 //
 // Why: with one kernel per GEMV the token is bounded by ~1.55 us of boundary + ramp per launch
-// (5 launches per layer) -- the weight stream stops at every dependency.  Weights
+// (5 launches per layer; DESIGN.md / HISTORY.md section 3) -- the weight stream stops at every dependency.  Weights
 // do not depend on activations, so here the stream never stops: each of the 7 STREAMING waves of a CU
 // walks a static list of 8 KB row tiles (its share of qkv, wo, w1|w3, w2 of every layer, then the
 // classifier) and always has NB (TkShape::NB) tiles requested ahead in registers (non-temporal 16-byte loads),
@@ -23,11 +23,11 @@
 // TkShape); tile t of that range goes to streaming wave t % 7.  A tile is one row x up to 2048
 // columns; its wave-reduced partial dot goes to LDS and the service wave folds the parts of a row.
 // The x fragment a wave dots its tiles against is the same for every tile of a phase and lives in
-// registers (TkX).  DESIGN.md section 3b has the measurements behind each of these choices.
+// registers (TkX).  DESIGN.md / HISTORY.md section 3b has the measurements behind each of these choices.
 //
 // q4_0 matrices (round 5) take the same kernel with another kind of tile: a UNIT of 16 rows x 32 blocks in its own device layout,
 // dotted on the matrix core against an f16 image of x in LDS (q4_units.h), all EIGHT waves taking units and gathering an eighth
-// of every input vector each (TkShape::COOP, tk_step, tk_stream_coop); DESIGN.md section 3d.
+// of every input vector each (TkShape::COOP, tk_step, tk_stream_coop); DESIGN.md / HISTORY.md section 3d.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -271,7 +271,7 @@ struct TkShape {
     // COOP (q4_0): all eight waves gather the phase's input vector, one eighth each, and the units are requested from
     // inside the dot products (tk_step): a unit's dots take ~1.3 us, the loads' issue is spread through them instead of bursting
     // behind the exchange, and a wave that polls right after its phase has little of its own queued ahead of the poll -- the
-    // reason the f32 / f16 kernels keep a wave that never streams (section 3b of DESIGN.md) weighs less here than an 88 KB hb
+    // reason the f32 / f16 kernels keep a wave that never streams (section 3b of HISTORY.md) weighs less here than an 88 KB hb
     // sweep by ONE wave did (7.3 us per layer at 7B, round 2).
     // Measured for f16 too (round 2, ring depth 4): any vector gathered by the streaming waves loses -- hb only 1,710 tok/s,
     // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills

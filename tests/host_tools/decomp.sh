@@ -10,7 +10,7 @@ lib() { case $1 in base) echo "$PWD/llm.f90_amd/csrc/libllmk.so";; debug) echo "
 echo "# bench.py --no-cpu-baseline --steps 64 --warmup 8 $ARGS" | tee -a $OUT/decomp.txt
 for e in "$@"; do
   v=${e%%:*}; ns=""; [ "$e" != "$v" ] && ns=1
-  line=$(LLMK_LIB=$(lib $v) ${ns:+LLMK_TK_NOSYNC=1} timeout 400 python bench.py --no-cpu-baseline --steps 64 --warmup 8 $ARGS 2>/dev/null | tail -1)
+  line=$(env LLMK_LIB=$(lib $v) ${ns:+LLMK_TK_NOSYNC=1} timeout 400 python bench.py --no-cpu-baseline --steps 64 --warmup 8 $ARGS 2>/dev/null | tail -1)
   python - "$e" "$line" <<'PY' | tee -a $OUT/decomp.txt
 import json, sys
 try:
