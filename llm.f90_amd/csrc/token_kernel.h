@@ -42,8 +42,11 @@
 // 44 loads per lane: 32 -> two pieces of 22.  Round-3 sweep (profiles/r03_gather_piece_sweep.jsonl, kernel us, f16 / f32):
 // one piece of 44: 570 / 723; 22+22: 556 / 719; 15+15+14: 555 / 717 (spills 20 bytes in the f32 kernel); 4 x 11: 553 / 738;
 // 6 x 8: 561 / 743; E-vectors in pieces of 8: 563 / 724.  Nothing beats two pieces by more than the box-to-box noise.
+// Round 6, with the sweeps led by "gather first" (a first pass practically never fails now: passes mean 1.0 in the traces): ONE piece
+// of 44 for f32 -- 1,470.7-1,482.6 against 1,447.4-1,471.7 tok/s, four interleaved rounds on one box (profiles/r06_ab.txt) -- while f16
+// keeps two (2,046-2,061 against 2,074-2,105 with one).  -1 = these per-type defaults (TkShape::HB_NL).
 #ifndef LLMK_TK_HB_NL
-#define LLMK_TK_HB_NL 32
+#define LLMK_TK_HB_NL -1
 #endif
 // the same for the E-vectors x / xa (rmsnorm gains are held across these) and xb
 #ifndef LLMK_TK_E_NL
@@ -97,6 +100,9 @@
 #ifndef LLMK_TK_GF_DELAY
 #define LLMK_TK_GF_DELAY -1
 #endif
+// (round 6, measured and removed: the residual-stream gathers staging x * gains in the pass that delivers them -- tk_coop_part on the
+// service wave instead of tk_gather + TkNorm::apply: f16 2,005 against 2,090 tok/s, f32 1,433 against 1,465; csrc/variants/
+// fused_norm_gather.patch, profiles/r06_ab.txt)
 #ifndef LLMK_TK_ATT_SPLIT
 #define LLMK_TK_ATT_SPLIT 1          // contexts longer than 256 timesteps: a head's attention in parts on the CUs of its group (TkAttPlan)
 #endif
@@ -277,6 +283,7 @@ struct TkShape {
     // xb only 1,787, all four 1,631, against 1,855 with the service wave alone.  So does holding back the late refills
     // that the next phase does not need until its input vector has been gathered (1,675).
     static constexpr bool COOP = Q4;
+    static constexpr int HB_NL = LLMK_TK_HB_NL > 0 ? LLMK_TK_HB_NL : (WT == WT_F32 ? 44 : 32);      // loads per lane in flight in one pass of the hb gather
     // "gather first" (LLMK_TK_GF): tiles per wave a phase's refill burst issues before the next sweep is in the pipeline, and
     // s_sleep units the service wave lets the producers have before the first pass of the x / xa / hb sweeps
     static constexpr int EARLY_A = LLMK_TK_EARLY_A >= 0 ? LLMK_TK_EARLY_A : (WT == WT_F16 ? 1 : 0);
@@ -1618,7 +1625,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         }
         else {
             if constexpr (GF && SH::GF_DELAY > 0) __builtin_amdgcn_s_sleep(SH::GF_DELAY);
-            ok = tk_gather<SH::H, TR_H, LLMK_TK_HB_NL, SH::GF_LAST>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr, gflag, 4 * l + 3) && ok;
+            ok = tk_gather<SH::H, TR_H, SH::HB_NL, SH::GF_LAST>(tk_g_hb<SH>(a), e_a, xs, a.err, lane, nosync, (tr && l < 32) ? tr + (32 + l) * 16 + 6 : nullptr, gflag, 4 * l + 3) && ok;
         }
         TK_STAMP(12);
         tk_barrier();
