@@ -242,6 +242,16 @@ def dequantize_q6_K(raw: np.ndarray, cols: int) -> np.ndarray:
     return y.reshape(*raw.shape[:-1], cols)
 
 
+def scale_q4_0(raw: np.ndarray, factor: float) -> np.ndarray:
+    """q4_0 rows with every block scale d multiplied by `factor` (rounded to f16 -- the result is a q4_0 tensor like any other: what
+    the tests use to build models whose intermediate activations are small or large while the logits stay O(1))."""
+    b = np.array(raw, dtype=np.uint8, copy=True)
+    blk = b.reshape(-1, Q4_0_BLOCK_BYTES)
+    d = blk[:, 0:2].copy().view(np.float16).astype(np.float32) * np.float32(factor)
+    blk[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    return b
+
+
 def encode(w: np.ndarray, ggml_type: int) -> np.ndarray:
     if ggml_type == GGML_F32:
         return np.ascontiguousarray(w, dtype="<f4")

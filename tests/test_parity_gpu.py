@@ -495,6 +495,80 @@ def test_llama2_7b_q4_0_activation_beyond_f16_falls_back_to_the_multi_kernel_pat
     assert b"beyond the f16 range" in r.stderr and b"multi-kernel path" in r.stderr
 
 
+def test_llama2_7b_q4_0_small_attention_and_ffn_activations_keep_their_precision(gguf):
+    """Advisor, round 5 (medium): the q4_0 persistent kernel wrote the xb (attention output) and hb (SwiGLU output) images of x
+    UNSCALED, so real-model activations of 1e-2 .. 1e-3 sat where the lo piece of the f16 hi | lo pair is a subnormal: an absolute
+    floor of 2^-20 per element under a high nibble, 1e-4 .. 1e-3 of such values.  The synthetic weights keep every activation O(1)
+    and never went there.  Here the V rows and the up rows carry 2^-7 in their block scales and wo / w2 carry 2^7: xb and hb are
+    ~1e-2 .. 1e-3 while the residual stream and the logits are what they were.  Round 6 scales those images by a per-vector power of
+    two (token_kernel.h TK_XSC_B / _H): persistent kernel within 1e-4 of the oracle on the decoded weights, top-8 element-wise."""
+    s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 64)
+    fw = gguf.synth_fused(s, 7, 2)
+    E, KV, H = s.emb_dim, s.kv_dim, s.hidden_dim
+    k = 2.0 ** -7
+    fw.wqkv = fw.wqkv.copy(); fw.wo = gguf.scale_q4_0(fw.wo, 1 / k)
+    fw.wqkv[:, E + KV:] = gguf.scale_q4_0(fw.wqkv[:, E + KV:], k)               # V rows
+    fw.w13 = fw.w13.copy(); fw.w2 = gguf.scale_q4_0(fw.w2, 1 / k)
+    fw.w13[:, H:] = gguf.scale_q4_0(fw.w13[:, H:], k)                           # up rows
+    n = 40
+    o = Oracle(fw.as_f32(), "omp")
+    ot, ol = o.generate(n)
+    m = llmk.Llmk(fw)
+    assert m.path() == 1
+    _, l = m.generate(n, prompt=ot.tolist())
+    assert m.path() == 1                                 # nothing left the f16 range: no position was redone elsewhere
+    m.close()
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    e8 = top8_elementwise(l, ref=ol)
+    assert e8.max() <= REL_TOL, (e8.max(), int(np.argmax(e8)))
+
+
+def test_llama2_7b_q4_0_one_position_beyond_f16_is_redone_alone_and_the_kernel_stays(gguf):
+    """Advisor, round 5 (low): ONE activation outside the f16 range used to retire the persistent kernel for the context (a third of
+    the rate gone for the rest of the session).  Everything behind an rmsnorm is scale-invariant per position, so a single position
+    can only leave the range through a DIRECTION: here layer 0's first gate row and first up row read column 5 alone (6.3 x[5]), and
+    one token's embedding row has 60 there (the others: |x| < 1): its hb[0] = silu(g) u is ~1e5 where every other token's is < 130 --
+    beyond what layer 0's hb image holds (largest element assumed in [1, 2): 2^9 of head room).  Fed at the last position: that
+    position is redone on the multi-kernel path, path() stays 1, every position carries the oracle's logits, the message appears
+    once, and the next sequence runs on the persistent kernel without an event."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import llm_f90_amd\n"
+        "from llm_f90_amd import llmk\n"
+        "from llm_f90_amd.tools import gguf\n"
+        "from oracle.oracle import Oracle\n"
+        "from conftest import rel_err, REL_TOL\n"
+        "s = gguf.LlamaShape(4096, 11008, 2, 32, 32, 32000, 64)\n"
+        "fw = gguf.synth_fused(s, 7, 2)\n"
+        "fw.token_embedding_table = fw.token_embedding_table.copy(); fw.token_embedding_table[776, 5] = np.float32(60.0)\n"
+        "row = np.zeros(s.emb_dim // 32 * 18, np.uint8).reshape(-1, 18); row[:, 2:] = 0x88\n"      # every block: scale 0, nibbles 8 (= 0)
+        "row[0, 0:2] = np.array([0.9], np.float16).view(np.uint8); row[0, 2 + 5] = 0x8F\n"          # block 0: d = 0.9, element 5 = +7 -> 6.3
+        "fw.w13 = fw.w13.copy(); fw.w13[0, 0] = row.reshape(-1); fw.w13[0, s.hidden_dim] = row.reshape(-1)\n"
+        "n = 8\n"
+        "prompt = [5, 9, 12, 31, 44, 8, 777]\n"             # 1-based ids: token 777 (row 776) is fed at position 8, the last one
+        "o = Oracle(fw.as_f32(), 'omp')\n"
+        "ot, ol = o.generate(n, prompt=prompt)\n"
+        "assert np.all(np.isfinite(ol))\n"
+        "m = llmk.Llmk(fw)\n"
+        "assert m.path() == 1\n"
+        "_, l = m.generate(n, prompt=prompt)\n"
+        "assert m.path() == 1, 'the kernel was retired'\n"
+        "assert rel_err(l, ol).max() <= REL_TOL, rel_err(l, ol)\n"
+        "ot2, ol2 = o.generate(6, prompt=prompt[:5])\n"
+        "_, l2 = m.generate(6, prompt=prompt[:5])\n"            # the next sequence: the persistent kernel, no event
+        "assert rel_err(l2, ol2).max() <= REL_TOL and m.path() == 1 and m.time_kernel(6, 1)[0] > 0\n"
+        "print('KEPT-OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"KEPT-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stderr.count(b"redone on the multi-kernel path, the kernel stays in use") == 1, r.stderr[-1500:]
+
+
 @pytest.fixture(scope="module")
 def llama7b_q4_blocks(gguf):
     """the 3.7 GB of q4_0 blocks tests/golden/llama2-7b.npz was generated from (every block its own scale, some negative)"""
