@@ -487,7 +487,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": f"token_kernel<{a.shape}, {a.type}> (persistent whole-token pass: "
                                                          f"{shape.n_layers} layers + classifier)",
                                "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("token_kernel", a.shape, a.type),
+                               "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("token_kernel", a.shape, a.type + ("_q6k" if a.cls_q6k else "")),
                                "bytes_per_launch": b, "us_per_launch": ms * 1000,
                                "note": f"bytes_per_launch = algorithmic bytes of one token at KV length {W + K}"}
         except llmk.LlmkError:

@@ -76,6 +76,9 @@ job_prof() {
   timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/tinyllama_f32_bench_driver_workload.json 2>/dev/null; cut -c1-400 $OUT/tinyllama_f32_bench_driver_workload.json
   run_cfg tinyllama_f16 --no-cpu-baseline --type f16
   run_cfg llama2-7b_q4_0 --no-cpu-baseline --shape llama2-7b --type q4_0
+  # round 6: a stock llama.cpp Q4_0 file's layout (q6_K classifier rows on the device), and Llama-2-7B f16 on the persistent kernel
+  run_cfg llama2-7b_q4_0_q6k --no-cpu-baseline --shape llama2-7b --type q4_0 --cls-q6k
+  run_cfg llama2-7b_f16 --no-cpu-baseline --shape llama2-7b --type f16
   echo "=== 70B rank kernels"; job_rank
   job_pfprof
   echo "=== KV-length curve"

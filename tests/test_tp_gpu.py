@@ -84,6 +84,26 @@ def test_virtual_ranks_quantised_match_oracle(wtype, gguf):
         m.close()
 
 
+def test_virtual_ranks_with_a_q6k_classifier_match_oracle(gguf):
+    """A stock llama.cpp q4_0 file's layout on a tensor-parallel context (round 6): the classifier's raw q6_K super-blocks are split
+    by vocabulary rows like every other classifier (llmk_upload on a rank keeps its V / P rows), each rank's gemv_q6k_kernel writes
+    its slice of the logits.  E = 512: two super-blocks per row."""
+    s = gguf.LlamaShape(512, 1024, 2, 4, 4, 640, 32)
+    fw = gguf.with_q6k_classifier(gguf.synth_fused(s, 99, 2))
+    assert fw.cls_type == 14
+    P = 2
+    ranks = [llmk.Llmk(fw, tp_rank=r, tp_size=P) for r in range(P)]
+    n = 8
+    toks, logits = tp_generate(ranks, n, s)
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    assert rel_err(logits, ol).max() <= REL_TOL
+    margin = np.sort(ol, axis=1)
+    safe = (margin[:, -1] - margin[:, -2]) > 4 * REL_TOL * np.abs(ol).max()
+    assert np.array_equal(toks[safe], ot[safe])
+    for m in ranks:
+        m.close()
+
+
 def test_ranks_fed_only_their_own_rows_hold_the_same_shards(gguf):
     """llmk_upload_rows on a tensor-parallel ctx takes row numbers of the FULL tensor and keeps the part its shard holds:
     a rank handed only its own rows (what host/gguf_loader.f90 stream_ggml_weights reads from the file), in pieces, ends
