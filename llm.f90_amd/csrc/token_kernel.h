@@ -1688,6 +1688,10 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
         tk_wave_argmax(bv, bi);
         if (lane == 0) tk_cand(a, pos & 1)[c] = make_float2(bv, __int_as_float(bi));
     }
+    // q4_0: any of the CU's eight waves may have raised the word (an image slice beyond the f16 range: tk_coop_part) -- the streaming
+    // waves' gathers have no other way to tell this wave, and until round 6 an event in ANOTHER wave's slice never reached the host's
+    // copy of the word (direct mode): NaN logits returned as an answer.  All of this CU's gathers lie behind the barrier above.
+    if constexpr (SH::Q4) { if (ok && lane == 0 && !nosync) ok = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; }
     if (!ok && lane == 0) {
         const unsigned cause = atomicOr(a.err, 0x1000u);      // (what the first failing wave left there: a timed-out spin's code, 0x4000 ...)
         if (a.herr) __hip_atomic_store(a.herr, cause | 0x1000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -788,3 +788,23 @@ def test_tinyllama_q4_0_with_q6k_classifier_matches_oracle(gguf):
     err = rel_err(l, ol)
     assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
     assert top8_elementwise(l, ref=ol).max() <= REL_TOL
+
+
+def test_a_shape_added_at_build_time_runs_the_persistent_kernel_and_matches_oracle(gguf):
+    """`make TK_SHAPES="4096,14336,32,8,32000,WT_F16"` (the Makefile's own example: Mistral-7B's geometry -- grouped-query
+    attention at head size 128, K = H rows of 28 segments) adds a persistent-kernel instantiation without touching a source file.
+    Runs when the loaded library lists that shape (LLMK_LIB=... of such a build; the product build does not: skipped): 2 layers, 300
+    positions against the oracle on the decoded f16 weights, path() == 1."""
+    if (4096, 14336, 32, 8, 32000, "f16") not in llmk.tk_shapes():
+        pytest.skip("this build of libllmk.so has no persistent kernel for 4096,14336,32,8,32000,f16 (make TK_SHAPES=...)")
+    s = gguf.LlamaShape(4096, 14336, 2, 32, 8, 32000, 320)
+    fw = gguf.synth_fused(s, 7, 1)
+    n = 300
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    m = llmk.Llmk(fw)
+    assert m.path() == 1, m.path_name()
+    _, l = m.generate(n, prompt=ot.tolist())
+    m.close()
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
+    assert top8_elementwise(l, ref=ol).max() <= REL_TOL
