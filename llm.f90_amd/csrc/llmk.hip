@@ -49,7 +49,10 @@ template <class T>
 hipError_t dev_alloc(T** p, size_t bytes) {
     static const bool poison = getenv("LLMK_POISON") && getenv("LLMK_POISON")[0] == '1';
     hipError_t e = hipMalloc((void**)p, bytes);
-    if (e == hipSuccess && poison) e = hipMemset(*p, 0xFF, bytes);
+    // (the fill runs on the null stream and hipMemset of device memory need not block the host; the shim's own initialisation often
+    // goes to the ctx's NON-BLOCKING stream, which the null stream does not order: without the wait the fill could land AFTER it --
+    // round 6's poison run: the self-test's mismatch counter read 0xFFFFFFFF on three ranks)
+    if (e == hipSuccess && poison) { e = hipMemset(*p, 0xFF, bytes); if (e == hipSuccess) e = hipDeviceSynchronize(); }
     return e;
 }
 
@@ -115,6 +118,7 @@ struct llmk_ctx {
     float4* d_zeros = nullptr;
     unsigned long long* d_trace = nullptr;  // debug stamps (LLMK_TK_TRACE=1)
     size_t tk_lds = 0;
+    size_t tk_ngran = 0;   // granules in d_gran (the last 4 * TK_QSC_LMAX: the q4_0 kernels' per-layer scale records)
     // pipelined greedy decode (llmk_decode_greedy): per-CU classifier maxima of the last two launches, and the ids as they
     // are resolved (host-mapped; 0 = not there yet)
     // (the candidates sit behind the device error word, the ids behind the host error word: token_kernel.h tk_cand)
@@ -465,7 +469,10 @@ int tk_setup(llmk_ctx* c, int id) {
     HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, token_kernel<TK>, TK_THREADS, c->tk_lds));
     if (per_cu < 1 || (long long)per_cu * c->n_cu < TK_NCU) return LLMK_OK;
     // qkv | xb | xa | hb | x | per head: the (PMAX - 1) other parts of a long context's attention (HS values + maximum + sum each)
-    const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H + (size_t)TK::NH * (TkAttPlan<TK>::PMAX - 1) * (TK::HS + 2);
+    // (+ 4 granule slots per layer behind them (two buffers by position parity): the q4_0 kernels' per-layer records of the previous position's largest xb / hb elements,
+    // token_kernel.h tk_qsc; cleared by llmk_reset)
+    const size_t ngran = (size_t)TK::QKV + 3 * (size_t)TK::E + TK::H + (size_t)TK::NH * (TkAttPlan<TK>::PMAX - 1) * (TK::HS + 2) + 4 * (size_t)TK_QSC_LMAX;
+    c->tk_ngran = ngran;
     if (!c->d_gran) HIPCHK(dev_alloc(&c->d_gran, ngran * sizeof(unsigned long long)));      // (kept over a re-type of the classifier: same shape)
     if (!c->d_zeros) HIPCHK(dev_alloc(&c->d_zeros, (size_t)TK_NCU * TK_WAVES * 1024));
     if (TK_DEBUG && getenv("LLMK_TK_TRACE")) HIPCHK(dev_alloc(&c->d_trace, (size_t)TK_NCU * TK_TRACE_N * 8));   // libllmk_debug.so only
@@ -1686,6 +1693,8 @@ int llmk_reset(llmk_ctx* c) {
     HIPCHK(hipMemsetAsync(c->d_kc, 0, kvn, c->stream));
     HIPCHK(hipMemsetAsync(c->d_vc, 0, kvn, c->stream));
     HIPCHK(hipMemsetAsync(c->d_logits + c->V, 0, sizeof(float), c->stream));   // the token kernel's sticky error word
+    if (c->d_gran && c->tk_ngran)      // a new sequence: no position before it (the q4_0 kernels' scale records, token_kernel.h tk_qsc)
+        HIPCHK(hipMemsetAsync(c->d_gran + c->tk_ngran - 4 * TK_QSC_LMAX, 0, 4 * TK_QSC_LMAX * sizeof(unsigned long long), c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     reinterpret_cast<unsigned*>(c->h_logits)[c->V] = 0;
     c->h_next[1] = 0;
@@ -1835,6 +1844,10 @@ int llmk_peek(llmk_ctx* c, int which, int layer, int pos, float* out, int n) {
 #ifdef LLMK_PF_TRACE
         case 7: src = c->pf[0].HB; len = PF_TMAX * c->H; break;
 #endif
+        case 8:  // the q4_0 persistent kernels' per-layer scale records (token_kernel.h tk_qsc): [2 buffers][TK_QSC_LMAX] x {|xb|, |hb|, pos, pos}
+            if (!c->d_gran || !c->tk_ngran) return LLMK_E_ARG;
+            src = reinterpret_cast<const float*>(c->d_gran + c->tk_ngran - 4 * TK_QSC_LMAX); len = 8 * TK_QSC_LMAX;
+            break;
         case 6:  // debug: raw trace stamps reinterpret as floats (2 per stamp)
             if (!c->d_trace) return LLMK_E_ARG;
             src = (const float*)c->d_trace; len = TK_NCU * TK_TRACE_N * 2;

@@ -48,6 +48,9 @@ constexpr int Q16_ROWS = 16, Q16_BLOCKS = 32, Q16_UNIT_BYTES = 9216, Q16_W_BYTES
 constexpr int Q16_IMG_BLK = 128;          // image bytes per block: 4 k groups x 8 halves of hi, then of lo
 constexpr int Q16_ZERO_BYTES = 4096;      // a column that holds no block reads here: group offsets up to 3 x 1 KB + 16
 constexpr float Q16_RESCALE = 16777216.0f;
+// the blocks' sums of x sit in the image as sum / 32: |sum / 32| <= the block's largest |element|, so whatever range the elements
+// fit (the gathers' power-of-two scaling, token_kernel.h) the sums fit too; the -8 d sum(x) term is then -256 d (sum / 32)
+constexpr float Q16_SUM_DIV = 32.0f;
 
 typedef _Float16 q16_v8h __attribute__((ext_vector_type(8)));
 typedef float q16_v4f __attribute__((ext_vector_type(4)));
@@ -199,8 +202,9 @@ __device__ __forceinline__ float q16_row_sum(float v) {
 }
 // the unit's 16 row sums sum_b d (sum n x - 8 sum x) -> part[0..15] (row 4 g + j by lane (n = j, g))
 __device__ __forceinline__ void q16_unit_store(const q16_v4f& acc, const q16_v4f& acc8, float* part, int lane) {
-    const float y0 = q16_row_sum(fmaf(acc.x, Q16_RESCALE, -8.0f * acc8.x)), y1 = q16_row_sum(fmaf(acc.y, Q16_RESCALE, -8.0f * acc8.y));
-    const float y2 = q16_row_sum(fmaf(acc.z, Q16_RESCALE, -8.0f * acc8.z)), y3 = q16_row_sum(fmaf(acc.w, Q16_RESCALE, -8.0f * acc8.w));
+    constexpr float M8 = -8.0f * Q16_SUM_DIV;
+    const float y0 = q16_row_sum(fmaf(acc.x, Q16_RESCALE, M8 * acc8.x)), y1 = q16_row_sum(fmaf(acc.y, Q16_RESCALE, M8 * acc8.y));
+    const float y2 = q16_row_sum(fmaf(acc.z, Q16_RESCALE, M8 * acc8.z)), y3 = q16_row_sum(fmaf(acc.w, Q16_RESCALE, M8 * acc8.w));
     const int n = lane & 15;
     const float y = n == 0 ? y0 : n == 1 ? y1 : n == 2 ? y2 : y3;
     if (n < 4) part[4 * (lane >> 4) + n] = y;

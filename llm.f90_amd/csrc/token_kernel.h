@@ -379,8 +379,10 @@ struct TkLds {
     static constexpr int ATT_RED = ATT_Q + 3 * SH::HS * 4;                 // [16 waves][HS/4] float4
     static constexpr int ATT_R4 = ATT_RED + TK_WAVES * (256 / SH::HS) * SH::HS * 4;   // [waves][TPW][HS/4] float4
     static constexpr int RED8 = ATT_R4;                                    // COOP: the eight waves' partial sums of x^2 (32 of the 64 bytes)
-    // (q4_0: 256 bytes -- the scales and per-wave maxima of the xb / hb images sit behind the partial sums: TK_XSC_B ...)
-    static constexpr int ROPE = ATT_R4 + (SH::Q4 ? 256 : 64);              // cos[HS/2] | sin[HS/2] of pos*freq
+    // (q4_0: 256 bytes -- the scales and per-wave maxima of the xb / hb images sit behind the partial sums: TK_XSC_B ... -- and behind
+    // them the per-layer records of the previous position's largest xb / hb elements: TK_QSC_LMAX x 16 bytes, tk_qsc)
+    static constexpr int QSC = RED8 + 256;
+    static constexpr int ROPE = ATT_R4 + (SH::Q4 ? 256 + 128 * 16 : 64);   // cos[HS/2] | sin[HS/2] of pos*freq
     static constexpr int ATT_P = ROPE + SH::HS * 4;                        // [waves][32] softmax weights of the wave's own timesteps
     static constexpr int ATT_S = ATT_P + TK_WAVES * 32 * 4;                // scores [S], then exp(score - max) [S]
 };
@@ -534,18 +536,61 @@ constexpr int TK_XSC = 12;      // red8[TK_XSC]: that power of two (q4_0), next 
 // assumed in [1, 2)).  red8[TK_XSC_B / _H]: the scale in force; red8[TK_AMX_B / _H + w]: wave w's largest |scaled element| of the image
 // it has just written (every wave writes one eighth).  The service wave divides the row sums by the scale (exactly) and sets the
 // next layer's from the eight maxima behind the phase's second barrier.  A vector that still does not fit raises 0x4000 as before.
+// ACROSS POSITIONS (round 6, second step): the layer before is a poor predictor where a model's activations jump between layers and
+// stay put between tokens (Llama-2's down-projection inputs of layers 1 and 30 are hundreds of times their neighbours') -- a vector
+// 2^9 above its predecessor would raise 0x4000 at EVERY position and retire the kernel after four.  So each launch leaves, per layer,
+// the largest |element| of its xb and hb vectors with its position (tk_qsc: 16 bytes per layer behind the exchange granules, written
+// by CU 1 -- every CU computes the same numbers), and the next launch, if it is the NEXT position, scales layer l's images from
+// layer l's record of the position before; the layer-before rule is the fallback (position 1, the position after a prefill or a redo).
 constexpr int TK_XSC_B = 16, TK_XSC_H = 17, TK_AMX_B = 24, TK_AMX_H = 32;
+constexpr int TK_EVT = 40;             // red8[TK_EVT] (as unsigned): the first range event THIS workgroup met or heard of, 0 = none (tk_rec_ok)
+constexpr int TK_QSC_LMAX = 128;        // layers with a record (deeper models: the layer-before rule beyond)
 constexpr float TK_IMG_TARGET = 64.f;
-__device__ __forceinline__ float tk_next_scale(float cur, const float* amx8) {
+// the largest |element| of the image just written, as it is (cur = the power of two it was scaled with: the division is exact)
+__device__ __forceinline__ float tk_amax_true(float cur, const float* amx8) {
     const float4 a = reinterpret_cast<const float4*>(amx8)[0], b = reinterpret_cast<const float4*>(amx8)[1];      // (two 16-byte LDS reads)
-    float m = fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
-    m = m / cur;                                      // (a power of two: exact) the largest |element| as it is
-    return (m > 0.f && m < 3.0e38f) ? tk_pow2_inv(m * (1.f / TK_IMG_TARGET)) : cur;
+    return fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))) / cur;
+}
+__device__ __forceinline__ float tk_scale_for(float amax, float fallback) {
+    return (amax > 0.f && amax < 3.0e38f) ? tk_pow2_inv(amax * (1.f / TK_IMG_TARGET)) : fallback;
+}
+// record of layer l: {largest |xb|, largest |hb|, position that wrote .x, position that wrote .y} (positions as int bits).  Two
+// buffers by position parity: a launch reads the one the position before wrote and writes its own -- no workgroup can meet a record
+// of its own launch, however late it starts (the choice of scale must not depend on timing: reruns are bit-identical)
+template <class SH>
+__device__ __forceinline__ float4* tk_qsc(const TokenArgs& a, int pos) {
+    constexpr size_t NG = (size_t)SH::QKV + 3 * (size_t)SH::E + SH::H + (size_t)SH::NH * ((TK_NCU / SH::NH < 8 ? TK_NCU / SH::NH : 8) - 1) * (SH::HS + 2);
+    return reinterpret_cast<float4*>(a.g_qkv + NG) + (pos & 1) * TK_QSC_LMAX;
+}
+// Two predictions of the next image's largest |element|: this token's vector of the layer before (`now`), the same layer's vector
+// of the position before (`hist`, 0 = none).  Models differ in which one jumps -- between LAYERS (Llama-2's massive activations: the
+// history is right, the layer before 2^11 off) or between TOKENS (the bench's synthetic 7B weights: hb is ~1 or ~92 by token, the layer
+// before is right) -- and an image holds 2^9 above its target and full precision 2^6 below: the GEOMETRIC MEAN halves the exponent
+// of whichever is wrong (measured round 6: the maximum of the two lost 1.2e-4 on the layer behind a jump, either alone lost the kernel
+// or a position per jump)
+__device__ __forceinline__ float tk_predict(float now, float hist) { return hist > 0.f ? sqrtf(now * hist) : now; }
+// may the vector gathered under `epoch` leave its record?  Yes while the sticky word is clear, and when it is THIS gather's own range event
+// (decided on the workgroup's own LDS word, set by the waves that met the event or gave up on hearing of it, in front of the barrier this
+// is read behind: the device word is stored by other waves without an order against this load, and later gathers over the debris overwrite it)
+__device__ __forceinline__ bool tk_rec_ok(const float* red8, unsigned epoch) {
+    const unsigned e = reinterpret_cast<const unsigned*>(red8)[TK_EVT];
+    return e == 0 || e == (0x4000u | (epoch & 0xffu));
+}
+__device__ __forceinline__ void tk_evt_note(unsigned* evt, unsigned epoch, int lane) {
+    if (evt && lane == 0 && *evt == 0) *evt = 0x4000u | (epoch & 0xffu);
+}
+// the largest |element| layer l's vector KIND (0 xb, 1 hb) had at the position before (0 when that position left no record)
+__device__ __forceinline__ float tk_hist_amax(const float4* qsc_lds, int l, int L, int kind, int pos) {
+    if (l >= L || l >= TK_QSC_LMAX) return 0.f;
+    const float4 r = qsc_lds[l];
+    const int tag = __float_as_int(kind ? r.w : r.z);
+    const float v = kind ? r.y : r.x;
+    return (tag == pos - 1 && v > 0.f && v < 3.0e38f) ? v : 0.f;
 }
 template <int NLW, int NBP, bool NORM>
 __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int first_pair, unsigned epoch, float* xraw, float* xs,
                                              const float* __restrict__ gains, float* ss, unsigned* err, int lane, bool nowait, float psc = 1.f,
-                                             float* amx = nullptr) {
+                                             float* amx = nullptr, unsigned* evt = nullptr) {
     if constexpr (NLW == 0) { if (amx && lane == 0) *amx = 0.f; return true; }
     else {
         float2 gn[NORM ? NLW : 1];
@@ -562,7 +607,6 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
         char* ip = reinterpret_cast<char*>(xs) + (NBP > 0 ? q16_pair_off(e0) : 0);
         const float isc = NBP > 0 ? q16_pair_scale(e0) : 1.f;
         float amax = 0.f;               // NBP > 0: the largest |value| written as an f16 hi piece (65504 is the end of that format)
-        float smax = 0.f;               //          and the largest |block sum| (they go through the matrix core as f16 pieces too)
         char* sp = reinterpret_cast<char*>(xs) + (NBP > 0 ? Q16Img<(NBP > 0 ? NBP : 32)>::SUM + (e0 >> 5) * 2 : 0);
         for (unsigned spin = 0;; ++spin) {
             tk_v4u r[NLW];
@@ -588,8 +632,9 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                         amax = fmaxf(amax, fmaxf(fabsf(y0), fabsf(y1)));
                         q16_put2(ip + k * (4 * Q16_IMG_BLK), isc, y0, y1);
                         const float bs = row16_sum(y0 + y1);             // a load's 64 lanes hold 4 whole blocks, one per DPP row
-                        if ((lane & 15) == 15) q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs);
-                        smax = fmaxf(smax, fabsf(bs));      // (every lane: the other lanes' partial sums only make the check stricter)
+                        // (the sum is held as sum / 32 -- never above the block's largest element, so it needs no head room of its own:
+                        // q4_units.h Q16_SUM_DIV; written whole, 32 coherent elements of 2^12 overflowed where none of them did)
+                        if ((lane & 15) == 15) q16_put_sum<(NBP > 0 ? NBP : 32)>(sp + k * 8, bs * (1.0f / Q16_SUM_DIV));
                     } else {
                         *reinterpret_cast<float2*>(xs + e0 + k * 2 * WAVE) = make_float2(y0, y1);
                     }
@@ -599,17 +644,20 @@ __device__ __forceinline__ bool tk_coop_part(__amdgpu_buffer_rsrc_t rs, int firs
                     // an activation beyond the f16 range (or not finite): the image is useless -- raise the sticky word, the host retires
                     // the kernel for this context and redoes the position on the multi-kernel path (f32 throughout)
                     if (amx) { const float wm = wave_max(amax); if (lane == 0) *amx = wm; }
-                    if (!nowait && __any(!(fmaxf(amax, smax) < 60000.f))) {
+                    if (!nowait && __any(!(amax < 60000.f))) {
                         if (lane == 0) __hip_atomic_store(err, 0x4000u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tk_evt_note(evt, epoch, lane);
                         return false;
                     }
                 }
                 return true;
             }
             if ((spin & 63) == 63) {
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+                // (a range event another workgroup met in this very vector -- all of them read the same one; anything else ends the launch)
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { tk_evt_note(evt, epoch, lane); return false; }
                 if (spin > TK_SPIN_LIMIT) {
                     if (lane == 0) __hip_atomic_store(err, 0x400u + (epoch & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tk_evt_note(evt, epoch, lane);
                     return false;
                 }
             }
@@ -630,8 +678,9 @@ __device__ __forceinline__ bool tk_coop_gather(const unsigned long long* g, unsi
     static_assert(KIND == 0 || (!NORM && NBP > 0), "scaled xb / hb images are the q4_0 kernels'");
     const float psc = NBP > 0 ? (NORM ? red8[TK_XSC] : KIND == 1 ? red8[TK_XSC_B] : KIND == 2 ? red8[TK_XSC_H] : 1.f) : 1.f;   // q4_0: see tk_pow2_inv, TK_XSC_B
     float* amx = KIND == 0 ? nullptr : red8 + (KIND == 1 ? TK_AMX_B : TK_AMX_H) + w;
-    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc, amx);
-    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc, amx);
+    unsigned* evt = NBP > 0 ? reinterpret_cast<unsigned*>(red8) + TK_EVT : nullptr;
+    if (w < X) ok = tk_coop_part<B + 1, NBP, NORM>(rs, w * (B + 1) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc, amx, evt);
+    else ok = tk_coop_part<B, NBP, NORM>(rs, (X * (B + 1) + (w - X) * B) * WAVE, epoch, xraw, xs, gains, &ss, err, lane, nowait, psc, amx, evt);
     if constexpr (NORM) {
         ss = wave_sum(ss);
         if (lane == 0) red8[w] = ss;
@@ -1302,7 +1351,7 @@ __device__ __forceinline__ float tk_stage_q16(const float* __restrict__ row, con
             bs += dpp_mov<0xB1, 0xf, true>(0.f, bs);
             bs += dpp_mov<0x4E, 0xf, true>(0.f, bs);
             bs += dpp_mov<0x114, 0xf, true>(0.f, bs);               // row_shr:4: lanes 4..7 / 12..15 hold their block's sum
-            if ((lane & 7) == 7) { q16_put_sum<SH::NBI>(reinterpret_cast<char*>(xs) + Q16Img<SH::NBI>::SUM + (e >> 5) * 2, bs); amax = fmaxf(amax, fabsf(bs)); }
+            if ((lane & 7) == 7) q16_put_sum<SH::NBI>(reinterpret_cast<char*>(xs) + Q16Img<SH::NBI>::SUM + (e >> 5) * 2, bs * (1.0f / Q16_SUM_DIV));
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
     }
@@ -1392,6 +1441,7 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
                 xn_att = tk_stage_q16<SH>(a.emb + (size_t)tok * SH::E, tk_rms_att(a, 0, SH::E), xraw, xs, lane, a.eps, sc_att, fits);   // :520, :527
                 if (!fits && !nosync) {      // an embedding row times its gains that no f16 holds: the same sticky word as a gather's (tk_coop_part)
                     if (lane == 0) __hip_atomic_store(a.err, 0x4000u + (e_q & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tk_evt_note(reinterpret_cast<unsigned*>(red8) + TK_EVT, e_q, lane);
                     ok = false;
                 }
             } else if (l == 0) {
@@ -1581,7 +1631,17 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = a.o0 + lane;
             tk_publish(tk_g_xa<SH>(a) + r, e_o, xraw[r] + v);
         }
-        if constexpr (SH::Q4) { if (!att_cu && lane == 0) red8[TK_XSC_B] = tk_next_scale(red8[TK_XSC_B], red8 + TK_AMX_B); }   // the next layer's xb image
+        if constexpr (SH::Q4) {      // the next layer's xb image: its own record of the position before, else from this layer's maximum
+            if (!att_cu && lane == 0) {
+                const float am = tk_amax_true(red8[TK_XSC_B], red8 + TK_AMX_B);
+                // (no record BEHIND a range event: from then on the images -- and every maximum taken from them -- are whatever the waves that
+                // gave up left in LDS.  The vector that raised the event itself is recorded -- its maximum is what the next position needs)
+                if (c == 1 && l < TK_QSC_LMAX && tk_rec_ok(red8, e_att)) {
+                    float4* rec = tk_qsc<SH>(a, pos) + l; rec->x = am; rec->z = __int_as_float(pos);
+                }
+                red8[TK_XSC_B] = tk_scale_for(tk_predict(am, tk_hist_amax(reinterpret_cast<const float4*>(lds + LD::QSC), l + 1, L, 0, pos)), red8[TK_XSC_B]);
+            }
+        }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 2, lane);
         // ---- P3: rmsnorm + w1|w3 + SwiGLU                                        llama2.f90:608-616
         float xn_ffn;
@@ -1643,7 +1703,15 @@ __device__ __forceinline__ void tk_service(const TokenArgs& a, char* lds, int c,
             const int r = (SH::Q4 ? tk_q4(a).d0 : c * SH::R_D) + lane;
             tk_publish(tk_g_x<SH>(a) + r, e_d, xraw[r] + v);
         }
-        if constexpr (SH::Q4) { if (lane == 0) red8[TK_XSC_H] = tk_next_scale(red8[TK_XSC_H], red8 + TK_AMX_H); }
+        if constexpr (SH::Q4) {
+            if (lane == 0) {
+                const float am = tk_amax_true(red8[TK_XSC_H], red8 + TK_AMX_H);
+                if (c == 1 && l < TK_QSC_LMAX && tk_rec_ok(red8, e_a)) {
+                    float4* rec = tk_qsc<SH>(a, pos) + l; rec->y = am; rec->w = __int_as_float(pos);
+                }
+                red8[TK_XSC_H] = tk_scale_for(tk_predict(am, tk_hist_amax(reinterpret_cast<const float4*>(lds + LD::QSC), l + 1, L, 1, pos)), red8[TK_XSC_H]);
+            }
+        }
         if (GF && SH::GF_PUB) tk_flag_set(gflag + 1, 4 * l + 4, lane);
         TK_STAMP(15);
     }
@@ -1947,8 +2015,21 @@ __global__ __launch_bounds__(TK_THREADS, 2) void token_kernel(TokenArgs a_in) {
             for (int i = SH::H / 32 * Q16_IMG_BLK + tid * 16; i < SH::NBI * Q16_IMG_BLK; i += TK_THREADS * 16)
                 *reinterpret_cast<uint4*>(img + i) = make_uint4(0u, 0u, 0u, 0u);
             for (int i = Q16Img<SH::NBI>::SUM + tid * 4; i < Q16Img<SH::NBI>::BYTES; i += TK_THREADS * 4) *reinterpret_cast<unsigned*>(img + i) = 0u;
-            // layer 0's xb / hb images: the largest element assumed in [1, 2) (TK_XSC_B; first read behind the QKV phase's barriers)
-            if (tid < 2) reinterpret_cast<float*>(lds + TkLds<SH>::RED8)[TK_XSC_B + tid] = TK_IMG_TARGET;
+            // the previous position's per-layer records (tk_qsc) into LDS, and layer 0's xb / hb scales: from its record, else the largest
+            // element assumed in [1, 2) (first read behind the QKV phase's barriers)
+            {
+                const int pos0 = a.tokpos ? a.tokpos[1] : a.pos_imm;
+                const float4* rec = tk_qsc<SH>(a, pos0 - 1);
+                float4* ql = reinterpret_cast<float4*>(lds + TkLds<SH>::QSC);
+                const int nrec = min(a.L, TK_QSC_LMAX);
+                for (int i = tid; i < nrec; i += TK_THREADS) ql[i] = rec[i];
+                if (tid == TK_NS * WAVE) reinterpret_cast<unsigned*>(lds + TkLds<SH>::RED8)[TK_EVT] = 0u;      // (the service wave: it may set the word in layer 0, before any barrier)
+                if (tid < 2) {
+                    const float4 r0 = rec[0];
+                    const bool hit = __float_as_int(tid ? r0.w : r0.z) == pos0 - 1;
+                    reinterpret_cast<float*>(lds + TkLds<SH>::RED8)[TK_XSC_B + tid] = hit ? tk_scale_for(tid ? r0.y : r0.x, TK_IMG_TARGET) : TK_IMG_TARGET;
+                }
+            }
         } else if constexpr (SH::H % SH::SEGW != 0) {
             // f32 / f16, ragged K = H rows: the staged hb vector is whole segments wide, the part behind H stays zero for the whole
             // launch (the gathers write H floats); first read behind the QKV phase's barriers

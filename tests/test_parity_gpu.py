@@ -569,6 +569,46 @@ def test_llama2_7b_q4_0_one_position_beyond_f16_is_redone_alone_and_the_kernel_s
     assert r.stderr.count(b"redone on the multi-kernel path, the kernel stays in use") == 1, r.stderr[-1500:]
 
 
+def test_llama2_7b_q4_0_activations_that_jump_between_layers_cost_one_position_not_the_kernel(gguf):
+    """Real Llama-2 has layers whose FFN activations are hundreds of times their neighbours' (and about the same from token to token).
+    The xb / hb images of the q4_0 persistent kernel are scaled from the SAME layer's vector of the position before (token_kernel.h
+    tk_qsc), the layer before being only the fallback: here layer 1's up rows carry 2^11 (its w2 2^-11), so under the layer-before
+    rule alone EVERY position would leave the f16 range at layer 1 and the kernel would be retired after four.  With the records only
+    position 1 (no position before it) is redone on the multi-kernel path; positions 2..10 run on the persistent kernel; all carry
+    the oracle's logits; a second pass over the same tokens is bit-identical (the choice of scale does not depend on timing)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "import llm_f90_amd\n"
+        "from llm_f90_amd import llmk\n"
+        "from llm_f90_amd.tools import gguf\n"
+        "from oracle.oracle import Oracle\n"
+        "from conftest import rel_err, REL_TOL\n"
+        "s = gguf.LlamaShape(4096, 11008, 3, 32, 32, 32000, 64)\n"
+        "fw = gguf.synth_fused(s, 7, 2)\n"
+        "H = s.hidden_dim\n"
+        "fw.w13 = fw.w13.copy(); fw.w13[1, H:] = gguf.scale_q4_0(fw.w13[1, H:], 2.0 ** 11)\n"
+        "fw.w2 = fw.w2.copy(); fw.w2[1] = gguf.scale_q4_0(fw.w2[1], 2.0 ** -11)\n"
+        "n = 10\n"
+        "ot, ol = Oracle(fw.as_f32(), 'omp').generate(n)\n"
+        "assert np.all(np.isfinite(ol))\n"
+        "m = llmk.Llmk(fw)\n"
+        "assert m.path() == 1\n"
+        "_, l = m.generate(n, prompt=ot.tolist())\n"
+        "assert m.path() == 1, 'the kernel was retired'\n"
+        "assert rel_err(l, ol).max() <= REL_TOL, rel_err(l, ol)\n"
+        "_, l2 = m.generate(n, prompt=ot.tolist())\n"
+        "assert np.array_equal(l, l2) and m.path() == 1\n"
+        "print('JUMP-OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600)
+    assert r.returncode == 0 and b"JUMP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stderr.count(b"redone on the multi-kernel path, the kernel stays in use") == 1, r.stderr[-1500:]      # (said once per context)
+
+
 @pytest.fixture(scope="module")
 def llama7b_q4_blocks(gguf):
     """the 3.7 GB of q4_0 blocks tests/golden/llama2-7b.npz was generated from (every block its own scale, some negative)"""
