@@ -67,6 +67,10 @@ SHAPES: Dict[str, LlamaShape] = {
     "tinyllama": LlamaShape(2048, 5632, 22, 32, 4, 32000, 2048),
     "llama2-7b": LlamaShape(4096, 11008, 32, 32, 32, 32000, 2048),
     "llama2-70b": LlamaShape(8192, 28672, 80, 64, 8, 32000, 2048),
+    # other Llama-architecture geometries (what one edits llama2.f90:102-108 to): the persistent kernel holds them when the library is
+    # built with them (make TK_SHAPES=...); the multi-kernel path runs them in any build
+    "mistral-7b": LlamaShape(4096, 14336, 32, 32, 8, 32000, 2048),
+    "llama3-8b": LlamaShape(4096, 14336, 32, 32, 8, 128256, 2048),
     # parity shapes (oracle / reference finish in milliseconds)
     "tiny-gqa": LlamaShape(128, 256, 2, 8, 2, 300, 64),      # hs 16, kv_mul 4
     "tiny-mha": LlamaShape(128, 352, 3, 4, 4, 512, 48),      # hs 32, kv_mul 1

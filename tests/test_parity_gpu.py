@@ -830,21 +830,33 @@ def test_tinyllama_q4_0_with_q6k_classifier_matches_oracle(gguf):
     assert top8_elementwise(l, ref=ol).max() <= REL_TOL
 
 
-def test_a_shape_added_at_build_time_runs_the_persistent_kernel_and_matches_oracle(gguf):
-    """`make TK_SHAPES="4096,14336,32,8,32000,WT_F16"` (the Makefile's own example: Mistral-7B's geometry -- grouped-query
-    attention at head size 128, K = H rows of 28 segments) adds a persistent-kernel instantiation without touching a source file.
-    Runs when the loaded library lists that shape (LLMK_LIB=... of such a build; the product build does not: skipped): 2 layers, 300
-    positions against the oracle on the decoded f16 weights, path() == 1."""
-    if (4096, 14336, 32, 8, 32000, "f16") not in llmk.tk_shapes():
-        pytest.skip("this build of libllmk.so has no persistent kernel for 4096,14336,32,8,32000,f16 (make TK_SHAPES=...)")
-    s = gguf.LlamaShape(4096, 14336, 2, 32, 8, 32000, 320)
-    fw = gguf.synth_fused(s, 7, 1)
-    n = 300
-    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
-    m = llmk.Llmk(fw)
-    assert m.path() == 1, m.path_name()
-    _, l = m.generate(n, prompt=ot.tolist())
-    m.close()
-    err = rel_err(l, ol)
-    assert err.max() <= REL_TOL, (err.max(), int(np.argmax(err)))
-    assert top8_elementwise(l, ref=ol).max() <= REL_TOL
+# the persistent-kernel shapes every build holds (csrc/llmk.hip LLMK_TK_SHAPES); anything else in llmk_tk_shapes() came from TK_SHAPES
+TK_BUILTIN = {(2048, 5632, 32, 4, 32000, "f32"), (256, 768, 4, 2, 1024, "f32"), (2048, 5632, 32, 4, 32000, "f16"), (512, 1536, 8, 2, 1024, "f16"),
+              (4096, 11008, 32, 32, 32000, "q4_0"), (2048, 5632, 32, 4, 32000, "q4_0"), (4096, 11008, 32, 32, 32000, "q4_0+q6_K"),
+              (2048, 5632, 32, 4, 32000, "q4_0+q6_K"), (4096, 11008, 32, 32, 32000, "f16")}
+
+
+def test_shapes_added_at_build_time_run_the_persistent_kernel_and_match_oracle(gguf):
+    """`make TK_SHAPES="4096,14336,32,8,32000,WT_F16 ..."` adds persistent-kernel instantiations without touching a source
+    file (the Makefile's own example: Mistral-7B's geometry -- grouped-query attention at head size 128, K = H rows of 28 segments).
+    For EVERY shape the loaded library lists beyond the built-in ones (LLMK_LIB=... of such a build; the product build has none:
+    skipped): 2 layers, 300 positions (3 attention parts) against the oracle on the decoded weights, path() == 1.
+    Round 6 ran it on Mistral-7B f16 / q4_0 + q6_K, a 128,256-entry vocabulary at both, and E 2048 / H 8192 f16 (profiles/README.md)."""
+    extra = [t for t in llmk.tk_shapes() if t not in TK_BUILTIN]
+    if not extra:
+        pytest.skip("this build of libllmk.so holds the built-in persistent-kernel shapes only (make TK_SHAPES=...)")
+    for E, H, NH, NKV, V, wt in extra:
+        s = gguf.LlamaShape(E, H, 2, NH, NKV, V, 320)
+        fw = gguf.synth_fused(s, 7, {"f32": 0, "f16": 1}.get(wt, 2))
+        if wt == "q4_0+q6_K":
+            fw = gguf.with_q6k_classifier(fw)
+        n = 300
+        ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+        m = llmk.Llmk(fw)
+        assert m.path() == 1, ((E, H, NH, NKV, V, wt), m.path_name())
+        _, l = m.generate(n, prompt=ot.tolist())
+        m.close()
+        err = rel_err(l, ol)
+        assert err.max() <= REL_TOL, ((E, H, NH, NKV, V, wt), err.max(), int(np.argmax(err)))
+        assert top8_elementwise(l, ref=ol).max() <= REL_TOL, (E, H, NH, NKV, V, wt)
+        print("build-time shape", (E, H, NH, NKV, V, wt), "max err", err.max())
