@@ -230,7 +230,9 @@ int llmk_time_kernel(llmk_ctx *ctx, int kernel, int iters, float *avg_ms, double
 
 /* Debug/verification: copy internal device vectors to the host. which: 0 = x (residual stream, E),
  * 1 = q (E), 2 = xb (attention output, E), 3 = hb (H), 4 = key_cache row [layer][pos-1] (KV),
- * 5 = value_cache row (KV). */
+ * 5 = value_cache row (KV); debugging aids: 6, 7 = the debug library's trace stamps and a prefill workspace, 8 = the q4_0
+ * persistent kernel's per-layer scale records of the last two positions ([2][128] x {max|xb|, max|hb|, pos, pos} as floats /
+ * int bits: tests/host_tools/qsc_dump.py; LLMK_E_ARG on a ctx without the persistent kernel). */
 int llmk_peek(llmk_ctx *ctx, int which, int layer, int pos, float *out, int n);
 
 /* Which implementation of the token pass this ctx runs RIGHT NOW (it can change: a timed-out persistent kernel retires

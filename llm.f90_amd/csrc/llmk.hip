@@ -410,7 +410,7 @@ hipError_t launch_token_kernel_t(llmk_ctx* c, bool direct, const TkGreedy& g) {
 #endif
 #define LLMK_TK_SHAPES(X)                                                                                          \
     X(TkTinyLlama) X(TkSmall) X(TkTinyLlamaF16) X(TkSmallF16) X(TkLlama7BQ4) X(TkTinyLlamaQ4) X(TkLlama7BQ4Q6)     \
-    X(TkTinyLlamaQ4Q6) X(TkLlama7BF16) LLMK_TK_EXTRA_SHAPES(X)
+    X(TkTinyLlamaQ4Q6) X(TkLlama7BF16) X(TkMistral7BQ4Q6) LLMK_TK_EXTRA_SHAPES(X)
 struct TkEntry {
     int E, H, NH, NKV, V, WT, CLS;
     bool q4;                                        // units layout (q16_build) before the first token

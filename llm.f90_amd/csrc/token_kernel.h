@@ -2054,5 +2054,8 @@ typedef TkShape<2048, 5632, 32, 4, 32000, WT_Q4_0, WT_Q6_K> TkTinyLlamaQ4Q6;
 // Llama-2-7B with f16 matrices (round 6: "any shape the reference could be recompiled for" -- K = E rows of 8 segments: one row
 // per tile, a 64-register x fragment; K = H rows end inside their 22nd segment)
 typedef TkShape<4096, 11008, 32, 32, 32000, WT_F16> TkLlama7BF16;
+// Mistral-7B's geometry (grouped-query attention at head size 128, K = H rows of 14,336) as a stock llama.cpp Q4_0 file holds it: the most
+// common 7B file after Llama-2's.  Everything else of that kind: make TK_SHAPES=... (llmk.hip LLMK_TK_SHAPES)
+typedef TkShape<4096, 14336, 32, 8, 32000, WT_Q4_0, WT_Q6_K> TkMistral7BQ4Q6;
 
 }  // namespace llmk

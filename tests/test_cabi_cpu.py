@@ -67,7 +67,8 @@ def test_tk_shapes_lists_the_instantiated_shapes(lib):
     single-GPU configurations, the stock-file q6_K variants and Llama-2-7B f16 (round 6) must be there; a short buffer is an error."""
     shapes = llmk.tk_shapes()
     for want in [(2048, 5632, 32, 4, 32000, "f32"), (2048, 5632, 32, 4, 32000, "f16"), (4096, 11008, 32, 32, 32000, "q4_0"),
-                 (4096, 11008, 32, 32, 32000, "q4_0+q6_K"), (2048, 5632, 32, 4, 32000, "q4_0+q6_K"), (4096, 11008, 32, 32, 32000, "f16")]:
+                 (4096, 11008, 32, 32, 32000, "q4_0+q6_K"), (2048, 5632, 32, 4, 32000, "q4_0+q6_K"), (4096, 11008, 32, 32, 32000, "f16"),
+                 (4096, 14336, 32, 8, 32000, "q4_0+q6_K")]:
         assert want in shapes, (want, shapes)
     small = C.create_string_buffer(8)
     assert lib.llmk_tk_shapes(small, 8) != 0

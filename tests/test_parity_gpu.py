@@ -833,7 +833,31 @@ def test_tinyllama_q4_0_with_q6k_classifier_matches_oracle(gguf):
 # the persistent-kernel shapes every build holds (csrc/llmk.hip LLMK_TK_SHAPES); anything else in llmk_tk_shapes() came from TK_SHAPES
 TK_BUILTIN = {(2048, 5632, 32, 4, 32000, "f32"), (256, 768, 4, 2, 1024, "f32"), (2048, 5632, 32, 4, 32000, "f16"), (512, 1536, 8, 2, 1024, "f16"),
               (4096, 11008, 32, 32, 32000, "q4_0"), (2048, 5632, 32, 4, 32000, "q4_0"), (4096, 11008, 32, 32, 32000, "q4_0+q6_K"),
-              (2048, 5632, 32, 4, 32000, "q4_0+q6_K"), (4096, 11008, 32, 32, 32000, "f16")}
+              (2048, 5632, 32, 4, 32000, "q4_0+q6_K"), (4096, 11008, 32, 32, 32000, "f16"), (4096, 14336, 32, 8, 32000, "q4_0+q6_K")}
+
+
+def _two_layers_of(gguf, E, H, NH, NKV, V, wt, n=300):
+    """2 layers of a geometry at its real column sizes, n positions against the oracle on the decoded weights; path() == 1"""
+    s = gguf.LlamaShape(E, H, 2, NH, NKV, V, n + 20)
+    fw = gguf.synth_fused(s, 7, {"f32": 0, "f16": 1}.get(wt, 2))
+    if wt == "q4_0+q6_K":
+        fw = gguf.with_q6k_classifier(fw)
+    ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
+    m = llmk.Llmk(fw)
+    assert m.path() == 1, ((E, H, NH, NKV, V, wt), m.path_name())
+    _, l = m.generate(n, prompt=ot.tolist())
+    m.close()
+    err = rel_err(l, ol)
+    assert err.max() <= REL_TOL, ((E, H, NH, NKV, V, wt), err.max(), int(np.argmax(err)))
+    assert top8_elementwise(l, ref=ol).max() <= REL_TOL, (E, H, NH, NKV, V, wt)
+    return err.max()
+
+
+def test_mistral_7b_geometry_q4_0_with_q6k_classifier_runs_the_persistent_kernel(gguf):
+    """The built-in instantiation for a stock Mistral-7B Q4_0 file (token_kernel.h TkMistral7BQ4Q6): grouped-query attention at head
+    size 128 (4 query heads per kv head: the K / V rows of a group on one XCD), K = H rows of 448 blocks = 14 units.  2 layers, 300
+    positions (three attention parts) against the oracle."""
+    _two_layers_of(gguf, 4096, 14336, 32, 8, 32000, "q4_0+q6_K")
 
 
 def test_shapes_added_at_build_time_run_the_persistent_kernel_and_match_oracle(gguf):
@@ -846,17 +870,5 @@ def test_shapes_added_at_build_time_run_the_persistent_kernel_and_match_oracle(g
     if not extra:
         pytest.skip("this build of libllmk.so holds the built-in persistent-kernel shapes only (make TK_SHAPES=...)")
     for E, H, NH, NKV, V, wt in extra:
-        s = gguf.LlamaShape(E, H, 2, NH, NKV, V, 320)
-        fw = gguf.synth_fused(s, 7, {"f32": 0, "f16": 1}.get(wt, 2))
-        if wt == "q4_0+q6_K":
-            fw = gguf.with_q6k_classifier(fw)
-        n = 300
-        ot, ol = Oracle(fw.as_f32(), "omp").generate(n)
-        m = llmk.Llmk(fw)
-        assert m.path() == 1, ((E, H, NH, NKV, V, wt), m.path_name())
-        _, l = m.generate(n, prompt=ot.tolist())
-        m.close()
-        err = rel_err(l, ol)
-        assert err.max() <= REL_TOL, ((E, H, NH, NKV, V, wt), err.max(), int(np.argmax(err)))
-        assert top8_elementwise(l, ref=ol).max() <= REL_TOL, (E, H, NH, NKV, V, wt)
-        print("build-time shape", (E, H, NH, NKV, V, wt), "max err", err.max())
+        emax = _two_layers_of(gguf, E, H, NH, NKV, V, wt)
+        print("build-time shape", (E, H, NH, NKV, V, wt), "max err", emax)
