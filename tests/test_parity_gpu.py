@@ -603,6 +603,14 @@ def test_llama2_7b_q4_0_activations_that_jump_between_layers_cost_one_position_n
         "assert rel_err(l, ol).max() <= REL_TOL, rel_err(l, ol)\n"
         "_, l2 = m.generate(n, prompt=ot.tolist())\n"
         "assert np.array_equal(l, l2) and m.path() == 1\n"
+        # the pipelined greedy loop over the same event: the launches queued behind position 1 drain on the sticky word, the call goes on
+        # position by position (llmk_decode_greedy), the ids are the oracle's up to its first near-tie, the kernel stays
+        "srt = np.sort(ol, axis=1); safe = (srt[:, -1] - srt[:, -2]) > 4 * REL_TOL * np.abs(ol).max(axis=1)\n"
+        "k = n if safe.all() else int(np.argmin(safe))\n"
+        "m.reset()\n"
+        "ids = m.decode_greedy(2, 1, k) if k else []\n"
+        "assert np.array_equal(ids, ot[:k]) and m.path() == 1, (ids, ot[:k])\n"
+        "print('greedy positions', k)\n"
         "print('JUMP-OK')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=600)
     assert r.returncode == 0 and b"JUMP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
