@@ -49,10 +49,16 @@ template <class T>
 hipError_t dev_alloc(T** p, size_t bytes) {
     static const bool poison = getenv("LLMK_POISON") && getenv("LLMK_POISON")[0] == '1';
     hipError_t e = hipMalloc((void**)p, bytes);
-    // (the fill runs on the null stream and hipMemset of device memory need not block the host; the shim's own initialisation often
-    // goes to the ctx's NON-BLOCKING stream, which the null stream does not order: without the wait the fill could land AFTER it --
-    // round 6's poison run: the self-test's mismatch counter read 0xFFFFFFFF on three ranks)
-    if (e == hipSuccess && poison) { e = hipMemset(*p, 0xFF, bytes); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+    // (the fill must be COMPLETE when this returns: the shim's own initialisation often goes to the ctx's non-blocking stream, which the
+    // null stream does not order -- round 6's first poison run: the self-test's mismatch counter read 0xFFFFFFFF on three ranks.  And it
+    // must not wait for the DEVICE: with two ranks in one process a rank's kernel may be spinning for its peer, whose host thread is
+    // in here -- the second poison run.  So: a stream of its own for the calling thread, and a wait for that stream alone)
+    if (e == hipSuccess && poison) {
+        static thread_local hipStream_t ps = nullptr;
+        if (!ps) e = hipStreamCreateWithFlags(&ps, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemsetAsync(*p, 0xFF, bytes, ps);
+        if (e == hipSuccess) e = hipStreamSynchronize(ps);
+    }
     return e;
 }
 
@@ -84,6 +90,7 @@ struct llmk_ctx {
     ncclComm_t comm = nullptr;
     // one-shot peer-memory collectives (tp_p2p.h): this rank's inbox (fine-grained HBM) and the peers' as mapped here
     unsigned long long* d_inbox = nullptr;
+    unsigned* d_tp_bad = nullptr;         // the self-test's mismatch counter (allocated with the inbox: see tp_selftest_run)
     TpPeers peers = {};
     void* ipc_mapped[TP_MAX_RANKS] = {};
     bool p2p = false;
@@ -1556,6 +1563,10 @@ int llmk_prefill(llmk_ctx* c, const int* tokens, int n, int pos0, float* logits_
     std::vector<int> tok0(tokens, tokens + n);
     for (int& t : tok0) --t;
     HIPCHK(hipMemcpyAsync(c->pf_tok, tok0.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    // these positions are being rewritten by other kernels: whatever an earlier sequence's decode left in the q4_0 persistent kernel's
+    // scale records (token_kernel.h tk_qsc; tagged by position only) must not pass for "the position before" of the decode that follows
+    if (c->d_gran && c->tk_ngran)
+        HIPCHK(hipMemsetAsync(c->d_gran + c->tk_ngran - 4 * TK_QSC_LMAX, 0, 4 * TK_QSC_LMAX * sizeof(unsigned long long), c->stream));
     HIPCHK(hipEventRecord(c->pf_start, c->stream));
     HIPCHK(hipStreamWaitEvent(c->pf[1].stream, c->pf_start, 0));
     int k = 0;
@@ -1888,6 +1899,7 @@ static int tp_inbox_alloc(llmk_ctx* c) {
     // fine-grained: peers' stores over xGMI and this device's system-scope polls meet in memory, not in a stale L2 line
     HIPCHK(hipExtMallocWithFlags((void**)&c->d_inbox, bytes, hipDeviceMallocFinegrained));
     HIPCHK(hipMemset(c->d_inbox, 0, bytes));      // tag 0 is never a valid epoch
+    HIPCHK(dev_alloc(&c->d_tp_bad, sizeof(unsigned)));
     HIPCHK(hipDeviceSynchronize());
     c->peers.inbox[c->tp_rank] = c->d_inbox;
     // bound of every spin of the exchange kernels in WALL-CLOCK ticks (tp_p2p.h): 20 s unless LLMK_TP_TIMEOUT_MS says otherwise
@@ -1973,8 +1985,10 @@ static int tp_selftest_run(llmk_ctx* c, int iters, unsigned jseed) {
     if (!c || iters < 1) return LLMK_E_ARG;
     if (!c->p2p) return LLMK_E_COMM;
     HIPCHK(hipSetDevice(c->cfg.device));
-    unsigned* d_bad = nullptr;
-    HIPCHK(dev_alloc(&d_bad, sizeof(unsigned)));
+    // (no allocation and no hipFree in here: with two ranks in one process a peer's kernel may already be spinning for this rank, and
+    // an allocation's fill -- LLMK_POISON -- or a free's device-wide wait queues behind it: round 6's poison runs, 2 x 20 s of timeouts)
+    unsigned* d_bad = c->d_tp_bad;
+    if (!d_bad) return LLMK_E_COMM;
     HIPCHK(hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream));
     const int n = std::max(c->E, c->V);
     int rc = LLMK_OK;
@@ -2014,7 +2028,6 @@ static int tp_selftest_run(llmk_ctx* c, int iters, unsigned jseed) {
         else if (err) rc = LLMK_E_TIMEOUT;
         else if (bad) rc = LLMK_E_COMM;
     }
-    hipFree(d_bad);
     // leave the ctx as a fresh one: x, the logits and the sticky word
     hipMemsetAsync(c->d_x, 0, (size_t)c->E * sizeof(float), c->stream);
     hipMemsetAsync(c->d_logits, 0, ((size_t)c->V + 4) * sizeof(float), c->stream);
@@ -2177,6 +2190,7 @@ int llmk_destroy(llmk_ctx* c) {
     for (int r = 0; r < TP_MAX_RANKS; ++r)
         if (c->ipc_mapped[r]) hipIpcCloseMemHandle(c->ipc_mapped[r]);
     if (c->d_inbox) hipFree(c->d_inbox);
+    if (c->d_tp_bad) hipFree(c->d_tp_bad);
     if (c->graph_logits) hipGraphExecDestroy(c->graph_logits);
     if (c->graph_greedy) hipGraphExecDestroy(c->graph_greedy);
     for (int i = 0; i < LLMK_N_TENSORS; ++i) {
