@@ -14,16 +14,17 @@ import sys
 
 pkg = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "llm.f90_amd")
 defs = [a for a in sys.argv[1:] if a.startswith("-D")]
-r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-c", "csrc/llmk.hip",
-                    "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + defs, cwd=pkg, capture_output=True, text=True)
+# ONE device-only compilation gives both: the resource remarks on stderr, the ISA on stdout (two compilations of llmk.hip made this the
+# slowest test of the CPU suite by far)
+r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only", "csrc/llmk.hip",
+                    "-o", "-", "-Rpass-analysis=kernel-resource-usage"] + defs, cwd=pkg, capture_output=True, text=True)
 if r.returncode:
     sys.exit(r.stderr[-3000:])
+ISA = r.stdout
 def scratch_in_loops():
     """kernel symbol -> (scratch instructions inside loops, scratch instructions in all)"""
-    a = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only",
-                        "csrc/llmk.hip", "-o", "-"] + defs, cwd=pkg, capture_output=True, text=True)
     out, cur, inloop = {}, None, False
-    for line in a.stdout.split("\n"):
+    for line in ISA.split("\n"):
         t = line.strip()
         if line.startswith("_ZN") and t.endswith(":") is False and ":" in line and not line.startswith(" "):
             cur = line.split(":")[0]
@@ -39,10 +40,8 @@ def scratch_in_loops():
 
 def lds64():
     """kernel symbol -> (ds_read_b64, ds_write_b64) instruction counts"""
-    a = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-S", "--cuda-device-only",
-                        "csrc/llmk.hip", "-o", "-"] + defs, cwd=pkg, capture_output=True, text=True)
     out, cur = {}, None
-    for line in a.stdout.split("\n"):
+    for line in ISA.split("\n"):
         if line.startswith("_ZN") and ":" in line and not line.startswith(" "):
             cur = line.split(":")[0]
             out[cur] = [0, 0]
